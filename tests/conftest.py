@@ -1,0 +1,52 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_ROOT = os.path.join(REPO, 'tts-arabic-pytorch_amd')
+for p in (PKG_ROOT, os.path.join(REPO, 'oracle'), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import numpy as np
+
+    def load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    return load
+
+
+@pytest.fixture(scope='session')
+def synth_weights():
+    """Synthetic weights + a check that they are the very tensors the goldens were made with."""
+    import hashlib
+    import json
+    import numpy as np
+    from ttsamd import synth
+    from ttsamd.config import NET_CONFIG
+
+    def digest(sd):
+        h = hashlib.sha256()
+        for k in sorted(sd):
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(sd[k]).tobytes())
+        return h.hexdigest()
+
+    with open(os.path.join(GOLDEN, 'digests.json')) as f:
+        want = json.load(f)
+    fp = synth.fastpitch_state_dict()
+    hg = synth.hifigan_state_dict()
+    fp4 = synth.fastpitch_state_dict(dict(NET_CONFIG, n_speakers=4))
+    assert digest(fp) == want['fastpitch_seed0'], 'synthetic FastPitch weights differ from the golden run'
+    assert digest(hg) == want['hifigan_seed0'], 'synthetic HiFi-GAN weights differ from the golden run'
+    assert digest(fp4) == want['fastpitch_spk4_seed0']
+    return {'fastpitch': fp, 'hifigan': hg, 'fastpitch_spk4': fp4}

@@ -1,0 +1,42 @@
+"""Model hyper-parameters of the hot path.
+
+`NET_CONFIG` mirrors the reference default (models/fastpitch/__init__.py:3-41) and
+`HIFIGAN_CONFIG` the shipped vocoder json (pretrained/hifigan-asc-v1/config.json:1-24);
+they are data, restated here because the reference tree does not travel.
+"""
+
+NET_CONFIG = {
+    'n_mel_channels': 80, 'n_symbols': 148, 'padding_idx': 0,
+    'symbols_embedding_dim': 384,
+    'in_fft_n_layers': 6, 'in_fft_n_heads': 1, 'in_fft_d_head': 64,
+    'in_fft_conv1d_kernel_size': 3, 'in_fft_conv1d_filter_size': 1536,
+    'in_fft_output_size': 384,
+    'p_in_fft_dropout': 0.1, 'p_in_fft_dropatt': 0.1, 'p_in_fft_dropemb': 0.0,
+    'out_fft_n_layers': 6, 'out_fft_n_heads': 1, 'out_fft_d_head': 64,
+    'out_fft_conv1d_kernel_size': 3, 'out_fft_conv1d_filter_size': 1536,
+    'out_fft_output_size': 384,
+    'p_out_fft_dropout': 0.1, 'p_out_fft_dropatt': 0.1, 'p_out_fft_dropemb': 0.0,
+    'dur_predictor_kernel_size': 3, 'dur_predictor_filter_size': 256,
+    'p_dur_predictor_dropout': 0.1, 'dur_predictor_n_layers': 2,
+    'pitch_predictor_kernel_size': 3, 'pitch_predictor_filter_size': 256,
+    'p_pitch_predictor_dropout': 0.1, 'pitch_predictor_n_layers': 2,
+    'pitch_embedding_kernel_size': 3,
+    'n_speakers': 1, 'speaker_emb_weight': 1.0,
+    'energy_predictor_kernel_size': 3, 'energy_predictor_filter_size': 256,
+    'p_energy_predictor_dropout': 0.1, 'energy_predictor_n_layers': 2,
+    'energy_conditioning': True, 'energy_embedding_kernel_size': 3,
+}
+
+HIFIGAN_CONFIG = {
+    'resblock': '1',
+    'upsample_rates': [8, 8, 2, 2],
+    'upsample_kernel_sizes': [16, 16, 4, 4],
+    'upsample_initial_channel': 512,
+    'resblock_kernel_sizes': [3, 7, 11],
+    'resblock_dilation_sizes': [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    'num_mels': 80, 'n_fft': 1024, 'hop_size': 256, 'win_size': 1024,
+    'sampling_rate': 22050,
+}
+
+SAMPLE_RATE = 22050
+HOP = 256

@@ -1,0 +1,150 @@
+"""Deterministic synthetic weights / inputs (no pretrained weights exist in the
+reference tree: pretrained/ holds only hifigan-asc-v1/config.json, download_files.py:7-53
+needs the network).  A counter-based generator keyed by (seed, crc32(tensor name)) so the
+same tensors are reproduced bit-identically in the build container (where they are loaded
+into the *reference* modules to make the golden fixtures) and on the GPU box.
+
+Keys follow the reference checkpoints exactly:
+  FastPitch  {'model': state_dict, 'config': net_config, 'symbols': [...]}
+             (models/fastpitch/networks.py:52-71)
+  HiFi-GAN   {'generator': weight-normed state_dict}            (vocoder/__init__.py:15-16)
+"""
+import zlib
+
+import numpy as np
+
+from .config import NET_CONFIG, HIFIGAN_CONFIG
+
+
+def _rng(seed, name):
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
+def _normal(seed, name, shape, std):
+    return (_rng(seed, name).standard_normal(shape) * std).astype(np.float32)
+
+
+def _fft_stack(sd, prefix, n_layers, d_model, d_head, n_head, d_inner, k, seed):
+    for i in range(n_layers):
+        p = f'{prefix}.layers.{i}.'
+        sd[p + 'dec_attn.qkv_net.weight'] = _normal(seed, p + 'qkv.w', (3 * n_head * d_head, d_model), 1.2 / np.sqrt(d_model))
+        sd[p + 'dec_attn.qkv_net.bias'] = _normal(seed, p + 'qkv.b', (3 * n_head * d_head,), 0.1)
+        sd[p + 'dec_attn.o_net.weight'] = _normal(seed, p + 'o.w', (d_model, n_head * d_head), 1.0 / np.sqrt(d_head))
+        sd[p + 'dec_attn.layer_norm.weight'] = 1.0 + _normal(seed, p + 'ln1.w', (d_model,), 0.1)
+        sd[p + 'dec_attn.layer_norm.bias'] = _normal(seed, p + 'ln1.b', (d_model,), 0.1)
+        sd[p + 'pos_ff.CoreNet.0.weight'] = _normal(seed, p + 'ff0.w', (d_inner, d_model, k), 1.0 / np.sqrt(d_model * k))
+        sd[p + 'pos_ff.CoreNet.0.bias'] = _normal(seed, p + 'ff0.b', (d_inner,), 0.1)
+        sd[p + 'pos_ff.CoreNet.2.weight'] = _normal(seed, p + 'ff2.w', (d_model, d_inner, k), 1.0 / np.sqrt(d_inner * k))
+        sd[p + 'pos_ff.CoreNet.2.bias'] = _normal(seed, p + 'ff2.b', (d_model,), 0.1)
+        sd[p + 'pos_ff.layer_norm.weight'] = 1.0 + _normal(seed, p + 'ln2.w', (d_model,), 0.1)
+        sd[p + 'pos_ff.layer_norm.bias'] = _normal(seed, p + 'ln2.b', (d_model,), 0.1)
+
+
+def _predictor(sd, prefix, d_in, d_f, k, n_layers, seed, fc_bias):
+    for i in range(n_layers):
+        p = f'{prefix}.layers.{i}.'
+        cin = d_in if i == 0 else d_f
+        sd[p + 'conv.weight'] = _normal(seed, p + 'conv.w', (d_f, cin, k), 1.4 / np.sqrt(cin * k))
+        sd[p + 'conv.bias'] = _normal(seed, p + 'conv.b', (d_f,), 0.1)
+        sd[p + 'norm.weight'] = 1.0 + _normal(seed, p + 'norm.w', (d_f,), 0.1)
+        sd[p + 'norm.bias'] = _normal(seed, p + 'norm.b', (d_f,), 0.1)
+    sd[prefix + '.fc.weight'] = _normal(seed, prefix + '.fc.w', (1, d_f), 0.3 / np.sqrt(d_f))
+    sd[prefix + '.fc.bias'] = np.full((1,), fc_bias, np.float32)
+
+
+def fastpitch_state_dict(config=None, seed=0):
+    """name -> np.float32 array, same keys/shapes as reference FastPitch.state_dict()
+    minus the training-only `attention.*` sub-module (models/fastpitch/fastpitch/model.py:234)."""
+    c = dict(NET_CONFIG if config is None else config)
+    d = c['symbols_embedding_dim']
+    sd = {}
+    sd['pitch_mean'] = np.zeros((1,), np.float32)
+    sd['pitch_std'] = np.zeros((1,), np.float32)
+    emb = _normal(seed, 'encoder.word_emb', (c['n_symbols'], d), 1.0)
+    emb[c['padding_idx']] = 0.0
+    sd['encoder.word_emb.weight'] = emb
+    inv_freq = _inv_freq(d)
+    sd['encoder.pos_emb.inv_freq'] = inv_freq
+    _fft_stack(sd, 'encoder', c['in_fft_n_layers'], d, c['in_fft_d_head'], c['in_fft_n_heads'],
+               c['in_fft_conv1d_filter_size'], c['in_fft_conv1d_kernel_size'], seed)
+    _predictor(sd, 'duration_predictor', c['in_fft_output_size'], c['dur_predictor_filter_size'],
+               c['dur_predictor_kernel_size'], c['dur_predictor_n_layers'], seed, float(np.log(8.0)))
+    sd['decoder.pos_emb.inv_freq'] = inv_freq.copy()
+    _fft_stack(sd, 'decoder', c['out_fft_n_layers'], d, c['out_fft_d_head'], c['out_fft_n_heads'],
+               c['out_fft_conv1d_filter_size'], c['out_fft_conv1d_kernel_size'], seed)
+    _predictor(sd, 'pitch_predictor', c['in_fft_output_size'], c['pitch_predictor_filter_size'],
+               c['pitch_predictor_kernel_size'], c['pitch_predictor_n_layers'], seed, 0.0)
+    kp = c['pitch_embedding_kernel_size']
+    sd['pitch_emb.weight'] = _normal(seed, 'pitch_emb.w', (d, 1, kp), 0.3)
+    sd['pitch_emb.bias'] = _normal(seed, 'pitch_emb.b', (d,), 0.1)
+    if c['energy_conditioning']:
+        _predictor(sd, 'energy_predictor', c['in_fft_output_size'], c['energy_predictor_filter_size'],
+                   c['energy_predictor_kernel_size'], c['energy_predictor_n_layers'], seed, 0.0)
+        ke = c['energy_embedding_kernel_size']
+        sd['energy_emb.weight'] = _normal(seed, 'energy_emb.w', (d, 1, ke), 0.3)
+        sd['energy_emb.bias'] = _normal(seed, 'energy_emb.b', (d,), 0.1)
+    sd['proj.weight'] = _normal(seed, 'proj.w', (c['n_mel_channels'], c['out_fft_output_size']), 1.0 / np.sqrt(d))
+    sd['proj.bias'] = _normal(seed, 'proj.b', (c['n_mel_channels'],), 0.5)
+    if c['n_speakers'] > 1:
+        sd['speaker_emb.weight'] = _normal(seed, 'speaker_emb', (c['n_speakers'], d), 0.5)
+    return sd
+
+
+def _inv_freq(demb):
+    # models/fastpitch/fastpitch/transformer.py:37 — evaluated with torch so the buffer is
+    # bit-identical to what the reference module registers.
+    import torch
+    return (1 / (10000 ** (torch.arange(0.0, demb, 2.0) / demb))).numpy().astype(np.float32)
+
+
+def hifigan_state_dict(config=None, seed=0, weight_norm=True):
+    """Weight-normalised generator checkpoint (keys as torch>=2.1 parametrizations:
+    `<layer>.parametrizations.weight.original0` = g, `original1` = v; §3.4-6) or, with
+    weight_norm=False, the folded `<layer>.weight` form."""
+    h = dict(HIFIGAN_CONFIG if config is None else config)
+    sd = {}
+
+    def put(name, shape, fan_in, gain):
+        v = _normal(seed, name + '.v', shape, 1.0)
+        target = gain / np.sqrt(fan_in)                       # per-element std of folded w
+        nv = np.sqrt((v.astype(np.float64) ** 2).sum(axis=tuple(range(1, v.ndim)), keepdims=True))
+        n_per = np.prod(shape[1:])
+        g = (target * np.sqrt(n_per) * (1.0 + 0.1 * _rng(seed, name + '.g').standard_normal(nv.shape))).astype(np.float32)
+        if weight_norm:
+            sd[name + '.parametrizations.weight.original0'] = g
+            sd[name + '.parametrizations.weight.original1'] = v
+        else:
+            sd[name + '.weight'] = (g.astype(np.float64) * v / nv).astype(np.float32)
+        return g, v
+
+    c0 = h['upsample_initial_channel']
+    put('conv_pre', (c0, h['num_mels'], 7), h['num_mels'] * 7, 0.25)
+    sd['conv_pre.bias'] = _normal(seed, 'conv_pre.b', (c0,), 0.1)
+    ch = c0
+    for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+        cin, ch = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        # ConvTranspose1d weight is [Cin, Cout, k]; each output sample sees Cin*k/u taps
+        put(f'ups.{i}', (cin, ch, k), cin * k / u, 1.1)
+        sd[f'ups.{i}.bias'] = _normal(seed, f'ups.{i}.b', (ch,), 0.1)
+        for j, kk in enumerate(h['resblock_kernel_sizes']):
+            r = i * len(h['resblock_kernel_sizes']) + j
+            for m in range(len(h['resblock_dilation_sizes'][j])):
+                put(f'resblocks.{r}.convs1.{m}', (ch, ch, kk), ch * kk, 1.2)
+                sd[f'resblocks.{r}.convs1.{m}.bias'] = _normal(seed, f'rb{r}.c1.{m}.b', (ch,), 0.05)
+                put(f'resblocks.{r}.convs2.{m}', (ch, ch, kk), ch * kk, 0.6)
+                sd[f'resblocks.{r}.convs2.{m}.bias'] = _normal(seed, f'rb{r}.c2.{m}.b', (ch,), 0.05)
+    put('conv_post', (1, ch, 7), ch * 7, 0.4)
+    sd['conv_post.bias'] = _normal(seed, 'conv_post.b', (1,), 0.05)
+    return sd
+
+
+def synth_ids(batch, n_tokens, seed=1234):
+    """ids = 1 + rng mod 39 -> int64 [B, L] in [1, 39] (never padding_idx 0); SURVEY §8(d)."""
+    r = np.random.default_rng([int(seed), 1])
+    return (1 + r.integers(0, 39, size=(batch, n_tokens))).astype(np.int64)
+
+
+def synth_durations(batch, n_tokens, seed=1234):
+    """dur_tgt in [2, 12], mean 7 frames/token -> E[T_i] = 448 at 64 tokens; SURVEY §8(d)."""
+    r = np.random.default_rng([int(seed), 2])
+    return (2 + r.integers(0, 11, size=(batch, n_tokens))).astype(np.float32)
