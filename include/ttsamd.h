@@ -1,0 +1,154 @@
+/*
+ * ttsamd.h — C ABI of libttsamd.so: the MI355X (gfx950) FastPitch -> HiFi-GAN hot path.
+ *
+ * The reference (nipponjo/tts-arabic-pytorch) has no FFI/plugin interface; its boundary is
+ * the Python class surface models.fastpitch.FastPitch2Wave / FastPitch.
+ * Each entry point below replaces one reference *function* on that path and is what a
+ * ctypes binding inside the reference's own modules would call (INTEGRATION.md shows the
+ * stub).  Conventions:
+ *   - plain C types only; every data pointer is a DEVICE pointer (tensor.data_ptr()) to
+ *     contiguous row-major memory unless marked "host";
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     0/NULL = the default stream.  Calls are asynchronous on that stream;
+ *   - return 0 on success, a negative TTSAMD_E* code otherwise; ttsamd_last_error()
+ *     returns a thread-local message;
+ *   - no hidden device allocation on hot calls: the caller passes a workspace sized by the
+ *     matching *_workspace_bytes query.  Handles are immutable after create, so concurrent
+ *     calls with distinct workspaces/streams are allowed.
+ */
+#ifndef TTSAMD_H
+#define TTSAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTSAMD_OK 0
+#define TTSAMD_EINVAL (-1)   /* bad argument / shape / missing tensor */
+#define TTSAMD_EHIP (-2)     /* HIP runtime error */
+#define TTSAMD_ENOMEM (-3)   /* workspace too small / allocation failure */
+
+/* One named host tensor of a checkpoint (fp32, row-major).  Names are the reference's
+ * state_dict keys (models/fastpitch/networks.py:52-71; vocoder/__init__.py:15-16). */
+typedef struct ttsamd_tensor {
+    const char* name;
+    const float* data;   /* host */
+    int32_t ndim;
+    int64_t shape[4];
+} ttsamd_tensor;
+
+/* pretrained/hifigan-asc-v1/config.json:2,11-15 */
+typedef struct ttsamd_hifigan_cfg {
+    int32_t num_mels;                 /* 80 */
+    int32_t upsample_initial_channel; /* 512 */
+    int32_t n_ups;                    /* 4 */
+    int32_t upsample_rates[8];        /* 8,8,2,2 */
+    int32_t upsample_kernel_sizes[8]; /* 16,16,4,4 */
+    int32_t n_kernels;                /* 3 resblocks per stage */
+    int32_t resblock_kernel_sizes[8]; /* 3,7,11 */
+    int32_t n_dilations;              /* 3 */
+    int32_t resblock_dilations[8][8]; /* (1,3,5) each */
+} ttsamd_hifigan_cfg;
+
+/* models/fastpitch/__init__.py:3-41 (net_config), only the fields inference reads */
+typedef struct ttsamd_fastpitch_cfg {
+    int32_t n_mel_channels;   /* 80 */
+    int32_t n_symbols;        /* 148 */
+    int32_t padding_idx;      /* 0 */
+    int32_t d_model;          /* symbols_embedding_dim 384 */
+    int32_t in_fft_n_layers, in_fft_n_heads, in_fft_d_head, in_fft_kernel, in_fft_filter;
+    int32_t out_fft_n_layers, out_fft_n_heads, out_fft_d_head, out_fft_kernel, out_fft_filter;
+    int32_t dur_kernel, dur_filter, dur_n_layers;
+    int32_t pitch_kernel, pitch_filter, pitch_n_layers, pitch_emb_kernel;
+    int32_t energy_conditioning, energy_kernel, energy_filter, energy_n_layers, energy_emb_kernel;
+    int32_t n_speakers;
+    float speaker_emb_weight;
+} ttsamd_fastpitch_cfg;
+
+const char* ttsamd_last_error(void);
+int32_t ttsamd_version(void);
+/* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
+int32_t ttsamd_device_ok(void);
+
+/* ---- HiFi-GAN generator: replaces vocoder.load_hifigan + Generator.forward
+ *      (vocoder/__init__.py:3-20, vocoder/hifigan/models.py:86-136) ------------------- */
+
+/* Accepts weight-normalised checkpoints (`*.parametrizations.weight.original0/1`,
+ * `*.weight_g/_v`) and folded ones (`*.weight`); folds w = g*v/||v|| (norm over all dims
+ * but 0) on the host exactly as remove_weight_norm does (models.py:129-136). */
+int32_t ttsamd_hifigan_create(const ttsamd_tensor* weights, int32_t n_weights,
+                              const ttsamd_hifigan_cfg* cfg, void** handle);
+int32_t ttsamd_hifigan_destroy(void* handle);
+int64_t ttsamd_hifigan_workspace_bytes(void* handle, int32_t batch, int32_t t_max);
+/* mel  [B][num_mels][t_max] (frames >= lens[b] are ignored), lens int64 [B] or NULL (all
+ * t_max).  wave [B][hop*t_max]; samples >= hop*lens[b] are left untouched.  Every layer
+ * zero-pads at the TRUE utterance edge, i.e. utterance b's result equals the reference's
+ * unbatched Generator.forward(mel[b,:,:lens[b]]) (models/fastpitch/networks.py:340-341). */
+int32_t ttsamd_hifigan_forward(void* handle, const float* mel, const int64_t* lens,
+                               int32_t batch, int32_t t_max, float* wave,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- FastPitch.infer split at its one data-dependent size (dec_lens):
+ *      models/fastpitch/fastpitch/model.py:351-409 ------------------------------------ */
+
+int32_t ttsamd_fastpitch_create(const ttsamd_tensor* weights, int32_t n_weights,
+                                const ttsamd_fastpitch_cfg* cfg, void** handle);
+int32_t ttsamd_fastpitch_destroy(void* handle);
+int64_t ttsamd_fastpitch_encode_workspace_bytes(void* handle, int32_t batch, int32_t n_tokens);
+int64_t ttsamd_fastpitch_decode_workspace_bytes(void* handle, int32_t batch, int32_t t_max);
+
+/* Phase A (model.py:355-399 + the integer half of regulate_len :68-76).
+ * ids int64 [B][L], zero-padded at the END of each row (text_collate_fn,
+ * models/fastpitch/networks.py:16-35).  dur_tgt [B][L] / pitch_tgt [B][1][L] /
+ * energy_tgt [B][1][L] may be NULL (use predictions).  pitch_mul/pitch_add apply the
+ * reference's pitch_trf (networks.py:38-42) when != (1,0).
+ * Outputs: enc_cond [B][d_model][L] (CHANNEL-FIRST conditioned encoder output, the input
+ * of ttsamd_length_regulate), dur_pred [B][L], pitch_pred [B][1][L], energy_pred [B][L],
+ * reps int64 [B][L] = (dur/pace+0.5).long(), dec_lens int64 [B].  The host reads
+ * dec_lens (the reference syncs here too, model.py:76) to size phase B. */
+int32_t ttsamd_fastpitch_encode(void* handle, const int64_t* ids, int32_t batch, int32_t n_tokens,
+                                int32_t speaker, float pace, const float* dur_tgt,
+                                const float* pitch_tgt, const float* energy_tgt,
+                                float pitch_mul, float pitch_add, float max_duration,
+                                float* enc_cond, float* dur_pred, float* pitch_pred,
+                                float* energy_pred, int64_t* reps, int64_t* dec_lens,
+                                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Float half of regulate_len (model.py:77-85) as a gather instead of the reference's
+ * one-hot matmul: out[b][c][t] = enc[b][c][j] with cumsum[j] <= t < cumsum[j+1], zero for
+ * t >= dec_len.  enc [B][C][L], reps int64 [B][L], out [B][C][t_max], idx int32 [B][t_max]
+ * (token index per frame, -1 past the end) may be NULL.  Bit-exact indices. */
+int32_t ttsamd_length_regulate(const float* enc, const int64_t* reps, int32_t batch,
+                               int32_t n_tokens, int32_t channels, int32_t t_max,
+                               float* out, int32_t* idx, void* stream);
+
+/* Phase B (model.py:405-408): decoder FFT + proj.  x [B][d_model][t_max] channel-first
+ * (output of ttsamd_length_regulate; clobbered), dec_lens int64 [B], mel [B][80][t_max]. */
+int32_t ttsamd_fastpitch_decode(void* handle, float* x, const int64_t* dec_lens, int32_t batch,
+                                int32_t t_max, float* mel, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+
+/* ---- kernel-level entry used by the parity tests and the roofline bench ------------- */
+
+/* One Conv1d through the implicit-GEMM MFMA kernel: y = conv1d(lrelu_slope(x), w) + b.
+ * x [B][Cin][Lin], w [Cout][Cin][K] (torch layout, DEVICE), y [B][Cout][Lin] ("same"
+ * padding (K*dil-dil)/2), lens int64 [B] or NULL.  Allocates nothing; `packed` must hold
+ * ttsamd_conv1d_packed_floats(Cout,Cin,K) floats of scratch for the re-laid-out weights. */
+int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k);
+int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const int64_t* lens,
+                      int32_t batch, int32_t cin, int32_t cout, int32_t k, int32_t dilation,
+                      int32_t lin, float in_slope, int32_t relu_out, float* y, float* packed,
+                      void* stream);
+
+/* Timing hooks for bench.py (roofline of the dominant kernel): when enabled, hifigan
+ * forward brackets its ResBlock conv launches with HIP events on the launch stream. */
+int32_t ttsamd_profile_enable(int32_t on);
+/* Fills: [0]=sum of conv-kernel ms, [1]=number of conv launches, [2]=conv GFLOP (algorithmic) */
+int32_t ttsamd_profile_read(double* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTSAMD_H */

@@ -1,0 +1,167 @@
+"""GPU parity (pytest -m gpu): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs and against the committed reference goldens.
+Tolerances (BASELINE.json north_star): mel 1e-3 max-abs, waveform 1e-4 max-abs,
+length-regulator indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL = 1e-3
+WAVE_TOL = 1e-4
+
+
+def maxabs(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    from ttsamd import lib
+    assert lib.load().ttsamd_device_ok() == 1
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('cin,cout,k,dil,lin,B', [
+    (32, 32, 3, 1, 300, 2), (32, 32, 11, 5, 1000, 2), (64, 64, 7, 3, 777, 3), (128, 128, 11, 5, 515, 2),
+    (256, 256, 3, 1, 130, 2), (80, 512, 7, 1, 40, 2), (384, 1536, 3, 1, 64, 3), (1536, 384, 3, 1, 100, 2),
+    (384, 192, 1, 1, 64, 2), (64, 384, 1, 1, 33, 2), (384, 80, 1, 1, 200, 2), (384, 256, 3, 1, 16, 3),
+    (16, 32, 3, 1, 1, 1),
+])
+def test_conv1d_kernel(dev, cin, cout, k, dil, lin, B):
+    """One MFMA conv launch vs torch's fp32 conv on the CPU; ragged lengths, leaky-relu on load."""
+    from ttsamd.engine import conv1d
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k)
+    x = torch.randn(B, cin, lin, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    lens = torch.tensor([lin, max(1, lin - 7), max(1, lin // 2)][:B], dtype=torch.int64)
+    y = conv1d(x.to(dev), w.to(dev), b.to(dev), lens.to(dev), dilation=dil, in_slope=0.1).cpu()
+    for i in range(B):
+        n = int(lens[i])
+        ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x[i:i + 1, :, :n], 0.1), w, b,
+                                         dilation=dil, padding=(k * dil - dil) // 2)[0]
+        assert maxabs(y[i, :, :n], ref) < 2e-5, (i, n)
+        assert float(y[i, :, n:].abs().max()) == 0.0 if n < lin else True
+
+
+def test_length_regulate_exact(dev, golden):
+    import tts_oracle as O
+    from ttsamd.engine import length_regulate
+    g = golden('regulate_len')
+    enc = torch.from_numpy(g['enc']).permute(0, 2, 1).contiguous()          # channel-first
+    for tag, pace in (('0p8', 0.8), ('1p0', 1.0), ('1p25', 1.25)):
+        reps, dec_lens, idx_ref = O.regulate_len_indices(g['dur'], pace)
+        out, idx = length_regulate(enc.to(dev), torch.from_numpy(reps).to(dev), idx_ref.shape[1])
+        assert np.array_equal(idx.cpu().numpy(), idx_ref)
+        assert np.array_equal(idx.cpu().numpy(), g[f'idx_{tag}'])
+        assert np.array_equal(out[:, 1].cpu().numpy(), g[f'rep1_{tag}'])     # bit-exact gather
+
+
+def test_length_regulate_large_property(dev):
+    """Full-size property: sorted indices, each token repeated exactly reps times."""
+    from ttsamd.engine import length_regulate
+    from ttsamd import synth
+    B, Lt = 32, 64
+    dur = synth.synth_durations(B, Lt)
+    reps = torch.from_numpy(dur).long()
+    T = int(reps.sum(1).max())
+    enc = torch.arange(Lt, dtype=torch.float32)[None, None, :].repeat(B, 2, 1)
+    out, idx = length_regulate(enc.to(dev), reps.to(dev), T)
+    idx = idx.cpu().numpy()
+    for b in range(B):
+        n = int(reps[b].sum())
+        assert np.all(np.diff(idx[b, :n]) >= 0) and np.all(idx[b, n:] == -1)
+        assert np.array_equal(np.bincount(idx[b, :n], minlength=Lt), reps[b].numpy())
+        assert np.array_equal(out[b, 0, :n].cpu().numpy(), idx[b, :n].astype(np.float32))
+
+
+@pytest.fixture(scope='module')
+def hifigan_engine(dev, synth_weights):
+    from ttsamd.engine import HifiGanEngine
+    return HifiGanEngine(synth_weights['hifigan'])
+
+
+@pytest.mark.parametrize('T', [1, 7, 40])
+def test_hifigan_golden(dev, golden, hifigan_engine, T):
+    g = golden(f'hifigan_T{T}')
+    wave = hifigan_engine.forward(torch.from_numpy(g['mel'])[None].to(dev))
+    assert wave.shape == (1, 256 * T)
+    assert maxabs(wave[0], g['wave'][0]) < WAVE_TOL
+
+
+def test_hifigan_ragged_batch_matches_unbatched(dev, synth_weights, hifigan_engine):
+    """Batched ragged vocoder == the reference's per-utterance loop (networks.py:340-341):
+    every layer must zero-pad at the true utterance edge."""
+    import tts_oracle as O
+    from ttsamd.config import HIFIGAN_CONFIG
+    w = O.fold_weight_norm(synth_weights['hifigan'])
+    rng = np.random.default_rng(3)
+    lens = [23, 9, 16, 1]
+    mel = (rng.standard_normal((4, 80, 23)) * 1.5 - 4.0).astype(np.float32)
+    wave = hifigan_engine.forward(torch.from_numpy(mel).to(dev), torch.tensor(lens).to(dev)).cpu()
+    for b, n in enumerate(lens):
+        ref = O.hifigan_forward(w, mel[b, :, :n], HIFIGAN_CONFIG)[0]
+        assert maxabs(wave[b, :256 * n], ref) < WAVE_TOL, b
+        assert float(wave[b, 256 * n:].abs().max()) == 0.0 if n < 23 else True
+
+
+@pytest.fixture(scope='module')
+def fastpitch_engine(dev, synth_weights):
+    from ttsamd.engine import FastPitchEngine
+    return FastPitchEngine(synth_weights['fastpitch'])
+
+
+def test_fastpitch_ragged_golden(dev, golden, fastpitch_engine):
+    g = golden('fastpitch_b3_durtgt')
+    mel, dec_lens, dur, pitch, energy = fastpitch_engine.infer(g['ids'], dur_tgt=g['dur_tgt'])
+    assert np.array_equal(dec_lens.cpu().numpy(), g['dec_lens'])
+    assert maxabs(dur, g['dur_pred']) < 1e-3
+    assert maxabs(pitch, g['pitch_pred']) < 1e-3
+    assert maxabs(energy, g['energy_pred']) < 1e-3
+    assert maxabs(mel, g['mel']) < MEL_TOL
+
+
+@pytest.mark.parametrize('tag', ['p1', 'p0p9_pitch'])
+def test_fastpitch_predicted_durations_golden(dev, golden, fastpitch_engine, tag):
+    g = golden(f'fastpitch_b2_pred_{tag}')
+    out = fastpitch_engine.infer(g['ids'], pace=float(g['pace']), pitch_mul=float(g['pitch_mul']),
+                                 pitch_add=float(g['pitch_add']), return_idx=True)
+    mel, dec_lens, dur, pitch, energy, idx = out
+    assert np.array_equal(dec_lens.cpu().numpy(), g['dec_lens'])       # bit-exact lengths
+    assert maxabs(dur, g['dur_pred']) < 1e-3
+    assert maxabs(pitch, g['pitch_pred']) < 1e-3
+    assert maxabs(mel, g['mel']) < MEL_TOL
+
+
+def test_fastpitch_multispeaker_golden(dev, golden, synth_weights):
+    from ttsamd.engine import FastPitchEngine
+    from ttsamd.config import NET_CONFIG
+    g = golden('fastpitch_b3_spk2')
+    eng = FastPitchEngine(synth_weights['fastpitch_spk4'], dict(NET_CONFIG, n_speakers=4))
+    mel, dec_lens, *_ = eng.infer(g['ids'], dur_tgt=g['dur_tgt'], speaker=2)
+    assert np.array_equal(dec_lens.cpu().numpy(), g['dec_lens'])
+    assert maxabs(mel, g['mel']) < MEL_TOL
+
+
+def test_end_to_end_golden(dev, golden, fastpitch_engine, hifigan_engine):
+    """FastPitch2Wave.tts(list, batch_size=3, denoise=0) on three infer_text.txt lines."""
+    e = golden('e2e_tts')
+    t = golden('infer_text_ids')
+    seqs = [t['flat'][t['offsets'][i]:t['offsets'][i + 1]] for i in e['line_idx']]
+    order = np.argsort([-len(s) for s in seqs], kind='stable')
+    ids = np.zeros((3, max(map(len, seqs))), np.int64)
+    for r, i in enumerate(order):
+        ids[r, :len(seqs[i])] = seqs[i]
+    mel, dec_lens, *_ = fastpitch_engine.infer(ids)
+    wave = hifigan_engine.forward(mel, dec_lens).cpu()
+    dl = dec_lens.cpu().numpy()
+    for r, i in enumerate(order):
+        ref = e[f'wave{i}']
+        assert 256 * dl[r] == ref.shape[0]
+        assert maxabs(wave[r, :ref.shape[0]], ref) < WAVE_TOL

@@ -1,0 +1,211 @@
+// extern "C" surface of libttsamd.so (include/ttsamd.h): argument checks, error strings,
+// the launch-timing hooks used by bench.py, and thin forwards into the model code.
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace ttsamd {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// ---- launch timing (HIP events on the launch stream) -------------------------------
+struct Prof {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t used = 0;
+    double flops_per_frame = 0.0;
+} g_prof;
+
+void prof_begin(hipStream_t s, double flops_per_frame) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        g_prof.ev.push_back(a);
+        g_prof.ev.push_back(b);
+    }
+    (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+    g_prof.flops_per_frame += flops_per_frame;
+}
+
+void prof_end(hipStream_t s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (g_prof.used + 2 > g_prof.ev.size()) return;
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+    g_prof.used += 2;
+}
+
+struct HifiGan;
+struct FastPitch;
+int32_t hifigan_create(const ttsamd_tensor*, int32_t, const ttsamd_hifigan_cfg*, HifiGan**);
+void hifigan_destroy(HifiGan*);
+int64_t hifigan_workspace_bytes(const HifiGan*, int32_t, int32_t);
+int32_t hifigan_forward(const HifiGan*, const float*, const int64_t*, int32_t, int32_t, float*, void*, int64_t,
+                        hipStream_t);
+int32_t fastpitch_create(const ttsamd_tensor*, int32_t, const ttsamd_fastpitch_cfg*, int32_t, FastPitch**);
+void fastpitch_destroy(FastPitch*);
+int64_t fastpitch_encode_workspace_bytes(const FastPitch*, int32_t, int32_t);
+int64_t fastpitch_decode_workspace_bytes(const FastPitch*, int32_t, int32_t);
+int32_t fastpitch_encode(const FastPitch*, const int64_t*, int32_t, int32_t, int32_t, float, const float*,
+                         const float*, const float*, float, float, float, float*, float*, float*, float*, int64_t*,
+                         int64_t*, void*, int64_t, hipStream_t);
+int32_t fastpitch_decode(const FastPitch*, float*, const int64_t*, int32_t, int32_t, float*, void*, int64_t,
+                         hipStream_t);
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int cout, int cin, int k, int cp,
+                                        float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)cin * k * cp;
+    if (i >= n) return;
+    const int co = (int)(i % cp);
+    const int t = (int)((i / cp) % k);
+    const int ci = (int)(i / ((int64_t)cp * k));
+    out[i] = co < cout ? w[((int64_t)co * cin + ci) * k + t] : 0.f;
+}
+
+}  // namespace ttsamd
+
+using namespace ttsamd;
+
+extern "C" {
+
+const char* ttsamd_last_error(void) { return g_err.c_str(); }
+int32_t ttsamd_version(void) { return 1; }
+
+int32_t ttsamd_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0 ? 1 : 0;
+}
+
+int32_t ttsamd_hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hifigan_cfg* cfg, void** handle) {
+    HifiGan* h = nullptr;
+    const int32_t rc = hifigan_create(weights, n, cfg, &h);
+    if (rc == 0) *handle = h;
+    return rc;
+}
+int32_t ttsamd_hifigan_destroy(void* handle) {
+    hifigan_destroy((HifiGan*)handle);
+    return 0;
+}
+int64_t ttsamd_hifigan_workspace_bytes(void* handle, int32_t batch, int32_t t_max) {
+    if (!handle || batch < 1 || t_max < 1) return 0;
+    return hifigan_workspace_bytes((HifiGan*)handle, batch, t_max);
+}
+int32_t ttsamd_hifigan_forward(void* handle, const float* mel, const int64_t* lens, int32_t batch, int32_t t_max,
+                               float* wave, void* workspace, int64_t workspace_bytes, void* stream) {
+    return hifigan_forward((HifiGan*)handle, mel, lens, batch, t_max, wave, workspace, workspace_bytes,
+                           (hipStream_t)stream);
+}
+
+int32_t ttsamd_fastpitch_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_fastpitch_cfg* cfg,
+                                void** handle) {
+    FastPitch* h = nullptr;
+    const int32_t rc = fastpitch_create(weights, n, cfg, /*pos_cap=*/16384, &h);
+    if (rc == 0) *handle = h;
+    return rc;
+}
+int32_t ttsamd_fastpitch_destroy(void* handle) {
+    fastpitch_destroy((FastPitch*)handle);
+    return 0;
+}
+int64_t ttsamd_fastpitch_encode_workspace_bytes(void* handle, int32_t batch, int32_t n_tokens) {
+    if (!handle || batch < 1 || n_tokens < 1) return 0;
+    return fastpitch_encode_workspace_bytes((FastPitch*)handle, batch, n_tokens);
+}
+int64_t ttsamd_fastpitch_decode_workspace_bytes(void* handle, int32_t batch, int32_t t_max) {
+    if (!handle || batch < 1 || t_max < 1) return 0;
+    return fastpitch_decode_workspace_bytes((FastPitch*)handle, batch, t_max);
+}
+int32_t ttsamd_fastpitch_encode(void* handle, const int64_t* ids, int32_t batch, int32_t n_tokens, int32_t speaker,
+                                float pace, const float* dur_tgt, const float* pitch_tgt, const float* energy_tgt,
+                                float pitch_mul, float pitch_add, float max_duration, float* enc_cond,
+                                float* dur_pred, float* pitch_pred, float* energy_pred, int64_t* reps,
+                                int64_t* dec_lens, void* workspace, int64_t workspace_bytes, void* stream) {
+    return fastpitch_encode((FastPitch*)handle, ids, batch, n_tokens, speaker, pace, dur_tgt, pitch_tgt, energy_tgt,
+                            pitch_mul, pitch_add, max_duration, enc_cond, dur_pred, pitch_pred, energy_pred, reps,
+                            dec_lens, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int32_t ttsamd_length_regulate(const float* enc, const int64_t* reps, int32_t batch, int32_t n_tokens,
+                               int32_t channels, int32_t t_max, float* out, int32_t* idx, void* stream) {
+    TTS_REQUIRE(enc && reps && out && batch >= 1 && n_tokens >= 1 && channels >= 1 && t_max >= 0,
+                "length_regulate: bad argument");
+    return launch_regulate_gather(enc, reps, nullptr, 0, batch, n_tokens, channels, t_max, out, idx,
+                                  (hipStream_t)stream);
+}
+int32_t ttsamd_fastpitch_decode(void* handle, float* x, const int64_t* dec_lens, int32_t batch, int32_t t_max,
+                                float* mel, void* workspace, int64_t workspace_bytes, void* stream) {
+    return fastpitch_decode((FastPitch*)handle, x, dec_lens, batch, t_max, mel, workspace, workspace_bytes,
+                            (hipStream_t)stream);
+}
+
+int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {
+    return (int64_t)cin * k * cout_padded(cout);
+}
+
+int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t batch,
+                      int32_t cin, int32_t cout, int32_t k, int32_t dilation, int32_t lin, float in_slope,
+                      int32_t relu_out, float* y, float* packed, void* stream) {
+    TTS_REQUIRE(x && w && y && packed, "conv1d: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int cp = cout_padded(cout);
+    const int64_t n = (int64_t)cin * k * cp;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, cout, cin, k,
+                       cp, packed);
+    TTS_CHECK_HIP(hipGetLastError());
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x; p.x_bs = (int64_t)cin * lin; p.x_cs = lin;
+    p.w = packed; p.bias = bias;
+    p.y = y; p.y_bs = (int64_t)cout * lin; p.y_cs = lin; p.y_ts = 1;
+    p.lens_in = lens; p.lens_out = lens; p.len_in_mul = 1; p.len_out_mul = 1;
+    p.Lin = lin; p.Nout = lin; p.Cin = cin; p.Cout = cout; p.CoutP = cp; p.K = k;
+    p.dil = dilation; p.pad = (k * dilation - dilation) / 2;
+    p.n_phase = 1; p.in_slope = in_slope; p.relu_out = relu_out; p.mode = 0; p.div = 1.f; p.batch = batch;
+    prof_begin(s, 2.0 * cout * cin * k);
+    const int32_t rc = launch_conv(p, s);
+    prof_end(s);
+    return rc;
+}
+
+int32_t ttsamd_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.flops_per_frame = 0.0;
+    return 0;
+}
+
+int32_t ttsamd_profile_read(double* out3) {
+    TTS_REQUIRE(out3, "profile_read: null argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        TTS_CHECK_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+        float t = 0.f;
+        TTS_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+        ms += t;
+    }
+    out3[0] = ms;
+    out3[1] = (double)(g_prof.used / 2);
+    out3[2] = g_prof.flops_per_frame;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Shared host-side helpers of libttsamd (error reporting, launch checks, workspace carving).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/ttsamd.h"
+
+namespace ttsamd {
+
+void set_error(const char* fmt, ...);
+
+#define TTS_CHECK_HIP(expr)                                                         \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            ttsamd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                              __FILE__, __LINE__);                                  \
+            return TTSAMD_EHIP;                                                     \
+        }                                                                           \
+    } while (0)
+
+#define TTS_REQUIRE(cond, ...)              \
+    do {                                    \
+        if (!(cond)) {                      \
+            ttsamd::set_error(__VA_ARGS__); \
+            return TTSAMD_EINVAL;           \
+        }                                   \
+    } while (0)
+
+#define TTS_TRY(expr)               \
+    do {                            \
+        int32_t rc_ = (expr);       \
+        if (rc_ != 0) return rc_;   \
+    } while (0)
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller-provided workspace (no hidden hipMalloc on hot calls).
+struct Arena {
+    char* base;
+    int64_t size;
+    int64_t off = 0;
+    bool ok = true;
+    Arena(void* p, int64_t n) : base((char*)p), size(n) {}
+    template <typename T>
+    T* take(int64_t count) {
+        int64_t bytes = align_up(count * (int64_t)sizeof(T), 256);
+        if (base != nullptr && off + bytes > size) ok = false;
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+};
+
+// ---- generic implicit-GEMM conv1d (conv_mfma.hip) -----------------------------------
+struct ConvParams {
+    const float* x;      // [B][Cin][*], element (b,c,t) at x + b*x_bs + c*x_cs + t
+    int64_t x_bs;
+    int32_t x_cs;
+    const float* w;      // packed [n_phase][Cin][K][CoutP]
+    const float* bias;   // [>=Cout] or nullptr
+    float* y;            // (b,co,q) at y + b*y_bs + co*y_cs + q*y_ts + phase
+    int64_t y_bs;
+    int32_t y_cs, y_ts;
+    const float* res;    // residual, same indexing as y (nullptr = none)
+    int64_t r_bs;
+    int32_t r_cs;
+    const int64_t* lens_in;   // per-utterance valid input length = lens_in[b]*len_in_mul (nullptr -> Lin)
+    const int64_t* lens_out;  // per-utterance number of outputs  = lens_out[b]*len_out_mul (nullptr -> Nout)
+    int32_t len_in_mul, len_out_mul;
+    int32_t Lin, Nout;
+    int32_t Cin, Cout, CoutP, K;
+    int32_t dil, pad;    // input position of tap k for output q: q + k*dil - pad
+    int32_t n_phase;     // >1: transposed conv as n_phase polyphase convs (K=2, dil=-1)
+    int32_t phase_p;     // transposed conv padding p: delta = (phase+p)/n_phase, pad = -delta
+    float in_slope;      // leaky-relu slope applied to the input on load (1 = identity)
+    int32_t relu_out;    // ReLU on the output
+    int32_t mode;        // 0: y=v   1: y=y+v   2: y=(y+v)/div
+    float div;
+    int32_t batch;
+};
+
+// Launches the kernel; returns 0 or a negative code.
+int32_t launch_conv(const ConvParams& p, hipStream_t stream);
+// Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]
+void pack_conv_weight(const float* w, int cout, int cin, int k, float* out);
+// torch ConvTranspose1d [Cin][Cout][Kt] (Kt = 2u, stride u, padding p) -> [u][Cin][2][CoutP]
+void pack_convt_weight(const float* w, int cin, int cout, int kt, int u, int p, float* out);
+inline int cout_padded(int cout) { return (int)align_up(cout, 32); }
+
+}  // namespace ttsamd

@@ -1,0 +1,208 @@
+// Implicit-GEMM Conv1d / ConvTranspose1d / Linear on the gfx950 matrix cores, exact fp32
+// (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TFLOP/s peak).
+//
+// Replaces every F.conv1d / F.conv_transpose1d / F.linear the reference issues on the hot
+// path: HiFi-GAN conv_pre / ups / ResBlock1 convs (vocoder/hifigan/models.py:46-53,
+// 111-127), FastPitch conv-FF, qkv/o_net/proj, predictor convs
+// (models/fastpitch/fastpitch/transformer.py:59-65,122,148; model.py:54-57,406).
+//
+// GEMM view per utterance b:  Y[co][q] = sum_{ci,tap} Wp[ci][tap][co] * X[ci][q + tap*dil - pad]
+//   M = co (weights, A operand, read straight from L2 — all blocks share them),
+//   N = q  (time, B operand, staged once per 16-channel chunk in LDS with the input
+//           activation (leaky-relu) and the utterance-edge zero padding applied on load),
+//   K = (ci, tap) walked two input channels per MFMA.
+// Activations are channel-first [B][C][T] so a wave's 32 N-lanes read 32 consecutive time
+// steps (coalesced HBM, conflict-free LDS).  A block is 4 waves tiled WM x WN, each wave
+// owning MT x NTL 32x32 accumulators.  Ragged batches: positions >= lens_in[b] read as
+// zero at the INPUT of every layer, tiles past lens_out[b] exit early.
+#include "common.hpp"
+
+namespace ttsamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 16;  // input channels staged per LDS chunk
+
+template <int K, int MT, int NTL, int WM, int WN>
+__global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CO_BLK = WM * MT * 32;
+    constexpr int NT_BLK = WN * NTL * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z;
+    const int n_co_tiles = p.CoutP / CO_BLK;
+    const int phase = blockIdx.y / n_co_tiles;
+    const int co_blk0 = (blockIdx.y % n_co_tiles) * CO_BLK;
+    const int q0 = blockIdx.x * NT_BLK;
+
+    int n_out = p.Nout;
+    if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
+    if (q0 >= n_out) return;
+    int in_len = p.Lin;
+    if (p.lens_in) in_len = min(in_len, (int)p.lens_in[b] * p.len_in_mul);
+
+    const int dil = p.dil;
+    int pad = p.pad;
+    if (p.n_phase > 1) pad = -((phase + p.phase_p) / p.n_phase);
+    const int span = (K - 1) * (dil < 0 ? -dil : dil);
+    const int lo = (dil < 0 ? (K - 1) * dil : 0) - pad;  // first input position relative to q0
+    const int W = NT_BLK + span;                          // LDS row length
+
+    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+    const float* __restrict__ wp = p.w + (int64_t)phase * p.Cin * K * p.CoutP;
+    const float in_slope = p.in_slope;
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int co_w0 = co_blk0 + wm * MT * 32;
+    const int qw0 = wn * NTL * 32;
+    bool nt_ok[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) nt_ok[j] = (q0 + qw0 + j * 32) < n_out;
+
+    const int kk = lane >> 5, l31 = lane & 31;
+    const int soff = qw0 + l31 - pad - lo;  // >= 0
+
+    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+        __syncthreads();
+        for (int r = wid; r < KC; r += 4) {
+            const float* __restrict__ xr = xb + (int64_t)(c0 + r) * p.x_cs;
+            for (int col = lane; col < W; col += 64) {
+                const int pos = q0 + lo + col;
+                float v = 0.f;
+                if (pos >= 0 && pos < in_len) {
+                    v = xr[pos];
+                    v = v > 0.f ? v : v * in_slope;
+                }
+                smem[r * W + col] = v;
+            }
+        }
+        __syncthreads();
+        if (nt_ok[0]) {
+#pragma unroll
+            for (int pr = 0; pr < KC / 2; ++pr) {
+                const float* __restrict__ wrow =
+                    wp + (int64_t)(c0 + 2 * pr + kk) * K * p.CoutP + co_w0 + l31;
+                const float* srow = smem + (2 * pr + kk) * W + soff;
+#pragma unroll
+                for (int tap = 0; tap < K; ++tap) {
+                    float a[MT], bq[NTL];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) a[i] = wrow[tap * p.CoutP + i * 32];
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) bq[j] = srow[tap * dil + j * 32];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTL; ++j)
+                            if (j == 0 || nt_ok[j])
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: bias, residual, activation, accumulate modes
+    float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
+    const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs + phase : nullptr;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int q = q0 + qw0 + j * 32 + l31;
+            if (q >= n_out) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (co >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[co];
+                const int64_t yo = (int64_t)co * p.y_cs + (int64_t)q * p.y_ts;
+                if (rb) v += rb[(int64_t)co * p.r_cs + (int64_t)q * p.y_ts];
+                if (p.relu_out) v = fmaxf(v, 0.f);
+                if (p.mode == 1) v = yb[yo] + v;
+                else if (p.mode == 2) v = (yb[yo] + v) / p.div;
+                yb[yo] = v;
+            }
+        }
+    }
+}
+
+template <int K, int MT, int NTL, int WM, int WN>
+static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
+    constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
+    const int span = (K - 1) * (p.dil < 0 ? -p.dil : p.dil);
+    const size_t lds = (size_t)KC * (NT_BLK + span) * sizeof(float);
+    dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
+    hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN>), grid, dim3(256), lds, stream, p);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int K>
+static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
+    const bool is_long = p.Nout > 96;
+    if (p.CoutP % 128 == 0) {
+        if (is_long) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
+        return launch_cfg<K, 1, 2, 4, 1>(p, stream);                // 128 co x  64 t
+    }
+    if (p.CoutP % 64 == 0) {
+        if (is_long) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
+        return launch_cfg<K, 1, 1, 2, 2>(p, stream);                //  64 co x  64 t
+    }
+    if (is_long) return launch_cfg<K, 1, 2, 1, 4>(p, stream);       //  32 co x 256 t
+    return launch_cfg<K, 1, 1, 1, 4>(p, stream);                    //  32 co x 128 t
+}
+
+int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
+    TTS_REQUIRE(p.Cin % KC == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, KC);
+    TTS_REQUIRE(p.CoutP % 32 == 0 && p.CoutP >= p.Cout, "conv: bad CoutP=%d", p.CoutP);
+    TTS_REQUIRE(p.n_phase >= 1 && p.batch >= 1, "conv: bad n_phase/batch");
+    if (p.Nout <= 0) return 0;
+    switch (p.K) {
+        case 1: return launch_k<1>(p, stream);
+        case 2: return launch_k<2>(p, stream);
+        case 3: return launch_k<3>(p, stream);
+        case 7: return launch_k<7>(p, stream);
+        case 11: return launch_k<11>(p, stream);
+        default:
+            set_error("conv: kernel size %d not instantiated (1,2,3,7,11)", p.K);
+            return TTSAMD_EINVAL;
+    }
+}
+
+void pack_conv_weight(const float* w, int cout, int cin, int k, float* out) {
+    const int cp = cout_padded(cout);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int t = 0; t < k; ++t) {
+            float* o = out + ((int64_t)ci * k + t) * cp;
+            for (int co = 0; co < cp; ++co)
+                o[co] = co < cout ? w[((int64_t)co * cin + ci) * k + t] : 0.f;
+        }
+}
+
+// ConvTranspose1d(stride u, kernel Kt = 2u, padding p): y[co][q*u+rho] =
+//   sum_ci W[ci][co][ka] x[ci][q+delta] + W[ci][co][ka+u] x[ci][q+delta-1],
+//   ka = (rho+p) % u, delta = (rho+p) / u     (vocoder/hifigan/models.py:96-99).
+void pack_convt_weight(const float* w, int cin, int cout, int kt, int u, int p, float* out) {
+    const int cp = cout_padded(cout);
+    for (int rho = 0; rho < u; ++rho) {
+        const int ka = (rho + p) % u;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 2; ++t) {
+                const int kidx = ka + t * u;
+                float* o = out + (((int64_t)rho * cin + ci) * 2 + t) * cp;
+                for (int co = 0; co < cp; ++co)
+                    o[co] = (co < cout && kidx < kt) ? w[((int64_t)ci * cout + co) * kt + kidx] : 0.f;
+            }
+    }
+}
+
+}  // namespace ttsamd

@@ -1,0 +1,441 @@
+// HBM-/latency-bound kernels around the MFMA conv engine.  All activations are channel-first
+// [B][C][T] so that consecutive lanes touch consecutive time steps (coalesced, 64-wide waves).
+#include "kernels.hpp"
+
+namespace ttsamd {
+
+// ------------------------------------------------------------------------------------
+// HiFi-GAN tail (vocoder/hifigan/models.py:123-125): leaky_relu(x, 0.01) -> Conv1d(C->1,k7,p3)
+// -> tanh.  Each thread produces 4 consecutive samples from a 10-wide register window.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const int64_t* __restrict__ lens, int len_mul, int C, int L,
+                                                        float slope, float* __restrict__ wave, int64_t wave_bs) {
+    const int b = blockIdx.y;
+    int n = L;
+    if (lens) n = min(n, (int)lens[b] * len_mul);
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 >= n) return;
+    const float* xb = x + (int64_t)b * x_bs;
+    float acc[4];
+    const float b0 = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* xr = xb + (int64_t)c * x_cs;
+        float win[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int pos = t0 - 3 + i;
+            float v = 0.f;
+            if (pos >= 0 && pos < n) {
+                v = xr[pos];
+                v = v > 0.f ? v : v * slope;
+            }
+            win[i] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float wk = w[c * 7 + k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk, win[i + k], acc[i]);
+        }
+    }
+    float* o = wave + (int64_t)b * wave_bs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (t0 + i < n) o[t0 + i] = tanhf(acc[i] + b0);
+}
+
+int32_t launch_conv_post(const float* x, int64_t x_bs, int32_t x_cs, const float* w, const float* bias,
+                         const int64_t* lens, int32_t len_mul, int32_t B, int32_t C, int32_t L, float in_slope,
+                         float* wave, int64_t wave_bs, hipStream_t s) {
+    if (L <= 0 || B <= 0) return 0;
+    dim3 grid((L + 1023) / 1024, B);
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, s, x, x_bs, x_cs, w, bias, lens, len_mul, C, L,
+                       in_slope, wave, wave_bs);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// LayerNorm over channels of a channel-first tensor.  Block = 64 time steps x 4 channel
+// groups; two-pass mean / variance (biased, eps 1e-5) like torch.nn.LayerNorm.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const int64_t* __restrict__ lens, int apply_mask, int C,
+                                                           int S) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const bool ok = t < S;
+    const float* xb = x + (int64_t)b * C * S;
+    float* yb = y + (int64_t)b * C * S;
+    const int cpg = (C + 3) / 4;
+    const int c_lo = g * cpg, c_hi = min(C, c_lo + cpg);
+    float sum = 0.f;
+    if (ok)
+        for (int c = c_lo; c < c_hi; ++c) sum += xb[(int64_t)c * S + t];
+    red[g][tl] = sum;
+    __syncthreads();
+    const float mean = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+    if (ok)
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float d = xb[(int64_t)c * S + t] - mean;
+            sq = fmaf(d, d, sq);
+        }
+    red[g][tl] = sq;
+    __syncthreads();
+    const float var = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (!ok) return;
+    float m = 1.f;
+    if (apply_mask && lens && t >= (int)lens[b]) m = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float v = (xb[(int64_t)c * S + t] - mean) * rstd * gamma[c] + beta[c];
+        yb[(int64_t)c * S + t] = v * m;
+    }
+}
+
+int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const float* beta, const int64_t* lens,
+                            int32_t apply_mask, int32_t B, int32_t C, int32_t S, hipStream_t s) {
+    if (S <= 0 || B <= 0) return 0;
+    dim3 grid((S + 63) / 64, B);
+    hipLaunchKernelGGL(layernorm_cf_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Encoder embedding (transformer.py:212-219): word_emb gather + sinusoid table * mask + speaker.
+// pos_table is channel-first [C][pos_stride].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids,
+                                                    const float* __restrict__ word_emb,
+                                                    const float* __restrict__ pos, int pos_stride,
+                                                    const float* __restrict__ spk, int pad_idx, int L, int C,
+                                                    float* __restrict__ x, int64_t* __restrict__ lens) {
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const int64_t* idb = ids + (int64_t)b * L;
+    if (blockIdx.x == 0 && g == 0) {
+        int cnt = 0;
+        for (int i = tl; i < L; i += 64) cnt += (idb[i] != pad_idx) ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (tl == 0) lens[b] = cnt;
+    }
+    if (t >= L) return;
+    const int64_t id = idb[t];
+    const float m = (id != pad_idx) ? 1.f : 0.f;
+    const float* er = word_emb + id * C;
+    float* xb = x + (int64_t)b * C * L;
+    for (int c = g; c < C; c += 4) {
+        float v = er[c] + pos[(int64_t)c * pos_stride + t] * m;
+        if (spk) v += spk[c];
+        xb[(int64_t)c * L + t] = v;
+    }
+}
+
+int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos_table, int32_t pos_stride,
+                     const float* spk, int32_t pad_idx, int32_t B, int32_t L, int32_t C, float* x, int64_t* lens, hipStream_t s) {
+    dim3 grid((L + 63) / 64, B);
+    hipLaunchKernelGGL(embed_kernel, grid, dim3(256), 0, s, ids, word_emb, pos_table, pos_stride, spk, pad_idx, L,
+                       C, x, lens);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Single-head attention, flash-style (online softmax), fp32 VALU: 0.1 % of the path's FLOPs.
+// Block = 64 queries of one utterance; key/value tiles of 64 streamed through LDS.
+// Thread (ti = tid/16, tj = tid%16) owns score rows i0=4*ti.. and score cols / out dims 4*tj..
+// ------------------------------------------------------------------------------------
+constexpr int ATT_D = 64;
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
+                                                        const int64_t* __restrict__ lens, int S, float scale,
+                                                        float* __restrict__ out) {
+    __shared__ float Qs[ATT_D][64 + 4];
+    __shared__ float Ks[ATT_D][64 + 4];
+    __shared__ float Vs[ATT_D][64 + 1];
+    __shared__ float Ps[64][64 + 4];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int i0 = ti * 4, j0 = tj * 4;
+    const int qbase = blockIdx.x * 64;
+    int len = S;
+    if (lens) len = min(S, (int)lens[b]);
+    const float* qb = qkv + (int64_t)b * 3 * ATT_D * S;
+    const float* kb = qb + (int64_t)ATT_D * S;
+    const float* vb = kb + (int64_t)ATT_D * S;
+
+    for (int e = tid; e < ATT_D * 64; e += 256) {
+        const int d = e >> 6, i = e & 63;
+        Qs[d][i] = (qbase + i < S) ? qb[(int64_t)d * S + qbase + i] : 0.f;
+    }
+    float m_run[4], l_run[4], o[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        m_run[a] = -INFINITY;
+        l_run[a] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[a][c] = 0.f;
+    }
+    for (int kt = 0; kt < len; kt += 64) {
+        __syncthreads();
+        for (int e = tid; e < ATT_D * 64; e += 256) {
+            const int d = e >> 6, j = e & 63;
+            const bool ok = kt + j < len;
+            Ks[d][j] = ok ? kb[(int64_t)d * S + kt + j] : 0.f;
+            Vs[d][j] = ok ? vb[(int64_t)d * S + kt + j] : 0.f;
+        }
+        __syncthreads();
+        float sc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sc[a][c] = 0.f;
+        for (int d = 0; d < ATT_D; ++d) {
+            const float4 qv = *reinterpret_cast<const float4*>(&Qs[d][i0]);
+            const float4 kv = *reinterpret_cast<const float4*>(&Ks[d][j0]);
+            const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
+            const float ka[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sc[a][c] = fmaf(qa[a], ka[c], sc[a][c]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sc[a][c] = (kt + j0 + c < len) ? sc[a][c] * scale : -INFINITY;
+                mx = fmaxf(mx, sc[a][c]);
+            }
+            for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            const float m_new = fmaxf(m_run[a], mx);
+            const float alpha = expf(m_run[a] - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float pv = expf(sc[a][c] - m_new);
+                sc[a][c] = pv;
+                rs += pv;
+            }
+            for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off);
+            l_run[a] = l_run[a] * alpha + rs;
+            m_run[a] = m_new;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[a][c] *= alpha;
+            *reinterpret_cast<float4*>(&Ps[i0 + a][j0]) = make_float4(sc[a][0], sc[a][1], sc[a][2], sc[a][3]);
+        }
+        __syncthreads();
+        // O[i0+a][d0+c] += sum_j P[i0+a][j] * V[d0+c][j], d0 = j0
+        for (int j = 0; j < 64; ++j) {
+            float pa[4], va[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pa[a] = Ps[i0 + a][j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) va[c] = Vs[j0 + c][j];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[a][c] = fmaf(pa[a], va[c], o[a][c]);
+        }
+    }
+    float* ob = out + (int64_t)b * ATT_D * S;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = qbase + i0 + a;
+        if (i >= S) continue;
+        const float inv = 1.0f / l_run[a];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ob[(int64_t)(j0 + c) * S + i] = o[a][c] * inv;
+    }
+}
+
+int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S, float scale,
+                         float* out, hipStream_t s) {
+    TTS_REQUIRE(D == ATT_D, "attention: d_head=%d, only %d is built", D, ATT_D);
+    if (S <= 0 || B <= 0) return 0;
+    dim3 grid((S + 63) / 64, B);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Predictor head (model.py:132) + duration transform (model.py:368) / pitch_trf (networks.py:38-42)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pred_fc_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias,
+                                                      const int64_t* __restrict__ lens, int C, int S,
+                                                      float* __restrict__ out, float* __restrict__ out2,
+                                                      float max_dur, float mul, float add) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= S) return;
+    const float* xb = x + (int64_t)b * C * S;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(w[c], xb[(int64_t)c * S + t], acc);
+    acc += bias[0];
+    if (lens && t >= (int)lens[b]) acc = 0.f;   // "* enc_out_mask"
+    if (out2) out2[(int64_t)b * S + t] = fminf(fmaxf(expf(acc) - 1.0f, 0.f), max_dur);
+    out[(int64_t)b * S + t] = mul * acc + add;
+}
+
+int32_t launch_pred_fc(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t B,
+                       int32_t C, int32_t S, float* out, float* out2, float max_dur, float mul, float add,
+                       hipStream_t s) {
+    dim3 grid((S + 255) / 256, B);
+    hipLaunchKernelGGL(pred_fc_kernel, grid, dim3(256), 0, s, x, w, bias, lens, C, S, out, out2, max_dur, mul,
+                       add);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// enc[b][c][t] += bias[c] + sum_k w[c][k] * src[b][t + k - K/2]    (zero padded)
+__global__ __launch_bounds__(256) void scalar_emb_add_kernel(float* __restrict__ enc,
+                                                             const float* __restrict__ src,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int C, int S, int K) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= S) return;
+    const float* sb = src + (int64_t)b * S;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int pos = t + k - (K - 1) / 2;
+        const float v = (pos >= 0 && pos < S) ? sb[pos] : 0.f;
+        acc = fmaf(w[c * K + k], v, acc);
+    }
+    acc += bias[c];
+    enc[((int64_t)b * C + c) * S + t] += acc;
+}
+
+int32_t launch_scalar_emb_add(float* enc, const float* src, const float* w, const float* bias, int32_t B,
+                              int32_t C, int32_t S, int32_t K, hipStream_t s) {
+    dim3 grid((S + 255) / 256, C, B);
+    hipLaunchKernelGGL(scalar_emb_add_kernel, grid, dim3(256), 0, s, enc, src, w, bias, C, S, K);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Length regulator, integer half (model.py:72-76).  One wave64 per utterance.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void durations_to_reps_kernel(const float* __restrict__ dur, float pace, int L,
+                                                               int64_t* __restrict__ reps,
+                                                               int64_t* __restrict__ dec_lens) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    long long tot = 0;
+    for (int i = lane; i < L; i += 64) {
+        const float r = dur[(int64_t)b * L + i] / pace + 0.5f;   // fp32, as durations.float()/pace + 0.5
+        const long long n = (long long)r;                        // .long(): truncation toward zero
+        reps[(int64_t)b * L + i] = n;
+        tot += n;
+    }
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) dec_lens[b] = tot;
+}
+
+int32_t launch_durations_to_reps(const float* dur, float pace, int32_t B, int32_t L, int64_t* reps,
+                                 int64_t* dec_lens, hipStream_t s) {
+    hipLaunchKernelGGL(durations_to_reps_kernel, dim3(B), dim3(64), 0, s, dur, pace, L, reps, dec_lens);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Length regulator, gather half (model.py:77-85): wave64 inclusive scan of the repeat counts
+// (64 tokens per step, carry across steps), binary search of each frame in the prefix sums,
+// then a coalesced row gather.  Equivalent to the reference's one-hot matmul bit for bit
+// (each output is 1.0*x + 0.0*...).
+// ------------------------------------------------------------------------------------
+constexpr int REG_MAX_L = 4096;
+__global__ __launch_bounds__(256) void regulate_gather_kernel(const float* __restrict__ enc,
+                                                              const int64_t* __restrict__ reps,
+                                                              const float* __restrict__ pos, int pos_stride, int L,
+                                                              int C, int T, float* __restrict__ out,
+                                                              int32_t* __restrict__ idx) {
+    __shared__ int cs[REG_MAX_L + 1];   // exclusive prefix sums, cs[L] = dec_len
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        int carry = 0;
+        if (tid == 0) cs[0] = 0;
+        for (int base = 0; base < L; base += 64) {
+            const int i = base + tid;
+            int v = (i < L) ? (int)reps[(int64_t)b * L + i] : 0;
+            for (int o = 1; o < 64; o <<= 1) {                 // wave64 inclusive scan
+                const int n = __shfl_up(v, o);
+                if (tid >= o) v += n;
+            }
+            if (i < L) cs[i + 1] = carry + v;
+            carry += __shfl(v, 63);
+        }
+    }
+    __syncthreads();
+    const int dec_len = cs[L];
+    const int t = blockIdx.x * 256 + tid;
+    if (t >= T) return;
+    int j = -1;
+    if (t < dec_len) {
+        int lo = 0, hi = L;                // largest j with cs[j] <= t  (cs non-decreasing)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cs[mid] <= t) lo = mid; else hi = mid;
+        }
+        j = lo;
+    }
+    if (idx) idx[(int64_t)b * T + t] = j;
+    const float* eb = enc + (int64_t)b * C * L;
+    float* ob = out + (int64_t)b * C * T;
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+        if (j >= 0) {
+            v = eb[(int64_t)c * L + j];
+            if (pos) v += pos[(int64_t)c * pos_stride + t];
+        }
+        ob[(int64_t)c * T + t] = v;
+    }
+}
+
+int32_t launch_regulate_gather(const float* enc, const int64_t* reps, const float* pos_table, int32_t pos_stride,
+                               int32_t B, int32_t L, int32_t C, int32_t T, float* out, int32_t* idx, hipStream_t s) {
+    TTS_REQUIRE(L <= REG_MAX_L, "length_regulate: n_tokens=%d exceeds %d", L, REG_MAX_L);
+    if (T <= 0 || B <= 0) return 0;
+    dim3 grid((T + 255) / 256, B);
+    hipLaunchKernelGGL(regulate_gather_kernel, grid, dim3(256), 0, s, enc, reps, pos_table, pos_stride, L, C,
+                       T, out, idx);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos,
+                                                      int pos_stride, const int64_t* __restrict__ lens, int C,
+                                                      int S) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= S) return;
+    if (lens && t >= (int)lens[b]) return;
+    x[((int64_t)b * C + c) * S + t] += pos[(int64_t)c * pos_stride + t];
+}
+
+int32_t launch_add_pos(float* x, const float* pos_table, int32_t pos_stride, const int64_t* lens, int32_t B, int32_t C, int32_t S,
+                       hipStream_t s) {
+    dim3 grid((S + 255) / 256, C, B);
+    hipLaunchKernelGGL(add_pos_kernel, grid, dim3(256), 0, s, x, pos_table, pos_stride, lens, C, S);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ttsamd

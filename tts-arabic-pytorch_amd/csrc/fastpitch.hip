@@ -1,0 +1,370 @@
+// FastPitch.infer on the MI355X: handle creation (weight re-layout, sinusoid table, upload)
+// and the two phases either side of the data-dependent decoder length.
+// Replaces models/fastpitch/fastpitch/model.py:351-409 (FastPitch.infer), :114-133
+// (TemporalPredictor), :68-90 (regulate_len) and transformer.py:113-225 (FFTransformer).
+// Internals are channel-first [B][C][S]; the k=3 conv-FF (97 % of the FLOPs), qkv/o_net/proj
+// and predictor convs all run on the MFMA conv engine (conv_mfma.hip).
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace ttsamd {
+
+struct PConv {
+    int64_t w_off = 0, b_off = -1;
+    int cin = 0, cout = 0, k = 0;
+};
+struct FftLayer {
+    PConv qkv, o_net, ff0, ff2;
+    int64_t ln1_g, ln1_b, ln2_g, ln2_b;
+};
+struct Predictor {
+    std::vector<PConv> convs;
+    std::vector<int64_t> ln_g, ln_b;
+    int64_t fc_w, fc_b;
+    int filter;
+};
+
+struct FastPitch {
+    ttsamd_fastpitch_cfg cfg;
+    float* dev = nullptr;
+    std::vector<FftLayer> enc, dec;
+    Predictor dur, pitch, energy;
+    int64_t word_emb, pos_enc, pos_dec, spk_emb = -1, proj_b;
+    PConv proj;
+    int64_t pitch_emb_w, pitch_emb_b, energy_emb_w = -1, energy_emb_b = -1;
+    int pos_cap = 0;
+};
+
+using TensorMap = std::map<std::string, const ttsamd_tensor*>;
+
+static int64_t numel(const ttsamd_tensor* t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+}
+
+struct Builder {
+    const TensorMap& tm;
+    std::vector<float> blob;
+    int32_t rc = 0;
+    explicit Builder(const TensorMap& t) : tm(t) {}
+
+    const ttsamd_tensor* get(const std::string& name, int64_t n_expected) {
+        if (rc) return nullptr;
+        auto it = tm.find(name);
+        if (it == tm.end()) {
+            set_error("fastpitch: missing tensor '%s'", name.c_str());
+            rc = TTSAMD_EINVAL;
+            return nullptr;
+        }
+        if (n_expected >= 0 && numel(it->second) != n_expected) {
+            set_error("fastpitch: tensor '%s' has %lld elements, expected %lld", name.c_str(),
+                      (long long)numel(it->second), (long long)n_expected);
+            rc = TTSAMD_EINVAL;
+            return nullptr;
+        }
+        return it->second;
+    }
+    int64_t raw(const std::string& name, int64_t n_expected) {
+        const ttsamd_tensor* t = get(name, n_expected);
+        if (!t) return 0;
+        const int64_t off = (int64_t)blob.size();
+        blob.insert(blob.end(), t->data, t->data + numel(t));
+        blob.resize(align_up((int64_t)blob.size(), 64));
+        return off;
+    }
+    // Conv1d weight [cout][cin][k] or Linear weight [cout][cin] (k = 1)
+    PConv conv(const std::string& base, int cin, int cout, int k, bool bias) {
+        PConv c;
+        c.cin = cin; c.cout = cout; c.k = k;
+        const ttsamd_tensor* w = get(base + ".weight", (int64_t)cin * cout * k);
+        if (!w) return c;
+        c.w_off = (int64_t)blob.size();
+        blob.resize(blob.size() + (size_t)cin * k * cout_padded(cout));
+        pack_conv_weight(w->data, cout, cin, k, blob.data() + c.w_off);
+        blob.resize(align_up((int64_t)blob.size(), 64));
+        if (bias) c.b_off = raw(base + ".bias", cout);
+        return c;
+    }
+};
+
+static void build_fft(Builder& b, const std::string& prefix, int n_layers, int d_model, int d_head, int n_head,
+                      int d_inner, int k, std::vector<FftLayer>& out) {
+    for (int i = 0; i < n_layers && b.rc == 0; ++i) {
+        const std::string p = prefix + ".layers." + std::to_string(i) + ".";
+        FftLayer l;
+        l.qkv = b.conv(p + "dec_attn.qkv_net", d_model, 3 * n_head * d_head, 1, true);
+        l.o_net = b.conv(p + "dec_attn.o_net", n_head * d_head, d_model, 1, false);
+        l.ln1_g = b.raw(p + "dec_attn.layer_norm.weight", d_model);
+        l.ln1_b = b.raw(p + "dec_attn.layer_norm.bias", d_model);
+        l.ff0 = b.conv(p + "pos_ff.CoreNet.0", d_model, d_inner, k, true);
+        l.ff2 = b.conv(p + "pos_ff.CoreNet.2", d_inner, d_model, k, true);   // index 2: ReLU at 1 (transformer.py:59-65 with Dropout commented out -> Sequential index 2)
+        l.ln2_g = b.raw(p + "pos_ff.layer_norm.weight", d_model);
+        l.ln2_b = b.raw(p + "pos_ff.layer_norm.bias", d_model);
+        out.push_back(l);
+    }
+}
+
+static void build_predictor(Builder& b, const std::string& prefix, int d_in, int filter, int k, int n_layers,
+                            Predictor& pr) {
+    pr.filter = filter;
+    for (int i = 0; i < n_layers && b.rc == 0; ++i) {
+        const std::string p = prefix + ".layers." + std::to_string(i) + ".";
+        pr.convs.push_back(b.conv(p + "conv", i == 0 ? d_in : filter, filter, k, true));
+        pr.ln_g.push_back(b.raw(p + "norm.weight", filter));
+        pr.ln_b.push_back(b.raw(p + "norm.bias", filter));
+    }
+    pr.fc_w = b.raw(prefix + ".fc.weight", filter);
+    pr.fc_b = b.raw(prefix + ".fc.bias", 1);
+}
+
+// Channel-first sinusoid table [d_model][cap]: row c<half = sin(t*inv_freq[c]), else cos
+// (transformer.py:41-44).  The product t*inv_freq is rounded to fp32 as torch.matmul does.
+static int64_t build_pos_table(Builder& b, const std::string& name, int d_model, int cap) {
+    const ttsamd_tensor* f = b.get(name, d_model / 2);
+    if (!f) return 0;
+    const int64_t off = (int64_t)b.blob.size();
+    b.blob.resize(b.blob.size() + (size_t)d_model * cap);
+    float* o = b.blob.data() + off;
+    const int half = d_model / 2;
+    for (int c = 0; c < half; ++c) {
+        const float fr = f->data[c];
+        for (int t = 0; t < cap; ++t) {
+            const float arg = (float)t * fr;
+            o[(int64_t)c * cap + t] = (float)std::sin((double)arg);
+            o[(int64_t)(c + half) * cap + t] = (float)std::cos((double)arg);
+        }
+    }
+    return off;
+}
+
+int32_t fastpitch_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_fastpitch_cfg* cfg, int32_t pos_cap,
+                         FastPitch** out) {
+    TTS_REQUIRE(weights && cfg && out, "fastpitch_create: null argument");
+    TTS_REQUIRE(cfg->in_fft_n_heads == 1 && cfg->out_fft_n_heads == 1, "fastpitch: only n_heads = 1 is built");
+    TTS_REQUIRE(cfg->d_model % 16 == 0, "fastpitch: d_model must be a multiple of 16");
+    TensorMap tm;
+    for (int i = 0; i < n; ++i) tm[weights[i].name] = &weights[i];
+    Builder b(tm);
+    auto* h = new FastPitch();
+    h->cfg = *cfg;
+    h->pos_cap = pos_cap;
+    const int d = cfg->d_model;
+    h->word_emb = b.raw("encoder.word_emb.weight", (int64_t)cfg->n_symbols * d);
+    h->pos_enc = build_pos_table(b, "encoder.pos_emb.inv_freq", d, pos_cap);
+    h->pos_dec = build_pos_table(b, "decoder.pos_emb.inv_freq", d, pos_cap);
+    build_fft(b, "encoder", cfg->in_fft_n_layers, d, cfg->in_fft_d_head, cfg->in_fft_n_heads, cfg->in_fft_filter,
+              cfg->in_fft_kernel, h->enc);
+    build_fft(b, "decoder", cfg->out_fft_n_layers, d, cfg->out_fft_d_head, cfg->out_fft_n_heads,
+              cfg->out_fft_filter, cfg->out_fft_kernel, h->dec);
+    build_predictor(b, "duration_predictor", d, cfg->dur_filter, cfg->dur_kernel, cfg->dur_n_layers, h->dur);
+    build_predictor(b, "pitch_predictor", d, cfg->pitch_filter, cfg->pitch_kernel, cfg->pitch_n_layers, h->pitch);
+    h->pitch_emb_w = b.raw("pitch_emb.weight", (int64_t)d * cfg->pitch_emb_kernel);
+    h->pitch_emb_b = b.raw("pitch_emb.bias", d);
+    if (cfg->energy_conditioning) {
+        build_predictor(b, "energy_predictor", d, cfg->energy_filter, cfg->energy_kernel, cfg->energy_n_layers,
+                        h->energy);
+        h->energy_emb_w = b.raw("energy_emb.weight", (int64_t)d * cfg->energy_emb_kernel);
+        h->energy_emb_b = b.raw("energy_emb.bias", d);
+    }
+    h->proj = b.conv("proj", d, cfg->n_mel_channels, 1, true);
+    if (cfg->n_speakers > 1 && b.rc == 0) {
+        const ttsamd_tensor* e = b.get("speaker_emb.weight", (int64_t)cfg->n_speakers * d);
+        if (e) {
+            h->spk_emb = (int64_t)b.blob.size();
+            for (int64_t i = 0; i < numel(e); ++i) b.blob.push_back(e->data[i] * cfg->speaker_emb_weight);  // model.py:361
+            b.blob.resize(align_up((int64_t)b.blob.size(), 64));
+        }
+    }
+    int32_t rc = b.rc;
+    if (rc == 0) {
+        hipError_t e = hipMalloc((void**)&h->dev, b.blob.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(h->dev, b.blob.data(), b.blob.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("fastpitch_create: weight upload failed: %s", hipGetErrorString(e));
+            rc = TTSAMD_EHIP;
+        }
+    }
+    if (rc) {
+        if (h->dev) (void)hipFree(h->dev);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void fastpitch_destroy(FastPitch* h) {
+    if (!h) return;
+    if (h->dev) (void)hipFree(h->dev);
+    delete h;
+}
+
+// ------------------------------------------------------------------------------------
+
+struct FftWs {
+    float *q, *a, *y, *hid;
+};
+
+static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, float* y, const float* res, int B, int S,
+                        const int64_t* lens_in, int relu, hipStream_t s) {
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x; p.x_bs = (int64_t)c.cin * S; p.x_cs = S;
+    p.w = h->dev + c.w_off; p.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
+    p.y = y; p.y_bs = (int64_t)c.cout * S; p.y_cs = S; p.y_ts = 1;
+    p.res = res; p.r_bs = (int64_t)c.cout * S; p.r_cs = S;
+    p.lens_in = lens_in; p.lens_out = nullptr; p.len_in_mul = 1; p.len_out_mul = 1;
+    p.Lin = S; p.Nout = S;
+    p.Cin = c.cin; p.Cout = c.cout; p.CoutP = cout_padded(c.cout); p.K = c.k;
+    p.dil = 1; p.pad = c.k / 2;
+    p.n_phase = 1; p.in_slope = 1.0f; p.relu_out = relu; p.mode = 0; p.div = 1.f; p.batch = B;
+    prof_begin(s, 2.0 * c.cout * c.cin * c.k);
+    const int32_t rc = launch_conv(p, s);
+    prof_end(s);
+    return rc;
+}
+
+// transformer.py:172-177 x n_layers.  x is updated in place.
+static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, int d_head, float* x,
+                       const int64_t* lens, int B, int S, const FftWs& w, hipStream_t s) {
+    const int d = h->cfg.d_model;
+    const float scale = 1.0f / std::sqrt((float)d_head);
+    for (const FftLayer& l : layers) {
+        TTS_TRY(run_conv(h, l.qkv, x, w.q, nullptr, B, S, nullptr, 0, s));
+        TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s));
+        TTS_TRY(run_conv(h, l.o_net, w.a, w.y, x, B, S, nullptr, 0, s));
+        TTS_TRY(launch_layernorm_cf(w.y, w.y, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
+        TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s));
+        TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, nullptr, 0, s));
+        TTS_TRY(launch_layernorm_cf(x, x, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
+    }
+    return 0;
+}
+
+// model.py:129-133; input masked on load (lens_in), hidden NOT masked
+static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const float* x, const int64_t* lens, int B,
+                             int S, float* t0, float* t1, float* out, float* out2, float max_dur, float mul,
+                             float add, hipStream_t s) {
+    const float* src = x;
+    float* bufs[2] = {t0, t1};
+    for (size_t i = 0; i < pr.convs.size(); ++i) {
+        float* dst = bufs[i & 1];
+        TTS_TRY(run_conv(h, pr.convs[i], src, dst, nullptr, B, S, i == 0 ? lens : nullptr, 1, s));
+        TTS_TRY(launch_layernorm_cf(dst, dst, h->dev + pr.ln_g[i], h->dev + pr.ln_b[i], nullptr, 0, B, pr.filter, S, s));
+        src = dst;
+    }
+    return launch_pred_fc(src, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul,
+                          add, s);
+}
+
+struct EncWs {
+    FftWs f;
+    float *p0, *p1, *log_dur;
+    int64_t* lens;
+};
+
+static void carve_enc(const FastPitch* h, Arena& a, int B, int L, EncWs& w) {
+    const ttsamd_fastpitch_cfg& c = h->cfg;
+    const int d = c.d_model;
+    const int filt = std::max(std::max(c.dur_filter, c.pitch_filter), c.energy_filter);
+    w.f.q = a.take<float>((int64_t)B * 3 * c.in_fft_n_heads * c.in_fft_d_head * L);
+    w.f.a = a.take<float>((int64_t)B * c.in_fft_n_heads * c.in_fft_d_head * L);
+    w.f.y = a.take<float>((int64_t)B * d * L);
+    w.f.hid = a.take<float>((int64_t)B * c.in_fft_filter * L);
+    w.p0 = a.take<float>((int64_t)B * filt * L);
+    w.p1 = a.take<float>((int64_t)B * filt * L);
+    w.log_dur = a.take<float>((int64_t)B * L);
+    w.lens = a.take<int64_t>(B);
+}
+
+int64_t fastpitch_encode_workspace_bytes(const FastPitch* h, int32_t B, int32_t L) {
+    Arena a(nullptr, 0);
+    EncWs w;
+    carve_enc(h, a, B, L, w);
+    return a.off;
+}
+
+int32_t fastpitch_encode(const FastPitch* h, const int64_t* ids, int32_t B, int32_t L, int32_t speaker, float pace,
+                         const float* dur_tgt, const float* pitch_tgt, const float* energy_tgt, float pitch_mul,
+                         float pitch_add, float max_duration, float* enc_cond, float* dur_pred, float* pitch_pred,
+                         float* energy_pred, int64_t* reps, int64_t* dec_lens, void* ws, int64_t ws_bytes,
+                         hipStream_t s) {
+    TTS_REQUIRE(h && ids && enc_cond && dur_pred && pitch_pred && reps && dec_lens, "fastpitch_encode: null argument");
+    TTS_REQUIRE(B >= 1 && L >= 1 && L <= h->pos_cap, "fastpitch_encode: bad batch/n_tokens (%d, %d; cap %d)", B, L,
+                h->pos_cap);
+    TTS_REQUIRE(pace > 0.f, "fastpitch_encode: pace must be > 0");
+    const ttsamd_fastpitch_cfg& c = h->cfg;
+    TTS_REQUIRE(c.n_speakers <= 1 || (speaker >= 0 && speaker < c.n_speakers), "fastpitch_encode: speaker %d out of range", speaker);
+    TTS_REQUIRE(!c.energy_conditioning || energy_pred || energy_tgt, "fastpitch_encode: energy_pred is null");
+    Arena a(ws, ws_bytes);
+    EncWs w;
+    carve_enc(h, a, B, L, w);
+    if (!ws || !a.ok) {
+        set_error("fastpitch_encode: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
+        return TTSAMD_ENOMEM;
+    }
+    const int d = c.d_model;
+    float* x = enc_cond;
+    const float* spk = (c.n_speakers > 1 && h->spk_emb >= 0) ? h->dev + h->spk_emb + (int64_t)speaker * d : nullptr;
+    TTS_TRY(launch_embed(ids, h->dev + h->word_emb, h->dev + h->pos_enc, h->pos_cap, spk, c.padding_idx, B, L, d, x,
+                         w.lens, s));
+    TTS_TRY(run_fft(h, h->enc, c.in_fft_d_head, x, w.lens, B, L, w.f, s));
+    // durations (model.py:367-368)
+    TTS_TRY(run_predictor(h, h->dur, x, w.lens, B, L, w.p0, w.p1, w.log_dur, dur_pred, max_duration, 1.f, 0.f, s));
+    // pitch (model.py:371-386); pitch_trf = mul*p + add (networks.py:38-42)
+    TTS_TRY(run_predictor(h, h->pitch, x, w.lens, B, L, w.p0, w.p1, pitch_pred, nullptr, 0.f, pitch_mul, pitch_add, s));
+    TTS_TRY(launch_scalar_emb_add(x, pitch_tgt ? pitch_tgt : pitch_pred, h->dev + h->pitch_emb_w,
+                                  h->dev + h->pitch_emb_b, B, d, L, c.pitch_emb_kernel, s));
+    // energy (model.py:389-399)
+    if (c.energy_conditioning) {
+        if (energy_pred)
+            TTS_TRY(run_predictor(h, h->energy, x, w.lens, B, L, w.p0, w.p1, energy_pred, nullptr, 0.f, 1.f, 0.f, s));
+        TTS_TRY(launch_scalar_emb_add(x, energy_tgt ? energy_tgt : energy_pred, h->dev + h->energy_emb_w,
+                                      h->dev + h->energy_emb_b, B, d, L, c.energy_emb_kernel, s));
+    }
+    // integer half of regulate_len (model.py:72-76)
+    return launch_durations_to_reps(dur_tgt ? dur_tgt : dur_pred, pace, B, L, reps, dec_lens, s);
+}
+
+static void carve_dec(const FastPitch* h, Arena& a, int B, int T, FftWs& w) {
+    const ttsamd_fastpitch_cfg& c = h->cfg;
+    w.q = a.take<float>((int64_t)B * 3 * c.out_fft_n_heads * c.out_fft_d_head * T);
+    w.a = a.take<float>((int64_t)B * c.out_fft_n_heads * c.out_fft_d_head * T);
+    w.y = a.take<float>((int64_t)B * c.d_model * T);
+    w.hid = a.take<float>((int64_t)B * c.out_fft_filter * T);
+}
+
+int64_t fastpitch_decode_workspace_bytes(const FastPitch* h, int32_t B, int32_t T) {
+    Arena a(nullptr, 0);
+    FftWs w;
+    carve_dec(h, a, B, T, w);
+    return a.off;
+}
+
+int32_t fastpitch_decode(const FastPitch* h, float* x, const int64_t* dec_lens, int32_t B, int32_t T, float* mel,
+                         void* ws, int64_t ws_bytes, hipStream_t s) {
+    TTS_REQUIRE(h && x && dec_lens && mel, "fastpitch_decode: null argument");
+    TTS_REQUIRE(B >= 1 && T >= 1 && T <= h->pos_cap, "fastpitch_decode: bad batch/t_max (%d, %d; cap %d)", B, T,
+                h->pos_cap);
+    Arena a(ws, ws_bytes);
+    FftWs w;
+    carve_dec(h, a, B, T, w);
+    if (!ws || !a.ok) {
+        set_error("fastpitch_decode: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
+        return TTSAMD_ENOMEM;
+    }
+    const ttsamd_fastpitch_cfg& c = h->cfg;
+    // decoder input = len_regulated + pos_emb*mask (transformer.py:215-219, embed_input=False)
+    TTS_TRY(launch_add_pos(x, h->dev + h->pos_dec, h->pos_cap, dec_lens, B, c.d_model, T, s));
+    TTS_TRY(run_fft(h, h->dec, c.out_fft_d_head, x, dec_lens, B, T, w, s));
+    // proj + permute (model.py:406-408): channel-first output IS the permuted layout
+    return run_conv(h, h->proj, x, mel, nullptr, B, T, nullptr, 0, s);
+}
+
+}  // namespace ttsamd

@@ -1,0 +1,288 @@
+// HiFi-GAN V1 generator on the MFMA conv engine: handle creation (weight-norm fold, weight
+// re-layout, upload) and the batched ragged forward.
+// Replaces vocoder.load_hifigan (vocoder/__init__.py:3-20) and Generator.forward
+// (vocoder/hifigan/models.py:111-127) incl. ResBlock1.forward (:46-53).
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace ttsamd {
+
+struct ConvW {
+    int64_t w_off = 0, b_off = 0;  // float offsets into the device weight blob
+    int cin = 0, cout = 0, k = 0;
+};
+
+struct HifiGan {
+    ttsamd_hifigan_cfg cfg;
+    float* dev = nullptr;  // one blob with every packed weight and bias
+    ConvW conv_pre, conv_post;
+    std::vector<ConvW> ups;
+    std::vector<ConvW> c1, c2;  // [stage*n_kernels + j][m]
+    int hop = 1;
+    int64_t max_cl = 0;  // max over stages of C * (L / T)
+};
+
+using TensorMap = std::map<std::string, const ttsamd_tensor*>;
+
+static int64_t numel(const ttsamd_tensor* t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+}
+
+// Folded weight of `<base>` : either `<base>.weight`, or g*v/||v|| from the weight-norm pair
+// (norm over all dims but 0, as torch._weight_norm(v, g, 0); vocoder/hifigan/models.py:129-136).
+static int32_t folded_weight(const TensorMap& tm, const std::string& base, int ndim_expected,
+                             std::vector<float>& out, int64_t shape[3]) {
+    const ttsamd_tensor *w = nullptr, *g = nullptr, *v = nullptr;
+    auto it = tm.find(base + ".weight");
+    if (it != tm.end()) w = it->second;
+    if (!w) {
+        auto ig = tm.find(base + ".parametrizations.weight.original0");
+        auto iv = tm.find(base + ".parametrizations.weight.original1");
+        if (ig == tm.end() || iv == tm.end()) {
+            ig = tm.find(base + ".weight_g");
+            iv = tm.find(base + ".weight_v");
+        }
+        TTS_REQUIRE(ig != tm.end() && iv != tm.end(), "hifigan: no weight for layer '%s'", base.c_str());
+        g = ig->second;
+        v = iv->second;
+    }
+    const ttsamd_tensor* src = w ? w : v;
+    TTS_REQUIRE(src->ndim == ndim_expected, "hifigan: '%s' has ndim %d, expected %d", base.c_str(), src->ndim,
+                ndim_expected);
+    for (int i = 0; i < 3; ++i) shape[i] = src->shape[i];
+    const int64_t n = numel(src);
+    out.resize(n);
+    if (w) {
+        std::memcpy(out.data(), w->data, n * sizeof(float));
+        return 0;
+    }
+    const int64_t d0 = v->shape[0], inner = n / d0;
+    TTS_REQUIRE(numel(g) == d0, "hifigan: '%s' weight_g has %lld elements, expected %lld", base.c_str(),
+                (long long)numel(g), (long long)d0);
+    for (int64_t i = 0; i < d0; ++i) {
+        double ss = 0.0;
+        const float* vr = v->data + i * inner;
+        for (int64_t j = 0; j < inner; ++j) ss += (double)vr[j] * vr[j];
+        const float scale = g->data[i] / (float)std::sqrt(ss);
+        for (int64_t j = 0; j < inner; ++j) out[i * inner + j] = vr[j] * scale;
+    }
+    return 0;
+}
+
+static int32_t get_bias(const TensorMap& tm, const std::string& base, int n, std::vector<float>& blob,
+                        int64_t& off) {
+    auto it = tm.find(base + ".bias");
+    TTS_REQUIRE(it != tm.end() && numel(it->second) == n, "hifigan: missing/mis-sized '%s.bias'", base.c_str());
+    off = (int64_t)blob.size();
+    blob.insert(blob.end(), it->second->data, it->second->data + n);
+    blob.resize(align_up((int64_t)blob.size(), 64));
+    return 0;
+}
+
+static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, int cout, int k,
+                        std::vector<float>& blob, ConvW& cw) {
+    std::vector<float> w;
+    int64_t shp[3];
+    TTS_TRY(folded_weight(tm, base, 3, w, shp));
+    TTS_REQUIRE(shp[0] == cout && shp[1] == cin && shp[2] == k, "hifigan: '%s' has shape [%lld,%lld,%lld], expected [%d,%d,%d]",
+                base.c_str(), (long long)shp[0], (long long)shp[1], (long long)shp[2], cout, cin, k);
+    cw.cin = cin; cw.cout = cout; cw.k = k;
+    cw.w_off = (int64_t)blob.size();
+    blob.resize(blob.size() + (size_t)cin * k * cout_padded(cout));
+    pack_conv_weight(w.data(), cout, cin, k, blob.data() + cw.w_off);
+    blob.resize(align_up((int64_t)blob.size(), 64));
+    return get_bias(tm, base, cout, blob, cw.b_off);
+}
+
+int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hifigan_cfg* cfg, HifiGan** out) {
+    TTS_REQUIRE(weights && cfg && out, "hifigan_create: null argument");
+    TTS_REQUIRE(cfg->n_ups >= 1 && cfg->n_ups <= 8 && cfg->n_kernels >= 1 && cfg->n_kernels <= 8 &&
+                cfg->n_dilations >= 1 && cfg->n_dilations <= 8, "hifigan_create: bad config counts");
+    TensorMap tm;
+    for (int i = 0; i < n; ++i) tm[weights[i].name] = &weights[i];
+    auto* h = new HifiGan();
+    h->cfg = *cfg;
+    std::vector<float> blob;
+    const int c0 = cfg->upsample_initial_channel;
+    int32_t rc = add_conv(tm, "conv_pre", cfg->num_mels, c0, 7, blob, h->conv_pre);
+    int ch = c0, mul = 1;
+    h->max_cl = c0;
+    for (int i = 0; rc == 0 && i < cfg->n_ups; ++i) {
+        const int u = cfg->upsample_rates[i], kt = cfg->upsample_kernel_sizes[i];
+        const int cin = ch, cout = ch / 2;
+        if (kt != 2 * u || (kt - u) % 2 != 0) {
+            set_error("hifigan: upsample kernel %d / rate %d: only kernel = 2*rate is built", kt, u);
+            rc = TTSAMD_EINVAL;
+            break;
+        }
+        std::vector<float> w;
+        int64_t shp[3];
+        rc = folded_weight(tm, "ups." + std::to_string(i), 3, w, shp);
+        if (rc) break;
+        if (shp[0] != cin || shp[1] != cout || shp[2] != kt) {
+            set_error("hifigan: ups.%d has shape [%lld,%lld,%lld], expected [%d,%d,%d]", i, (long long)shp[0],
+                      (long long)shp[1], (long long)shp[2], cin, cout, kt);
+            rc = TTSAMD_EINVAL;
+            break;
+        }
+        ConvW cw;
+        cw.cin = cin; cw.cout = cout; cw.k = kt;
+        cw.w_off = (int64_t)blob.size();
+        blob.resize(blob.size() + (size_t)u * cin * 2 * cout_padded(cout));
+        pack_convt_weight(w.data(), cin, cout, kt, u, (kt - u) / 2, blob.data() + cw.w_off);
+        blob.resize(align_up((int64_t)blob.size(), 64));
+        rc = get_bias(tm, "ups." + std::to_string(i), cout, blob, cw.b_off);
+        if (rc) break;
+        h->ups.push_back(cw);
+        ch = cout;
+        mul *= u;
+        h->max_cl = std::max<int64_t>(h->max_cl, (int64_t)ch * mul);
+        for (int j = 0; rc == 0 && j < cfg->n_kernels; ++j) {
+            const int r = i * cfg->n_kernels + j, kk = cfg->resblock_kernel_sizes[j];
+            for (int m = 0; rc == 0 && m < cfg->n_dilations; ++m) {
+                ConvW a, b;
+                rc = add_conv(tm, "resblocks." + std::to_string(r) + ".convs1." + std::to_string(m), ch, ch, kk, blob, a);
+                if (rc) break;
+                rc = add_conv(tm, "resblocks." + std::to_string(r) + ".convs2." + std::to_string(m), ch, ch, kk, blob, b);
+                h->c1.push_back(a);
+                h->c2.push_back(b);
+            }
+        }
+    }
+    h->hop = mul;
+    if (rc == 0) {
+        // conv_post: [1][C][7] -> plain [C][7]
+        std::vector<float> w;
+        int64_t shp[3];
+        rc = folded_weight(tm, "conv_post", 3, w, shp);
+        if (rc == 0 && (shp[0] != 1 || shp[1] != ch || shp[2] != 7)) {
+            set_error("hifigan: conv_post has shape [%lld,%lld,%lld], expected [1,%d,7]", (long long)shp[0],
+                      (long long)shp[1], (long long)shp[2], ch);
+            rc = TTSAMD_EINVAL;
+        }
+        if (rc == 0) {
+            h->conv_post.cin = ch; h->conv_post.cout = 1; h->conv_post.k = 7;
+            h->conv_post.w_off = (int64_t)blob.size();
+            blob.insert(blob.end(), w.begin(), w.end());
+            blob.resize(align_up((int64_t)blob.size(), 64));
+            rc = get_bias(tm, "conv_post", 1, blob, h->conv_post.b_off);
+        }
+    }
+    if (rc == 0) {
+        hipError_t e = hipMalloc((void**)&h->dev, blob.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(h->dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("hifigan_create: weight upload failed: %s", hipGetErrorString(e));
+            rc = TTSAMD_EHIP;
+        }
+    }
+    if (rc != 0) {
+        if (h->dev) (void)hipFree(h->dev);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void hifigan_destroy(HifiGan* h) {
+    if (!h) return;
+    if (h->dev) (void)hipFree(h->dev);
+    delete h;
+}
+
+int64_t hifigan_workspace_bytes(const HifiGan* h, int32_t B, int32_t T) {
+    Arena a(nullptr, 0);
+    for (int i = 0; i < 4; ++i) a.take<float>((int64_t)B * h->max_cl * T);
+    return a.off;
+}
+
+int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens, int32_t B, int32_t T, float* wave,
+                        void* ws, int64_t ws_bytes, hipStream_t s) {
+    TTS_REQUIRE(h && mel && wave && B >= 1 && T >= 1, "hifigan_forward: bad argument");
+    Arena a(ws, ws_bytes);
+    float* buf[4];
+    for (int i = 0; i < 4; ++i) buf[i] = a.take<float>((int64_t)B * h->max_cl * T);
+    if (!ws || !a.ok) {
+        set_error("hifigan_forward: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
+        return TTSAMD_ENOMEM;
+    }
+    const ttsamd_hifigan_cfg& cfg = h->cfg;
+    float *cur = buf[0], *ups_out = buf[1], *R = buf[2], *Tb = buf[3];
+
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.batch = B;
+    p.lens_in = lens; p.lens_out = lens;
+    p.n_phase = 1; p.div = 1.f;
+    auto conv = [&](const ConvW& cw, const float* x, int C_in_stride_L, float* y, const float* res, int L, int mul,
+                    int dil, float slope, int mode, float div) -> int32_t {
+        p.x = x; p.x_bs = (int64_t)cw.cin * L; p.x_cs = L;
+        p.w = h->dev + cw.w_off; p.bias = h->dev + cw.b_off;
+        p.y = y; p.y_bs = (int64_t)cw.cout * L; p.y_cs = L; p.y_ts = 1;
+        p.res = res; p.r_bs = (int64_t)cw.cout * L; p.r_cs = L;
+        p.len_in_mul = mul; p.len_out_mul = mul; p.Lin = L; p.Nout = L;
+        p.Cin = cw.cin; p.Cout = cw.cout; p.CoutP = cout_padded(cw.cout); p.K = cw.k;
+        p.dil = dil; p.pad = (cw.k * dil - dil) / 2;
+        p.n_phase = 1; p.phase_p = 0;
+        p.in_slope = slope; p.relu_out = 0; p.mode = mode; p.div = div;
+        (void)C_in_stride_L;
+        prof_begin(s, 2.0 * cw.cout * cw.cin * cw.k * mul);
+        const int32_t rc = launch_conv(p, s);
+        prof_end(s);
+        return rc;
+    };
+
+    // conv_pre (models.py:112)
+    TTS_TRY(conv(h->conv_pre, mel, 0, cur, nullptr, T, 1, 1, 1.0f, 0, 1.f));
+    int L = T, mul = 1;
+    for (int i = 0; i < cfg.n_ups; ++i) {
+        const int u = cfg.upsample_rates[i], kt = cfg.upsample_kernel_sizes[i];
+        const ConvW& uw = h->ups[i];
+        // leaky_relu(0.1) + ConvTranspose1d as u polyphase 2-tap convs (models.py:114-115)
+        p.x = cur; p.x_bs = (int64_t)uw.cin * L; p.x_cs = L;
+        p.w = h->dev + uw.w_off; p.bias = h->dev + uw.b_off;
+        p.y = ups_out; p.y_bs = (int64_t)uw.cout * L * u; p.y_cs = L * u; p.y_ts = u;
+        p.res = nullptr;
+        p.len_in_mul = mul; p.len_out_mul = mul; p.Lin = L; p.Nout = L;
+        p.Cin = uw.cin; p.Cout = uw.cout; p.CoutP = cout_padded(uw.cout); p.K = 2;
+        p.dil = -1; p.pad = 0; p.n_phase = u; p.phase_p = (kt - u) / 2;
+        p.in_slope = 0.1f; p.relu_out = 0; p.mode = 0; p.div = 1.f;
+        prof_begin(s, 2.0 * uw.cout * uw.cin * 2 * u * mul);
+        int32_t rc = launch_conv(p, s);
+        prof_end(s);
+        TTS_TRY(rc);
+        L *= u; mul *= u;
+        // 3 ResBlock1 on the same input, averaged (models.py:116-122, 46-53)
+        for (int j = 0; j < cfg.n_kernels; ++j) {
+            const float* src = ups_out;
+            for (int m = 0; m < cfg.n_dilations; ++m) {
+                const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
+                const int d = cfg.resblock_dilations[j][m];
+                TTS_TRY(conv(h->c1[li], src, 0, Tb, nullptr, L, mul, d, 0.1f, 0, 1.f));
+                if (m + 1 < cfg.n_dilations) {
+                    TTS_TRY(conv(h->c2[li], Tb, 0, R, src, L, mul, 1, 0.1f, 0, 1.f));
+                    src = R;
+                } else {
+                    const int mode = (j == 0) ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2);
+                    const int md = cfg.n_kernels == 1 ? 0 : mode;
+                    TTS_TRY(conv(h->c2[li], Tb, 0, cur, src, L, mul, 1, 0.1f, md, (float)cfg.n_kernels));
+                }
+            }
+        }
+    }
+    // leaky_relu (default slope 0.01) + conv_post + tanh (models.py:123-125)
+    TTS_TRY(launch_conv_post(cur, (int64_t)h->conv_post.cin * L, L, h->dev + h->conv_post.w_off,
+                             h->dev + h->conv_post.b_off, lens, mul, B, h->conv_post.cin, L, 0.01f, wave,
+                             (int64_t)L, s));
+    return 0;
+}
+
+}  // namespace ttsamd

@@ -1,0 +1,56 @@
+// Launchers of the small (HBM-bound / latency-bound) kernels around the MFMA conv engine.
+#pragma once
+#include "common.hpp"
+
+namespace ttsamd {
+
+// HiFi-GAN tail: wave[b][t] = tanh(b0 + sum_{c,k} w[c][k] * lrelu_0.01(x[b][c][t+k-3]))
+// (vocoder/hifigan/models.py:123-125).  x [B][C][L] (row stride L), w [C][7] device.
+int32_t launch_conv_post(const float* x, int64_t x_bs, int32_t x_cs, const float* w, const float* bias,
+                         const int64_t* lens, int32_t len_mul, int32_t B, int32_t C, int32_t L,
+                         float in_slope, float* wave, int64_t wave_bs, hipStream_t s);
+
+// LayerNorm over the channel axis of a channel-first tensor, in place or out of place:
+// y[b][c][t] = ((x - mean_t) * rstd_t * gamma[c] + beta[c]) * (t < lens[b] || !mask)
+// (transformer.py:88,158,174,176; model.py:56).  eps = 1e-5 (torch default).
+int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const float* beta,
+                            const int64_t* lens, int32_t apply_mask, int32_t B, int32_t C, int32_t S,
+                            hipStream_t s);
+
+// Encoder input: x[b][c][t] = word_emb[ids[b][t]][c] + pos[t][c]*(ids!=pad) + spk[c]
+// (transformer.py:212-219; model.py:355-361).  Also writes lens[b] = #non-pad tokens.
+int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos_table, int32_t pos_stride,
+                     const float* spk, int32_t pad_idx, int32_t B, int32_t L, int32_t C, float* x, int64_t* lens, hipStream_t s);
+
+// 1-head self attention over channel-first q,k,v = rows [0,D),[D,2D),[2D,3D) of qkv [B][3D][S]
+// (transformer.py:131-141): out[b][d][i] = sum_j softmax_j(q_i.k_j * scale | j < lens[b]) v_j[d]
+int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S,
+                         float scale, float* out, hipStream_t s);
+
+// Predictor head (model.py:132): out[b][t] = (bias + sum_c w[c]*x[b][c][t]) * (t < lens[b]);
+// mode 1 additionally writes dur = clamp(exp(out)-1, 0, max_dur) (model.py:368) to out2.
+int32_t launch_pred_fc(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t B,
+                       int32_t C, int32_t S, float* out, float* out2, float max_dur, float mul, float add,
+                       hipStream_t s);
+
+// enc[b][c][t] += bias[c] + sum_k w[c][k] * src[b][t+k-K/2]   (Conv1d(1->C,k) embeddings, model.py:382-397)
+int32_t launch_scalar_emb_add(float* enc, const float* src, const float* w, const float* bias, int32_t B,
+                              int32_t C, int32_t S, int32_t K, hipStream_t s);
+
+// Integer half of regulate_len (model.py:72-76): reps=(dur/pace+0.5).long(), dec_lens=sum.
+int32_t launch_durations_to_reps(const float* dur, float pace, int32_t B, int32_t L, int64_t* reps,
+                                 int64_t* dec_lens, hipStream_t s);
+
+// Gather half (model.py:77-85) + optional decoder positional embedding (transformer.py:215-219).
+int32_t launch_regulate_gather(const float* enc, const int64_t* reps, const float* pos_table, int32_t pos_stride, int32_t B,
+                               int32_t L, int32_t C, int32_t T, float* out, int32_t* idx, hipStream_t s);
+
+// x[b][c][t] += pos[t][c] * (t < lens[b])
+int32_t launch_add_pos(float* x, const float* pos_table, int32_t pos_stride, const int64_t* lens, int32_t B, int32_t C,
+                       int32_t S, hipStream_t s);
+
+// Profiling of conv launches (bench roofline)
+void prof_begin(hipStream_t s, double flops);
+void prof_end(hipStream_t s);
+
+}  // namespace ttsamd

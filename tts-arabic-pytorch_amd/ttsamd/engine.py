@@ -1,0 +1,205 @@
+"""Engines = C-ABI handles + workspaces.  PyTorch here is plumbing only (device memory,
+current stream); every FLOP of the path runs in libttsamd.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import NET_CONFIG, HIFIGAN_CONFIG
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise L.TtsAmdError('no ROCm device visible: the ttsamd engines run only on an MI355X (gfx950); '
+                            'there is no CPU fallback')
+    lib = L.load()
+    if not lib.ttsamd_device_ok():
+        raise L.TtsAmdError('device 0 is not gfx950')
+    return lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, device):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class _Workspace:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class HifiGanEngine:
+    """Handle over ttsamd_hifigan_* (replaces vocoder.load_hifigan + Generator.forward)."""
+
+    def __init__(self, state_dict, config=None, device='cuda'):
+        self.lib = _require_gpu()
+        self.device = torch.device(device if device != 'cuda' else 'cuda:0')
+        h = dict(HIFIGAN_CONFIG if config is None else config)
+        if str(h.get('resblock', '1')) != '1':
+            raise L.TtsAmdError('only ResBlock1 generators are built (config.json:2)')
+        cfg = L.HifiGanCfg()
+        cfg.num_mels = h.get('num_mels', 80)
+        cfg.upsample_initial_channel = h['upsample_initial_channel']
+        cfg.n_ups = len(h['upsample_rates'])
+        for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+            cfg.upsample_rates[i], cfg.upsample_kernel_sizes[i] = u, k
+        cfg.n_kernels = len(h['resblock_kernel_sizes'])
+        cfg.n_dilations = len(h['resblock_dilation_sizes'][0])
+        for j, (k, ds) in enumerate(zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes'])):
+            cfg.resblock_kernel_sizes[j] = k
+            for m, d in enumerate(ds):
+                cfg.resblock_dilations[j][m] = d
+        self.hop = int(np.prod(h['upsample_rates']))
+        self.num_mels = cfg.num_mels
+        arr, keep = L.make_tensors(state_dict)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ttsamd_hifigan_create(arr, len(arr), C.byref(cfg), C.byref(handle)), 'hifigan_create')
+        self.handle = handle
+        self.ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, 'handle', None):
+            self.lib.ttsamd_hifigan_destroy(self.handle)
+            self.handle = None
+
+    def forward(self, mel, lens=None):
+        """mel [B,80,T] float32 on the GPU, lens int64 [B] (device) or None -> wave [B, hop*T].
+        Samples past hop*lens[b] are zero."""
+        mel = _f32(mel, self.device)
+        B, M, T = mel.shape
+        assert M == self.num_mels
+        if lens is not None:
+            lens = lens.to(device=self.device, dtype=torch.int64).contiguous()
+        wave = torch.zeros(B, self.hop * T, dtype=torch.float32, device=self.device)
+        if T == 0:
+            return wave
+        with torch.cuda.device(self.device):
+            nbytes = self.lib.ttsamd_hifigan_workspace_bytes(self.handle, B, T)
+            ws = self.ws.get(nbytes, self.device)
+            L.check(self.lib.ttsamd_hifigan_forward(self.handle, _ptr(mel), _ptr(lens), B, T, _ptr(wave), _ptr(ws),
+                                                    nbytes, _stream()), 'hifigan_forward')
+        return wave
+
+
+class FastPitchEngine:
+    """Handle over ttsamd_fastpitch_* (replaces FastPitch.infer, model.py:351-409)."""
+
+    def __init__(self, state_dict, config=None, device='cuda'):
+        self.lib = _require_gpu()
+        self.device = torch.device(device if device != 'cuda' else 'cuda:0')
+        c = dict(NET_CONFIG if config is None else config)
+        self.config = c
+        cfg = L.FastPitchCfg()
+        cfg.n_mel_channels, cfg.n_symbols, cfg.padding_idx = c['n_mel_channels'], c['n_symbols'], c['padding_idx']
+        cfg.d_model = c['symbols_embedding_dim']
+        cfg.in_fft_n_layers, cfg.in_fft_n_heads, cfg.in_fft_d_head = c['in_fft_n_layers'], c['in_fft_n_heads'], c['in_fft_d_head']
+        cfg.in_fft_kernel, cfg.in_fft_filter = c['in_fft_conv1d_kernel_size'], c['in_fft_conv1d_filter_size']
+        cfg.out_fft_n_layers, cfg.out_fft_n_heads, cfg.out_fft_d_head = c['out_fft_n_layers'], c['out_fft_n_heads'], c['out_fft_d_head']
+        cfg.out_fft_kernel, cfg.out_fft_filter = c['out_fft_conv1d_kernel_size'], c['out_fft_conv1d_filter_size']
+        cfg.dur_kernel, cfg.dur_filter, cfg.dur_n_layers = c['dur_predictor_kernel_size'], c['dur_predictor_filter_size'], c['dur_predictor_n_layers']
+        cfg.pitch_kernel, cfg.pitch_filter, cfg.pitch_n_layers = c['pitch_predictor_kernel_size'], c['pitch_predictor_filter_size'], c['pitch_predictor_n_layers']
+        cfg.pitch_emb_kernel = c['pitch_embedding_kernel_size']
+        cfg.energy_conditioning = int(bool(c['energy_conditioning']))
+        cfg.energy_kernel, cfg.energy_filter, cfg.energy_n_layers = c['energy_predictor_kernel_size'], c['energy_predictor_filter_size'], c['energy_predictor_n_layers']
+        cfg.energy_emb_kernel = c['energy_embedding_kernel_size']
+        cfg.n_speakers, cfg.speaker_emb_weight = c['n_speakers'], float(c['speaker_emb_weight'])
+        assert c.get('pitch_conditioning_formants', 1) == 1
+        self.d_model, self.n_mel = cfg.d_model, cfg.n_mel_channels
+        arr, keep = L.make_tensors(state_dict)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ttsamd_fastpitch_create(arr, len(arr), C.byref(cfg), C.byref(handle)), 'fastpitch_create')
+        self.handle = handle
+        self.ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, 'handle', None):
+            self.lib.ttsamd_fastpitch_destroy(self.handle)
+            self.handle = None
+
+    def infer(self, ids, pace=1.0, dur_tgt=None, pitch_tgt=None, energy_tgt=None, pitch_mul=1.0, pitch_add=0.0,
+              max_duration=75, speaker=0, return_idx=False):
+        """Same contract as FastPitch.infer (model.py:351-353) with pitch_transform restricted to
+        the affine pitch_trf the reference wrappers install (networks.py:38-42,121-122).
+        ids int64 [B,L] zero-padded at the end.  Returns (mel [B,80,T_max], dec_lens int64 [B],
+        dur_pred [B,L], pitch_pred [B,1,L], energy_pred [B,L] or None)."""
+        dev = self.device
+        ids = torch.as_tensor(ids).to(device=dev, dtype=torch.int64).contiguous()
+        B, Lt = ids.shape
+        d = self.d_model
+        dur_tgt, pitch_tgt, energy_tgt = _f32(dur_tgt, dev), _f32(pitch_tgt, dev), _f32(energy_tgt, dev)
+        enc = torch.empty(B, d, Lt, dtype=torch.float32, device=dev)
+        dur_pred = torch.empty(B, Lt, dtype=torch.float32, device=dev)
+        pitch_pred = torch.empty(B, 1, Lt, dtype=torch.float32, device=dev)
+        energy_pred = torch.empty(B, Lt, dtype=torch.float32, device=dev) if self.config['energy_conditioning'] else None
+        reps = torch.empty(B, Lt, dtype=torch.int64, device=dev)
+        dec_lens = torch.empty(B, dtype=torch.int64, device=dev)
+        lib = self.lib
+        with torch.cuda.device(dev):
+            nb = lib.ttsamd_fastpitch_encode_workspace_bytes(self.handle, B, Lt)
+            ws = self.ws.get(nb, dev)
+            L.check(lib.ttsamd_fastpitch_encode(self.handle, _ptr(ids), B, Lt, int(speaker), float(pace), _ptr(dur_tgt),
+                                                _ptr(pitch_tgt), _ptr(energy_tgt), float(pitch_mul), float(pitch_add),
+                                                float(max_duration), _ptr(enc), _ptr(dur_pred), _ptr(pitch_pred),
+                                                _ptr(energy_pred), _ptr(reps), _ptr(dec_lens), _ptr(ws), nb, _stream()),
+                    'fastpitch_encode')
+            t_max = int(dec_lens.max().item())          # the reference syncs here too (model.py:76)
+            x = torch.empty(B, d, t_max, dtype=torch.float32, device=dev)
+            idx = torch.empty(B, t_max, dtype=torch.int32, device=dev) if return_idx else None
+            mel = torch.empty(B, self.n_mel, t_max, dtype=torch.float32, device=dev)
+            if t_max > 0:
+                L.check(lib.ttsamd_length_regulate(_ptr(enc), _ptr(reps), B, Lt, d, t_max, _ptr(x), _ptr(idx), _stream()),
+                        'length_regulate')
+                nb = lib.ttsamd_fastpitch_decode_workspace_bytes(self.handle, B, t_max)
+                ws = self.ws.get(nb, dev)
+                L.check(lib.ttsamd_fastpitch_decode(self.handle, _ptr(x), _ptr(dec_lens), B, t_max, _ptr(mel), _ptr(ws), nb,
+                                                    _stream()), 'fastpitch_decode')
+        out = (mel, dec_lens, dur_pred, pitch_pred, energy_pred)
+        return out + (idx,) if return_idx else out
+
+
+def conv1d(x, w, bias=None, lens=None, dilation=1, in_slope=1.0, relu_out=False):
+    """Kernel-level entry (parity tests / roofline bench): y = conv1d(lrelu(x), w) + b, 'same' padding."""
+    lib = _require_gpu()
+    x = x.contiguous().float()
+    w = w.contiguous().float()
+    B, cin, lin = x.shape
+    cout, cin2, k = w.shape
+    assert cin == cin2
+    y = torch.zeros(B, cout, lin, dtype=torch.float32, device=x.device)
+    packed = torch.empty(lib.ttsamd_conv1d_packed_floats(cout, cin, k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(lib.ttsamd_conv1d(_ptr(x), _ptr(w), _ptr(bias), _ptr(lens), B, cin, cout, k, dilation, lin,
+                                  float(in_slope), int(relu_out), _ptr(y), _ptr(packed), _stream()), 'conv1d')
+    return y
+
+
+def length_regulate(enc, reps, t_max):
+    lib = _require_gpu()
+    enc = enc.contiguous().float()
+    reps = reps.contiguous().to(torch.int64)
+    B, Cc, Lt = enc.shape
+    out = torch.empty(B, Cc, t_max, dtype=torch.float32, device=enc.device)
+    idx = torch.empty(B, t_max, dtype=torch.int32, device=enc.device)
+    with torch.cuda.device(enc.device):
+        L.check(lib.ttsamd_length_regulate(_ptr(enc), _ptr(reps), B, Lt, Cc, t_max, _ptr(out), _ptr(idx), _stream()),
+                'length_regulate')
+    return out, idx

@@ -1,0 +1,108 @@
+"""ctypes binding of libttsamd.so — one Python function per symbol of include/ttsamd.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libttsamd.so')
+
+
+class TtsAmdError(RuntimeError):
+    pass
+
+
+class Tensor(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('data', C.POINTER(C.c_float)), ('ndim', C.c_int32),
+                ('shape', C.c_int64 * 4)]
+
+
+class HifiGanCfg(C.Structure):
+    _fields_ = [('num_mels', C.c_int32), ('upsample_initial_channel', C.c_int32), ('n_ups', C.c_int32),
+                ('upsample_rates', C.c_int32 * 8), ('upsample_kernel_sizes', C.c_int32 * 8),
+                ('n_kernels', C.c_int32), ('resblock_kernel_sizes', C.c_int32 * 8),
+                ('n_dilations', C.c_int32), ('resblock_dilations', (C.c_int32 * 8) * 8)]
+
+
+class FastPitchCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'n_mel_channels', 'n_symbols', 'padding_idx', 'd_model',
+        'in_fft_n_layers', 'in_fft_n_heads', 'in_fft_d_head', 'in_fft_kernel', 'in_fft_filter',
+        'out_fft_n_layers', 'out_fft_n_heads', 'out_fft_d_head', 'out_fft_kernel', 'out_fft_filter',
+        'dur_kernel', 'dur_filter', 'dur_n_layers',
+        'pitch_kernel', 'pitch_filter', 'pitch_n_layers', 'pitch_emb_kernel',
+        'energy_conditioning', 'energy_kernel', 'energy_filter', 'energy_n_layers', 'energy_emb_kernel',
+        'n_speakers')] + [('speaker_emb_weight', C.c_float)]
+
+
+# every symbol include/ttsamd.h declares: name -> (restype, argtypes)
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    'ttsamd_last_error': (C.c_char_p, []),
+    'ttsamd_version': (_I32, []),
+    'ttsamd_device_ok': (_I32, []),
+    'ttsamd_hifigan_create': (_I32, [C.POINTER(Tensor), _I32, C.POINTER(HifiGanCfg), C.POINTER(_P)]),
+    'ttsamd_hifigan_destroy': (_I32, [_P]),
+    'ttsamd_hifigan_workspace_bytes': (_I64, [_P, _I32, _I32]),
+    'ttsamd_hifigan_forward': (_I32, [_P, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
+    'ttsamd_fastpitch_create': (_I32, [C.POINTER(Tensor), _I32, C.POINTER(FastPitchCfg), C.POINTER(_P)]),
+    'ttsamd_fastpitch_destroy': (_I32, [_P]),
+    'ttsamd_fastpitch_encode_workspace_bytes': (_I64, [_P, _I32, _I32]),
+    'ttsamd_fastpitch_decode_workspace_bytes': (_I64, [_P, _I32, _I32]),
+    'ttsamd_fastpitch_encode': (_I32, [_P, _P, _I32, _I32, _I32, _F, _P, _P, _P, _F, _F, _F,
+                                       _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    'ttsamd_length_regulate': (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'ttsamd_fastpitch_decode': (_I32, [_P, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
+    'ttsamd_conv1d_packed_floats': (_I64, [_I32, _I32, _I32]),
+    'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
+    'ttsamd_profile_enable': (_I32, [_I32]),
+    'ttsamd_profile_read': (_I32, [C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libttsamd.so (built by `make -C tts-arabic-pytorch_amd/csrc` or
+    __graft_entry__.build()).  Fails loudly — there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TtsAmdError(f'{LIB_PATH} is missing: build it with `make -C tts-arabic-pytorch_amd/csrc` '
+                          '(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ttsamd_last_error()
+        raise TtsAmdError(f'{what} failed ({rc}): {msg.decode() if msg else "?"}')
+
+
+def make_tensors(state_dict):
+    """{name: np.float32 array or torch tensor} -> (ctypes array of Tensor, keep-alive list)."""
+    import numpy as np
+    keep, items = [], []
+    for name, v in state_dict.items():
+        if hasattr(v, 'detach'):
+            if not v.is_floating_point():
+                continue
+            v = v.detach().cpu().float().numpy()
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        if a.ndim > 4:
+            continue
+        t = Tensor()
+        nb = name.encode()
+        t.name = nb
+        t.data = a.ctypes.data_as(C.POINTER(C.c_float))
+        t.ndim = a.ndim
+        for i, s in enumerate(a.shape):
+            t.shape[i] = s
+        keep += [a, nb]
+        items.append(t)
+    arr = (Tensor * len(items))(*items)
+    return arr, keep
