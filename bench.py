@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — audio samples/s of the FastPitch -> HiFi-GAN hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--tokens 64]
+
+Workload (BASELINE.json configs[1]): FastPitch+HiFi-GAN, synthetic 64-phoneme x batch 32
+per GPU, fp32, synthetic weights (ttsamd.synth, seed 0), forced durations dur_tgt in [2,12]
+(mean 7 frames/token, T_i ~ 448) so the work is deterministic.  A step = one
+.tts_batch()-equivalent: ids already in HBM -> encoder+predictors -> (host reads dec_lens,
+as the reference does) -> length regulator -> decoder -> ragged batched HiFi-GAN -> audio in
+HBM.  N>1: one process per GPU (torch.distributed.run), weights broadcast once from rank 0
+over RCCL, B utterances PER RANK (weak scaling), audio gathered to rank 0 every step.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'tts-arabic-pytorch_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+SAMPLE_RATE = 22050
+
+
+def cpu_baseline(fp_sd, hg_sd, tokens, seconds_budget=25.0):
+    """The CPU oracle (own restatement of the reference's torch-CPU path, pinned against the
+    real reference by tests/test_oracle_golden.py) timed on this host's cores on a bounded
+    sample of the same workload: batched FastPitch + per-utterance vocoder loop
+    (models/fastpitch/networks.py:322-350)."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import tts_oracle as O
+    from ttsamd import synth
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    fw = O.to_torch(fp_sd)
+    hw = O.fold_weight_norm(hg_sd)
+    b = 2
+    ids = synth.synth_ids(b, tokens)
+    dur = synth.synth_durations(b, tokens)
+    with torch.inference_mode():
+        O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids[:1, :8], dur_tgt=dur[:1, :8])      # warm-up
+        t0 = time.perf_counter()
+        n_samples, n_utts = 0, 0
+        while True:
+            _, dec_lens, waves = O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids, dur_tgt=dur)
+            n_samples += int(sum(w.numel() for w in waves))
+            n_utts += b
+            el = time.perf_counter() - t0
+            if el > seconds_budget * 0.5:
+                break
+    return {'value': n_samples / el, 'unit': 'audio samples/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': f'{n_utts} utterances x {tokens} tokens (batch {b}, forced durations), '
+                                      f'{el:.1f} s of torch-CPU fp32 on {os.cpu_count()} host cpus',
+            'rtf': el / (n_samples / SAMPLE_RATE)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
+    ap.add_argument('--tokens', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world == 1:
+        print('bench.py: --gpus N>1 must be launched with torch.distributed.run', file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from ttsamd import synth, lib as L
+    from ttsamd.engine import FastPitchEngine, HifiGanEngine
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        from ttsamd import dp
+        fp_sd = synth.fastpitch_state_dict() if rank == 0 else None
+        hg_sd = synth.hifigan_state_dict() if rank == 0 else None
+        fp_sd = dp.broadcast_state_dict(fp_sd, dev)          # C1: RCCL broadcast over xGMI
+        hg_sd = dp.broadcast_state_dict(hg_sd, dev)
+    else:
+        fp_sd, hg_sd = synth.fastpitch_state_dict(), synth.hifigan_state_dict()
+
+    fp = FastPitchEngine(fp_sd, device=dev)
+    hg = HifiGanEngine(hg_sd, device=dev)
+    B, Lt = args.batch, args.tokens
+    # distinct synthetic utterances per rank (global batch = world * B)
+    ids_all = synth.synth_ids(world * B, Lt)
+    dur_all = synth.synth_durations(world * B, Lt)
+    ids = torch.from_numpy(ids_all[rank * B:(rank + 1) * B]).to(dev)
+    dur = torch.from_numpy(dur_all[rank * B:(rank + 1) * B]).to(dev)
+
+    def step():
+        mel, dec_lens, *_ = fp.infer(ids, dur_tgt=dur)
+        wave = hg.forward(mel, dec_lens)
+        if world > 1:
+            dp.gather_audio(wave, dec_lens * hg.hop)         # C2: audio fan-in to rank 0
+        return wave, dec_lens
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    lib = L.load()
+    lib.ttsamd_profile_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wave, dec_lens = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    prof = (ctypes.c_double * 3)()
+    L.check(lib.ttsamd_profile_read(prof), 'profile_read')
+    lib.ttsamd_profile_enable(0)
+
+    frames = int(dec_lens.sum().item())
+    samples = frames * hg.hop * args.steps
+    tot = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot[1:].clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, samples = float(mx[0]), float(sm[0])
+
+    if rank == 0:
+        conv_ms, n_launch, flop_per_frame = prof[0], prof[1], prof[2]
+        # algorithmic FLOPs of the bracketed MFMA conv launches over the timed region on this rank:
+        # per launch 2*Cout*Cin*K per output position; positions summed per utterance length.
+        # FastPitch encoder launches work on tokens, decoder + vocoder on frames; the library
+        # accumulates FLOP per *unit length* and we scale by the mean units per launch below.
+        t_max = int(dec_lens.max().item())
+        # exact accounting: HiFi-GAN convs process sum(frames)*mul positions (ragged, early exit);
+        # FastPitch decoder convs process B*T_max positions, encoder convs B*L positions.
+        from ttsamd.config import NET_CONFIG as NC, HIFIGAN_CONFIG as HC
+        hg_fpf = hifigan_flops_per_frame(HC)
+        dec_fpt, enc_fpt = fastpitch_conv_flops_per_pos(NC)
+        flops = args.steps * (hg_fpf * frames + dec_fpt * B * t_max + enc_fpt * B * Lt)
+        achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            'metric': 'audio samples/sec (FastPitch+HiFi-GAN, synthetic 64-phoneme inputs)',
+            'value': samples / elapsed, 'unit': 'audio samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (ids, forced durations, random-init weights)',
+            'rtf': elapsed / (samples / SAMPLE_RATE),
+            'config': {'workload': f'FastPitch+HiFi-GAN, synthetic {Lt}-phoneme x batch{B} per GPU, fp32, '
+                                   f'{world}xMI355X', 'batch_per_gpu': B, 'n_tokens': Lt,
+                       'frames_per_step_rank0': frames, 'parallelism': f'dp{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv1d_mfma_f32 (all instantiations)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'launches': int(n_launch), 'avg_launch_ms': conv_ms / max(1.0, n_launch),
+                         'kernel_ms_per_step': conv_ms / args.steps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(fp_sd, hg_sd, Lt)
+        elif world > 1:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def hifigan_flops_per_frame(h):
+    """Algorithmic FLOPs (2*MAC) of the MFMA conv launches per mel frame: conv_pre, the
+    polyphase upsamplers and every ResBlock1 conv (614.1 MFLOP/frame incl. conv_post)."""
+    c0 = h['upsample_initial_channel']
+    f = 2.0 * c0 * h['num_mels'] * 7
+    ch, mul = c0, 1
+    for u, k in zip(h['upsample_rates'], h['upsample_kernel_sizes']):
+        f += 2.0 * (ch // 2) * ch * k / u * (mul * u)        # k/u taps per output sample
+        ch, mul = ch // 2, mul * u
+        for kk, dil in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+            f += len(dil) * 2 * (2.0 * ch * ch * kk) * mul
+    return f
+
+
+def fastpitch_conv_flops_per_pos(c):
+    """(decoder FLOP per frame incl. proj, encoder+predictor FLOP per token) of the MFMA conv launches."""
+    d = c['symbols_embedding_dim']
+
+    def layer(dh, nh, filt, k):
+        return 2.0 * d * 3 * nh * dh + 2.0 * nh * dh * d + 2.0 * d * filt * k * 2
+    dec = c['out_fft_n_layers'] * layer(c['out_fft_d_head'], c['out_fft_n_heads'], c['out_fft_conv1d_filter_size'],
+                                        c['out_fft_conv1d_kernel_size']) + 2.0 * d * c['n_mel_channels']
+    enc = c['in_fft_n_layers'] * layer(c['in_fft_d_head'], c['in_fft_n_heads'], c['in_fft_conv1d_filter_size'],
+                                       c['in_fft_conv1d_kernel_size'])
+    for p in ('dur', 'pitch', 'energy'):
+        if p == 'energy' and not c['energy_conditioning']:
+            continue
+        f, k, n = c[f'{p}_predictor_filter_size'], c[f'{p}_predictor_kernel_size'], c[f'{p}_predictor_n_layers']
+        enc += 2.0 * d * f * k + (n - 1) * 2.0 * f * f * k
+    return dec, enc
+
+
+if __name__ == '__main__':
+    main()

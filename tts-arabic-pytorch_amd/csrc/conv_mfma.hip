@@ -23,11 +23,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 16;  // input channels staged per LDS chunk
 
+constexpr int DMAX = 5;  // largest |dilation| the LDS row is sized for
+
+template <int K, int NT_BLK>
+struct Geo {
+    static constexpr int WS = ((NT_BLK + (K - 1) * DMAX + 3) / 4) * 4;  // LDS row stride (floats)
+    static constexpr int NJ = (NT_BLK + (K - 1) * DMAX + 63) / 64;      // 64-wide column steps
+    static constexpr int NLD = (KC / 4) * NJ;                           // staged floats per thread
+};
+
 template <int K, int MT, int NTL, int WM, int WN>
 __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_BLK = WM * MT * 32;
     constexpr int NT_BLK = WN * NTL * 32;
+    using G = Geo<K, NT_BLK>;
+    constexpr int WS = G::WS, NJ = G::NJ, NLD = G::NLD;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int b = blockIdx.z;
@@ -47,11 +58,12 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
     if (p.n_phase > 1) pad = -((phase + p.phase_p) / p.n_phase);
     const int span = (K - 1) * (dil < 0 ? -dil : dil);
     const int lo = (dil < 0 ? (K - 1) * dil : 0) - pad;  // first input position relative to q0
-    const int W = NT_BLK + span;                          // LDS row length
+    const int W = NT_BLK + span;                          // staged row length (<= WS)
 
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
     const float* __restrict__ wp = p.w + (int64_t)phase * p.Cin * K * p.CoutP;
     const float in_slope = p.in_slope;
+    const int n_chunks = p.Cin / KC;
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -63,53 +75,92 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
 
     const int co_w0 = co_blk0 + wm * MT * 32;
     const int qw0 = wn * NTL * 32;
-    bool nt_ok[NTL];
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) nt_ok[j] = (q0 + qw0 + j * 32) < n_out;
-
+    const bool wave_active = (q0 + qw0) < n_out;   // wave-uniform
     const int kk = lane >> 5, l31 = lane & 31;
-    const int soff = qw0 + l31 - pad - lo;  // >= 0
+    const int soff = qw0 + l31 - pad - lo;         // >= 0
 
-    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
-        __syncthreads();
-        for (int r = wid; r < KC; r += 4) {
-            const float* __restrict__ xr = xb + (int64_t)(c0 + r) * p.x_cs;
-            for (int col = lane; col < W; col += 64) {
-                const int pos = q0 + lo + col;
-                float v = 0.f;
-                if (pos >= 0 && pos < in_len) {
-                    v = xr[pos];
+    // ---- staging: wave w owns rows w, w+4, ...; lanes walk the row 64 columns at a time.
+    // Loads are unconditional (clamped address) + select, so they all issue back to back.
+    float st[NLD];
+    bool st_ok[NJ];
+    int st_pos[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = lane + 64 * j;
+        const int pos = q0 + lo + col;
+        st_ok[j] = (col < W) && (pos >= 0) && (pos < in_len);
+        st_pos[j] = min(max(pos, 0), max(in_len - 1, 0));
+    }
+    auto stage_load = [&](int chunk) {
+        const float* __restrict__ xc = xb + (int64_t)(chunk * KC + wid) * p.x_cs;
+#pragma unroll
+        for (int i = 0; i < KC / 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) st[i * NJ + j] = xc[(int64_t)(4 * i) * p.x_cs + st_pos[j]];
+    };
+    auto stage_write = [&](int buf) {
+        float* sb = smem + buf * (KC * WS);
+#pragma unroll
+        for (int i = 0; i < KC / 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = lane + 64 * j;
+                if (col < WS) {
+                    float v = st[i * NJ + j];
                     v = v > 0.f ? v : v * in_slope;
+                    sb[(wid + 4 * i) * WS + col] = st_ok[j] ? v : 0.f;
                 }
-                smem[r * W + col] = v;
             }
-        }
-        __syncthreads();
-        if (nt_ok[0]) {
+    };
+
+    // ---- A operand (weights): straight from L2 into registers, one channel pair ahead.
+    float a_cur[K][MT], a_nxt[K][MT];
+    const int n_pairs = p.Cin / 2;
+    auto load_a = [&](float (&a)[K][MT], int pair) {
+        pair = min(pair, n_pairs - 1);
+        const float* __restrict__ wrow = wp + (int64_t)(2 * pair + kk) * K * p.CoutP + co_w0 + l31;
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[t][i] = wrow[t * p.CoutP + i * 32];
+    };
+
+    stage_load(0);
+    load_a(a_cur, 0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) stage_load(c + 1);
+        if (wave_active) {
+            const float* sbuf = smem + (c & 1) * (KC * WS) + kk * WS + soff;
 #pragma unroll
             for (int pr = 0; pr < KC / 2; ++pr) {
-                const float* __restrict__ wrow =
-                    wp + (int64_t)(c0 + 2 * pr + kk) * K * p.CoutP + co_w0 + l31;
-                const float* srow = smem + (2 * pr + kk) * W + soff;
+                load_a(a_nxt, c * (KC / 2) + pr + 1);
+                const float* srow = sbuf + (2 * pr) * WS;
 #pragma unroll
                 for (int tap = 0; tap < K; ++tap) {
-                    float a[MT], bq[NTL];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) a[i] = wrow[tap * p.CoutP + i * 32];
+                    float bq[NTL];
 #pragma unroll
                     for (int j = 0; j < NTL; ++j) bq[j] = srow[tap * dil + j * 32];
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NTL; ++j)
-                            if (j == 0 || nt_ok[j])
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[tap][i], bq[j], acc[i][j], 0, 0, 0);
                 }
+#pragma unroll
+                for (int t = 0; t < K; ++t)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) a_cur[t][i] = a_nxt[t][i];
             }
         }
+        if (c + 1 < n_chunks) stage_write((c + 1) & 1);
+        __syncthreads();
     }
 
     // epilogue: bias, residual, activation, accumulate modes
+    if (!wave_active) return;
     float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
     const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs + phase : nullptr;
 #pragma unroll
@@ -138,8 +189,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
 template <int K, int MT, int NTL, int WM, int WN>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
-    const int span = (K - 1) * (p.dil < 0 ? -p.dil : p.dil);
-    const size_t lds = (size_t)KC * (NT_BLK + span) * sizeof(float);
+    const size_t lds = (size_t)2 * KC * Geo<K, NT_BLK>::WS * sizeof(float);
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
     hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN>), grid, dim3(256), lds, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
@@ -165,6 +215,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.Cin % KC == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, KC);
     TTS_REQUIRE(p.CoutP % 32 == 0 && p.CoutP >= p.Cout, "conv: bad CoutP=%d", p.CoutP);
     TTS_REQUIRE(p.n_phase >= 1 && p.batch >= 1, "conv: bad n_phase/batch");
+    TTS_REQUIRE(p.dil >= -DMAX && p.dil <= DMAX && p.dil != 0, "conv: dilation %d outside [-%d,%d]", p.dil, DMAX, DMAX);
     if (p.Nout <= 0) return 0;
     switch (p.K) {
         case 1: return launch_k<1>(p, stream);
