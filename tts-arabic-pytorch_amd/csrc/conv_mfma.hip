@@ -21,15 +21,24 @@ namespace ttsamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KC = 16;  // input channels staged per LDS chunk
-
 constexpr int DMAX = 5;  // largest |dilation| the LDS row is sized for
 
-template <int K, int NT_BLK>
+// Input channels staged per LDS chunk: KC*K ~ 48 (ci,tap) rows so that every chunk carries
+// the same ~6k cycles of MFMA work per wave between two barriers.
+template <int K> struct ChunkOf { static constexpr int KC = K >= 11 ? 4 : (K >= 7 ? 8 : 16); };
+
+template <int K, int NT_BLK, int CO_BLK>
 struct Geo {
-    static constexpr int WS = ((NT_BLK + (K - 1) * DMAX + 3) / 4) * 4;  // LDS row stride (floats)
+    static constexpr int KC = ChunkOf<K>::KC;
+    static constexpr int WS = ((NT_BLK + (K - 1) * DMAX + 3) / 4) * 4;  // X row stride (floats)
     static constexpr int NJ = (NT_BLK + (K - 1) * DMAX + 63) / 64;      // 64-wide column steps
-    static constexpr int NLD = (KC / 4) * NJ;                           // staged floats per thread
+    static constexpr int XROWS = (KC + 3) / 4;                          // X rows per wave
+    static constexpr int NX = XROWS * NJ;                               // staged X floats / thread
+    static constexpr int W4 = KC * K * CO_BLK / 4;                      // float4s of the W chunk
+    static constexpr int NW = (W4 + 255) / 256;                         // staged W float4s / thread
+    static constexpr int X_FLOATS = KC * WS;
+    static constexpr int W_FLOATS = KC * K * CO_BLK;
+    static constexpr int BUF_FLOATS = X_FLOATS + W_FLOATS;              // one pipeline stage
 };
 
 template <int K, int MT, int NTL, int WM, int WN>
@@ -37,8 +46,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_BLK = WM * MT * 32;
     constexpr int NT_BLK = WN * NTL * 32;
-    using G = Geo<K, NT_BLK>;
-    constexpr int WS = G::WS, NJ = G::NJ, NLD = G::NLD;
+    using G = Geo<K, NT_BLK, CO_BLK>;
+    constexpr int KC = G::KC, WS = G::WS, NJ = G::NJ, NX = G::NX, NW = G::NW, XROWS = G::XROWS;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int b = blockIdx.z;
@@ -61,9 +70,10 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
     const int W = NT_BLK + span;                          // staged row length (<= WS)
 
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
-    const float* __restrict__ wp = p.w + (int64_t)phase * p.Cin * K * p.CoutP;
+    const float* __restrict__ wp = p.w + (int64_t)phase * p.Cin * K * p.CoutP + co_blk0;
     const float in_slope = p.in_slope;
     const int n_chunks = p.Cin / KC;
+    const int x_cs = p.x_cs, CoutP = p.CoutP;   // locals: the lambdas below must not capture `p`
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -73,15 +83,16 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int co_w0 = co_blk0 + wm * MT * 32;
     const int qw0 = wn * NTL * 32;
     const bool wave_active = (q0 + qw0) < n_out;   // wave-uniform
     const int kk = lane >> 5, l31 = lane & 31;
     const int soff = qw0 + l31 - pad - lo;         // >= 0
 
-    // ---- staging: wave w owns rows w, w+4, ...; lanes walk the row 64 columns at a time.
-    // Loads are unconditional (clamped address) + select, so they all issue back to back.
-    float st[NLD];
+    // ---- staging registers: X rows (wave w owns rows w, w+4, ..; lanes walk the row) and
+    // the W chunk (a linear float4 copy).  All loads are unconditional (clamped address +
+    // select) so they issue back to back and are only waited for at the end of the chunk.
+    float sx[NX];
+    float sw[4 * NW];
     bool st_ok[NJ];
     int st_pos[NJ];
 #pragma unroll
@@ -91,76 +102,93 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
         st_ok[j] = (col < W) && (pos >= 0) && (pos < in_len);
         st_pos[j] = min(max(pos, 0), max(in_len - 1, 0));
     }
-    auto stage_load = [&](int chunk) {
-        const float* __restrict__ xc = xb + (int64_t)(chunk * KC + wid) * p.x_cs;
-#pragma unroll
-        for (int i = 0; i < KC / 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) st[i * NJ + j] = xc[(int64_t)(4 * i) * p.x_cs + st_pos[j]];
-    };
-    auto stage_write = [&](int buf) {
-        float* sb = smem + buf * (KC * WS);
-#pragma unroll
-        for (int i = 0; i < KC / 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int col = lane + 64 * j;
-                if (col < WS) {
-                    float v = st[i * NJ + j];
-                    v = v > 0.f ? v : v * in_slope;
-                    sb[(wid + 4 * i) * WS + col] = st_ok[j] ? v : 0.f;
-                }
-            }
-    };
+#define TTS_STAGE_LOAD(CH)                                                                          \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < XROWS; ++i) {                                         \
+            const int r = min(wid + 4 * i, KC - 1);                                                 \
+            const float* __restrict__ xc = xb + (int64_t)((CH)*KC + r) * x_cs;                      \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) sx[i * NJ + j] = xc[st_pos[j]];          \
+        }                                                                                           \
+        const float* __restrict__ wc = wp + (int64_t)(CH)*KC * K * CoutP;                           \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                            \
+            const int e = min(tid + 256 * i, G::W4 - 1);                                            \
+            const int row = e / (CO_BLK / 4), c4 = e % (CO_BLK / 4);                                \
+            const float4 t4 = *reinterpret_cast<const float4*>(wc + (int64_t)row * CoutP + 4 * c4); \
+            sw[4 * i + 0] = t4.x; sw[4 * i + 1] = t4.y; sw[4 * i + 2] = t4.z; sw[4 * i + 3] = t4.w; \
+        }                                                                                           \
+    }
+#define TTS_STAGE_WRITE(BUF)                                                                        \
+    {                                                                                               \
+        float* sb = smem + (BUF)*G::BUF_FLOATS;                                                     \
+        _Pragma("unroll") for (int i = 0; i < XROWS; ++i) {                                         \
+            if (wid + 4 * i < KC) {                                                                 \
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                    \
+                    const int col = lane + 64 * j;                                                  \
+                    if (col < WS) {                                                                 \
+                        float v = sx[i * NJ + j];                                                   \
+                        v = v > 0.f ? v : v * in_slope;                                             \
+                        sb[(wid + 4 * i) * WS + col] = st_ok[j] ? v : 0.f;                          \
+                    }                                                                               \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+        float4* swp = reinterpret_cast<float4*>(sb + G::X_FLOATS);                                  \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                            \
+            const int e = tid + 256 * i;                                                            \
+            if (e < G::W4) swp[e] = make_float4(sw[4 * i], sw[4 * i + 1], sw[4 * i + 2], sw[4 * i + 3]); \
+        }                                                                                           \
+    }
 
-    // ---- A operand (weights): straight from L2 into registers, one channel pair ahead.
-    float a_cur[K][MT], a_nxt[K][MT];
-    const int n_pairs = p.Cin / 2;
-    auto load_a = [&](float (&a)[K][MT], int pair) {
-        pair = min(pair, n_pairs - 1);
-        const float* __restrict__ wrow = wp + (int64_t)(2 * pair + kk) * K * p.CoutP + co_w0 + l31;
-#pragma unroll
-        for (int t = 0; t < K; ++t)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[t][i] = wrow[t * p.CoutP + i * 32];
-    };
-
-    stage_load(0);
-    load_a(a_cur, 0);
-    stage_write(0);
+    // One barrier per chunk:
+    // [issue loads of chunk c+1] -> [MFMAs of chunk c from LDS] -> [write chunk c+1 to LDS] -> barrier
+    // Waves whose whole time range lies past n_out still run the MFMAs (results discarded):
+    // keeping the MFMA block unconditional lets the accumulators live in AGPRs across chunks.
+    TTS_STAGE_LOAD(0)
+    TTS_STAGE_WRITE(0)
     __syncthreads();
-
     for (int c = 0; c < n_chunks; ++c) {
-        if (c + 1 < n_chunks) stage_load(c + 1);
-        if (wave_active) {
-            const float* sbuf = smem + (c & 1) * (KC * WS) + kk * WS + soff;
+        const bool more = c + 1 < n_chunks;
+        if (more) TTS_STAGE_LOAD(c + 1)
+        {
+            const float* sx_ = smem + (c & 1) * G::BUF_FLOATS + kk * WS + soff;
+            const float* sw_ = smem + (c & 1) * G::BUF_FLOATS + G::X_FLOATS + kk * K * CO_BLK + wm * MT * 32 + l31;
+            // software-pipelined operand fetch: the LDS reads of step s+1 are issued before the
+            // MFMAs of step s (register ping-pong), so the ~100-cycle LDS latency hides under
+            // the 4 x 64-cycle MFMAs instead of stalling every quad.
+            constexpr int NSTEP = (KC / 2) * K;
+            float a[2][MT], bq[2][NTL];
 #pragma unroll
-            for (int pr = 0; pr < KC / 2; ++pr) {
-                load_a(a_nxt, c * (KC / 2) + pr + 1);
-                const float* srow = sbuf + (2 * pr) * WS;
+            for (int i = 0; i < MT; ++i) a[0][i] = sw_[i * 32];
 #pragma unroll
-                for (int tap = 0; tap < K; ++tap) {
-                    float bq[NTL];
+            for (int j = 0; j < NTL; ++j) bq[0][j] = sx_[j * 32];
 #pragma unroll
-                    for (int j = 0; j < NTL; ++j) bq[j] = srow[tap * dil + j * 32];
+            for (int st = 0; st < NSTEP; ++st) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < NSTEP) {
+                    const int pr = (st + 1) / K, tap = (st + 1) % K;
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i) a[nxt][i] = sw_[((2 * pr) * K + tap) * CO_BLK + i * 32];
 #pragma unroll
-                        for (int j = 0; j < NTL; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[tap][i], bq[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NTL; ++j) bq[nxt][j] = sx_[(2 * pr) * WS + tap * dil + j * 32];
                 }
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
-                for (int t = 0; t < K; ++t)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) a_cur[t][i] = a_nxt[t][i];
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bq[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (c + 1 < n_chunks) stage_write((c + 1) & 1);
+        if (more) TTS_STAGE_WRITE((c + 1) & 1)
         __syncthreads();
     }
+#undef TTS_STAGE_LOAD
+#undef TTS_STAGE_WRITE
 
     // epilogue: bias, residual, activation, accumulate modes
     if (!wave_active) return;
+    const int co_w0 = co_blk0 + wm * MT * 32;
     float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
     const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs + phase : nullptr;
 #pragma unroll
@@ -189,7 +217,15 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
 template <int K, int MT, int NTL, int WM, int WN>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
-    const size_t lds = (size_t)2 * KC * Geo<K, NT_BLK>::WS * sizeof(float);
+    using G = Geo<K, NT_BLK, CO_BLK>;
+    TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
+    const size_t lds = (size_t)2 * G::BUF_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_f32<K, MT, NTL, WM, WN>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
     hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN>), grid, dim3(256), lds, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
@@ -212,7 +248,6 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
 }
 
 int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
-    TTS_REQUIRE(p.Cin % KC == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, KC);
     TTS_REQUIRE(p.CoutP % 32 == 0 && p.CoutP >= p.Cout, "conv: bad CoutP=%d", p.CoutP);
     TTS_REQUIRE(p.n_phase >= 1 && p.batch >= 1, "conv: bad n_phase/batch");
     TTS_REQUIRE(p.dil >= -DMAX && p.dil <= DMAX && p.dil != 0, "conv: dilation %d outside [-%d,%d]", p.dil, DMAX, DMAX);
