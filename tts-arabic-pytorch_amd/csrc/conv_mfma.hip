@@ -25,7 +25,7 @@ constexpr int DMAX = 5;  // largest |dilation| the LDS row is sized for
 
 // Input channels staged per LDS chunk: KC*K ~ 48 (ci,tap) rows so that every chunk carries
 // the same ~6k cycles of MFMA work per wave between two barriers.
-template <int K> struct ChunkOf { static constexpr int KC = K >= 11 ? 4 : (K >= 7 ? 8 : 16); };
+template <int K> struct ChunkOf { static constexpr int KC = K >= 7 ? 4 : (K >= 3 ? 8 : 16); };
 
 template <int K, int NT_BLK, int CO_BLK>
 struct Geo {
@@ -42,7 +42,7 @@ struct Geo {
 };
 
 template <int K, int MT, int NTL, int WM, int WN>
-__global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
+__global__ __launch_bounds__(256, 3) void conv1d_mfma_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_BLK = WM * MT * 32;
     constexpr int NT_BLK = WN * NTL * 32;
@@ -186,29 +186,47 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32(const ConvParams p) {
 #undef TTS_STAGE_LOAD
 #undef TTS_STAGE_WRITE
 
-    // epilogue: bias, residual, activation, accumulate modes
+    // epilogue: bias, residual, activation, accumulate modes.  Per 32x32 tile all loads
+    // (bias, residual, previous y) are issued first and only then consumed, so a tile costs
+    // one memory round trip instead of sixteen.
     if (!wave_active) return;
     const int co_w0 = co_blk0 + wm * MT * 32;
     float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
     const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs + phase : nullptr;
+    const float* __restrict__ bias = p.bias;
+    const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
+    const int y_cs = p.y_cs, y_ts = p.y_ts, r_cs = p.r_cs;
+    const float div = p.div;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             const int q = q0 + qw0 + j * 32 + l31;
-            if (q >= n_out) continue;
+            const bool q_ok = q < n_out;
+            const int qc = q_ok ? q : 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (co >= p.Cout) continue;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[co];
-                const int64_t yo = (int64_t)co * p.y_cs + (int64_t)q * p.y_ts;
-                if (rb) v += rb[(int64_t)co * p.r_cs + (int64_t)q * p.y_ts];
-                if (p.relu_out) v = fmaxf(v, 0.f);
-                if (p.mode == 1) v = yb[yo] + v;
-                else if (p.mode == 2) v = (yb[yo] + v) / p.div;
-                yb[yo] = v;
+            for (int h = 0; h < 2; ++h) {
+                float bv[8], rv[8], pv[8];
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = h * 8 + r8;
+                    const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    const int coc = min(co, Cout - 1);
+                    bv[r8] = bias ? bias[coc] : 0.f;
+                    rv[r8] = rb ? rb[(int64_t)coc * r_cs + (int64_t)qc * y_ts] : 0.f;
+                    pv[r8] = mode != 0 ? yb[(int64_t)coc * y_cs + (int64_t)qc * y_ts] : 0.f;
+                }
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = h * 8 + r8;
+                    const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    float v = acc[i][j][r] + bv[r8];
+                    v += rv[r8];
+                    if (relu_out) v = fmaxf(v, 0.f);
+                    if (mode == 1) v = pv[r8] + v;
+                    else if (mode == 2) v = (pv[r8] + v) / div;
+                    if (q_ok && co < Cout) yb[(int64_t)co * y_cs + (int64_t)q * y_ts] = v;
+                }
             }
         }
     }
