@@ -130,6 +130,23 @@ int32_t ttsamd_fastpitch_decode(void* handle, float* x, const int64_t* dec_lens,
                                 int32_t t_max, float* mel, void* workspace,
                                 int64_t workspace_bytes, void* stream);
 
+/* ---- HiFi-GAN bias denoiser: replaces vocoder.hifigan.denoiser.Denoiser
+ *      (vocoder/hifigan/denoiser.py:32-64 __init__, :66-72 forward).  STFT/ISTFT with
+ *      n_fft = win = 1024, hop 256, periodic hann, center/reflect, onesided, unnormalised. --- */
+int32_t ttsamd_denoiser_create(void** handle);
+int32_t ttsamd_denoiser_destroy(void* handle);
+int64_t ttsamd_denoiser_workspace_bytes(int32_t batch, int32_t n_max);
+/* bias_spec[513] = |STFT(audio)|[:, frame 0]; audio [n] is the vocoder output for a zero mel
+ * (denoiser.py:50-64); n_dev = device int64 holding n. */
+int32_t ttsamd_denoiser_bias_spec(void* handle, const float* audio, const int64_t* n_dev, int32_t n,
+                                  float* bias_spec, void* workspace, int64_t workspace_bytes,
+                                  void* stream);
+/* In place: wave[b][0 : 256*(nsamples[b]/256)] <- ISTFT(max(|X|-strength*bias,0) * e^{i arg X}).
+ * wave [B][wave_stride], nsamples int64 [B] (device), every nsamples[b] > 512. */
+int32_t ttsamd_denoise(void* handle, float* wave, int64_t wave_stride, const int64_t* nsamples,
+                       int32_t batch, int32_t n_max, const float* bias_spec, float strength,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- kernel-level entry used by the parity tests and the roofline bench ------------- */
 
 /* One Conv1d through the implicit-GEMM MFMA kernel: y = conv1d(lrelu_slope(x), w) + b.

@@ -165,3 +165,93 @@ def test_end_to_end_golden(dev, golden, fastpitch_engine, hifigan_engine):
         ref = e[f'wave{i}']
         assert 256 * dl[r] == ref.shape[0]
         assert maxabs(wave[r, :ref.shape[0]], ref) < WAVE_TOL
+
+
+# ---------------------------------------------------------------------------------------
+# The drop-in boundary: models.fastpitch.FastPitch2Wave / FastPitch, vocoder.load_hifigan,
+# vocoder.hifigan.denoiser.Denoiser driven exactly as inference.py / test.py / app_utils.py do
+# ---------------------------------------------------------------------------------------
+
+@pytest.fixture(scope='module')
+def checkpoints(tmp_path_factory, synth_weights):
+    import json
+    import text
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    d = tmp_path_factory.mktemp('ckpt')
+    fp = {k: torch.from_numpy(v.copy()) for k, v in synth_weights['fastpitch'].items()}
+    torch.save({'model': fp, 'config': dict(NET_CONFIG), 'symbols': list(text.symbols)}, d / 'fp.pth')
+    torch.save({'generator': {k: torch.from_numpy(v.copy()) for k, v in synth_weights['hifigan'].items()}}, d / 'hg.pth')
+    with open(d / 'config.json', 'w') as f:
+        json.dump(HIFIGAN_CONFIG, f)
+    return str(d / 'fp.pth'), str(d / 'hg.pth'), str(d / 'config.json')
+
+
+def _lines(golden, idx):
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, 'infer_text_lines.json'), encoding='utf-8') as f:
+        lines = json.load(f)
+    return [lines[i] for i in idx]
+
+
+def test_dropin_tts_matches_reference(dev, golden, checkpoints):
+    from models.fastpitch import FastPitch2Wave
+    e = golden('e2e_tts')
+    texts = _lines(golden, e['line_idx'])
+    model = FastPitch2Wave(checkpoints[0], vocoder_sd=checkpoints[1], vocoder_config=checkpoints[2])
+    model = model.to(dev)
+    model.eval()
+    assert model.device.type == 'cuda'
+    waves = model.tts(texts, batch_size=3, denoise=0.0)
+    assert isinstance(waves, list) and all(w.device.type == 'cpu' and w.dim() == 1 for w in waves)
+    for i, w in enumerate(waves):
+        assert maxabs(w, e[f'wave{i}']) < WAVE_TOL
+    # chunked path (batch_size < len) must equal the reference run on the same sub-batches: the
+    # first chunk of 2 is what produced wave_dn* (denoise 0.005, tts default)
+    wd = model.tts(texts[:2], batch_size=2)                      # default denoise=0.005
+    for i, w in enumerate(wd):
+        assert w.shape == e[f'wave_dn{i}'].shape
+        assert maxabs(w, e[f'wave_dn{i}']) < WAVE_TOL
+    # str input -> tts_single, return_mel
+    w1, mel1 = model.tts(texts[0], denoise=0.0, return_mel=True)
+    assert maxabs(w1, e['single_wave']) < WAVE_TOL
+    assert maxabs(mel1, e['single_mel']) < MEL_TOL
+    # batch_size == 1 loops tts_single
+    w_list = model.tts(texts[:2], batch_size=1, denoise=0.0)
+    assert maxabs(w_list[0], e['single_wave']) < WAVE_TOL
+    # denoiser bias spectrum (torch.stft-based golden)
+    assert maxabs(model.denoiser.bias_spec, e['bias_spec']) < 1e-4
+
+
+def test_dropin_test_py_flow(dev, golden, checkpoints):
+    """test.py:36-67: FastPitch(ckpt).ttmel(text) -> vocoder(mel[None]) -> denoiser(wave, s)."""
+    import tts_oracle as O
+    from models.fastpitch import FastPitch
+    from vocoder import load_hifigan
+    from vocoder.hifigan.denoiser import Denoiser
+    e = golden('e2e_tts')
+    texts = _lines(golden, e['line_idx'])
+    model = FastPitch(checkpoints[0])
+    vocoder = load_hifigan(state_dict_path=checkpoints[1], config_file=checkpoints[2])
+    model, vocoder = model.to(dev), vocoder.to(dev)
+    denoiser = Denoiser(vocoder)
+    mel = model.ttmel(texts[0])
+    assert maxabs(mel, e['single_mel']) < MEL_TOL
+    wave = vocoder(mel[None])
+    assert wave.shape == (1, 1, 256 * mel.shape[1])
+    assert maxabs(wave[0, 0], e['single_wave']) < WAVE_TOL
+    den = denoiser(wave, 0.01)
+    ref = O.denoise(torch.from_numpy(e['single_wave'])[None], torch.from_numpy(e['bias_spec']), 0.01)
+    assert maxabs(den[0], ref) < WAVE_TOL
+    # ttmel(list, batch_size=2) returns mels in the original order
+    mels = model.ttmel(texts, batch_size=3)
+    assert [m.shape[1] * 256 for m in mels] == [e[f'wave{i}'].shape[0] for i in range(3)]
+
+
+def test_dropin_cpu_device_raises(checkpoints):
+    from models.fastpitch import FastPitch
+    from ttsamd.lib import TtsAmdError
+    model = FastPitch(checkpoints[0])           # stays on the CPU
+    with pytest.raises(TtsAmdError):
+        model.ttmel('marHabAF')

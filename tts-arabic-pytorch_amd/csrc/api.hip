@@ -51,6 +51,13 @@ void prof_end(hipStream_t s) {
 
 struct HifiGan;
 struct FastPitch;
+struct Denoiser;
+int32_t denoiser_create(Denoiser**);
+void denoiser_destroy(Denoiser*);
+int64_t denoiser_workspace_bytes(int32_t, int32_t);
+int32_t denoiser_bias_spec(const Denoiser*, const float*, const int64_t*, int32_t, float*, void*, int64_t, hipStream_t);
+int32_t denoise(const Denoiser*, float*, int64_t, const int64_t*, int32_t, int32_t, const float*, float, void*, int64_t,
+                hipStream_t);
 int32_t hifigan_create(const ttsamd_tensor*, int32_t, const ttsamd_hifigan_cfg*, HifiGan**);
 void hifigan_destroy(HifiGan*);
 int64_t hifigan_workspace_bytes(const HifiGan*, int32_t, int32_t);
@@ -153,6 +160,32 @@ int32_t ttsamd_fastpitch_decode(void* handle, float* x, const int64_t* dec_lens,
                                 float* mel, void* workspace, int64_t workspace_bytes, void* stream) {
     return fastpitch_decode((FastPitch*)handle, x, dec_lens, batch, t_max, mel, workspace, workspace_bytes,
                             (hipStream_t)stream);
+}
+
+int32_t ttsamd_denoiser_create(void** handle) {
+    Denoiser* h = nullptr;
+    const int32_t rc = denoiser_create(&h);
+    if (rc == 0) *handle = h;
+    return rc;
+}
+int32_t ttsamd_denoiser_destroy(void* handle) {
+    denoiser_destroy((Denoiser*)handle);
+    return 0;
+}
+int64_t ttsamd_denoiser_workspace_bytes(int32_t batch, int32_t n_max) {
+    if (batch < 1 || n_max < 1) return 0;
+    return denoiser_workspace_bytes(batch, n_max);
+}
+int32_t ttsamd_denoiser_bias_spec(void* handle, const float* audio, const int64_t* n_dev, int32_t n,
+                                  float* bias_spec, void* workspace, int64_t workspace_bytes, void* stream) {
+    return denoiser_bias_spec((Denoiser*)handle, audio, n_dev, n, bias_spec, workspace, workspace_bytes,
+                              (hipStream_t)stream);
+}
+int32_t ttsamd_denoise(void* handle, float* wave, int64_t wave_stride, const int64_t* nsamples, int32_t batch,
+                       int32_t n_max, const float* bias_spec, float strength, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+    return denoise((Denoiser*)handle, wave, wave_stride, nsamples, batch, n_max, bias_spec, strength, workspace,
+                   workspace_bytes, (hipStream_t)stream);
 }
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {

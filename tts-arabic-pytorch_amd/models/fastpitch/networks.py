@@ -1,0 +1,225 @@
+"""Drop-in for the reference's models/fastpitch/networks.py: same classes, signatures,
+defaults and return conventions, with the arithmetic routed to the HIP engines.
+
+  FastPitch       (reference :45-253)  checkpoint -> .infer/.ttmel/.ttmel_single/.ttmel_batch
+  FastPitch2Wave  (reference :256-435) + vocoder + denoiser -> .tts/.tts_single/.tts_batch
+  text_collate_fn (:16-35), pitch_trf (:38-42)
+
+Differences, all host-side: the vocoder runs ONCE on the ragged batch instead of in a
+per-utterance loop (:340-345) — results are identical because every layer pads at the true
+utterance edge — and `vowelizer=` raises (diacritizers are outside the hot path).
+"""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import text
+from ttsamd.engine import FastPitchEngine
+from ttsamd.lib import TtsAmdError
+from utils import get_basic_config
+from vocoder import load_hifigan
+from vocoder.hifigan.denoiser import Denoiser
+from vocoder.hifigan.models import _HipModule
+
+
+def text_collate_fn(batch: List[torch.Tensor]):
+    """Sort by length (descending), zero-pad; returns (ids_pad, lens_sorted, reverse_ids)."""
+    lens_sorted, sort_ids = torch.sort(torch.LongTensor([len(x) for x in batch]), descending=True)
+    ids_pad = torch.zeros(len(batch), int(lens_sorted[0]), dtype=torch.long)
+    for i, j in enumerate(sort_ids):
+        ids_pad[i, :batch[j].size(0)] = batch[j]
+    return ids_pad, lens_sorted, sort_ids.argsort()
+
+
+def pitch_trf(mul: float = 1, add: float = 0):
+    """Affine transform of the *normalised* pitch prediction; mean/std are ignored, as in the
+    reference (:38-42).  Tagged so `infer` can run it inside the HIP predictor head."""
+    def _pitch_trf(pitch_pred, enc_mask_sum, mean, std):
+        return mul * pitch_pred + add
+    _pitch_trf.affine = (float(mul), float(add))
+    return _pitch_trf
+
+
+class FastPitch(_HipModule):
+    def __init__(self, checkpoint: str, arabic_in: bool = True, vowelizer: Optional[str] = None, **kwargs):
+        super().__init__()
+        from models.fastpitch import net_config
+        state_dicts = torch.load(checkpoint, map_location='cpu')
+        self.net_config = dict(state_dicts['config']) if 'config' in state_dicts else dict(net_config)
+        self.arabic_in = arabic_in
+        self._sd = {k: v.detach().cpu().float().numpy() for k, v in state_dicts['model'].items()
+                    if torch.is_tensor(v) and v.is_floating_point() and not k.startswith('attention.')}
+        self.config = get_basic_config()
+        if vowelizer is not None:
+            raise NotImplementedError('vowelizer= (Shakkala/Shakkelha diacritizers) is not part of the MI355X hot path')
+        self.default_vowelizer = None
+        self.phon_to_id = None
+        if 'symbols' in state_dicts:
+            self.phon_to_id = {phon: i for i, phon in enumerate(state_dicts['symbols'])}
+        self.pitch_mean = float(self._sd.get('pitch_mean', np.zeros(1))[0])
+        self.pitch_std = float(self._sd.get('pitch_std', np.zeros(1))[0])
+        self.eval()
+
+    def engine(self):
+        return self._engine(lambda dev: FastPitchEngine(self._sd, self.net_config, device=dev))
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._sd = {k: v.detach().cpu().float().numpy() for k, v in state_dict.items()
+                    if torch.is_tensor(v) and v.is_floating_point() and not k.startswith('attention.')}
+        self._engines.clear()
+
+    def state_dict(self, *a, **k):
+        return {k_: torch.from_numpy(v) for k_, v in self._sd.items()}
+
+    # ---- FastPitch.infer (models/fastpitch/fastpitch/model.py:351-353) -------------------
+    @torch.inference_mode()
+    def infer(self, inputs, pace=1.0, dur_tgt=None, pitch_tgt=None, energy_tgt=None, pitch_transform=None,
+              max_duration=75, speaker=0):
+        ids = torch.as_tensor(inputs).long()
+        nz = (ids != self.net_config['padding_idx'])
+        lens = nz.sum(1)
+        if not bool((nz == (torch.arange(ids.shape[1], device=ids.device)[None] < lens[:, None])).all()):
+            raise ValueError('ids must be zero-padded at the end of each row (text_collate_fn layout)')
+        eng = self.engine()
+        mul, add = 1.0, 0.0
+        if pitch_transform is not None:
+            if hasattr(pitch_transform, 'affine'):
+                mul, add = pitch_transform.affine
+            else:
+                # arbitrary callable: run the predictor, transform on the host side, feed back
+                _, _, _, pp, _ = eng.infer(ids, pace=pace, dur_tgt=dur_tgt, max_duration=max_duration, speaker=speaker)
+                mean, std = (218.14, 67.24) if self.pitch_std == 0.0 else (self.pitch_mean, self.pitch_std)
+                pp = pitch_transform(pp, lens.to(pp.device), mean, std)
+                out = eng.infer(ids, pace=pace, dur_tgt=dur_tgt, pitch_tgt=pp if pitch_tgt is None else pitch_tgt,
+                                energy_tgt=energy_tgt, max_duration=max_duration, speaker=speaker)
+                return out[0], out[1], out[2], pp, out[4]
+        return eng.infer(ids, pace=pace, dur_tgt=dur_tgt, pitch_tgt=pitch_tgt, energy_tgt=energy_tgt,
+                         pitch_mul=mul, pitch_add=add, max_duration=max_duration, speaker=speaker)
+
+    # ---- text -> mel (reference :77-253) -----------------------------------------------
+    def _vowelize(self, utterance: str, vowelizer=None):
+        if vowelizer is not None:
+            raise NotImplementedError('vowelizer= is not part of the MI355X hot path')
+        return utterance
+
+    def _tokenize(self, utterance: str, vowelizer=None):
+        utterance = self._vowelize(utterance, vowelizer)
+        if self.arabic_in:
+            return text.arabic_to_tokens(utterance, append_space=False)
+        return text.buckwalter_to_tokens(utterance, append_space=False)
+
+    @staticmethod
+    def _ptrf(pitch_mul, pitch_add, pitch_transform):
+        if (pitch_mul != 1. or pitch_add != 0.) and pitch_transform is None:
+            return pitch_trf(pitch_mul, pitch_add)
+        return pitch_transform
+
+    @torch.inference_mode()
+    def ttmel_single(self, utterance: str, speed: float = 1, speaker_id: int = 0, vowelizer=None,
+                     pitch_mul: float = 1., pitch_add: float = 0., dur_tgt=None, pitch_tgt=None,
+                     energy_tgt=None, pitch_transform=None, max_duration=75):
+        tokens = self._tokenize(utterance, vowelizer=vowelizer)
+        ids = torch.LongTensor(text.tokens_to_ids(tokens, self.phon_to_id)).unsqueeze(0)
+        mel, *_ = self.infer(ids, pace=speed, speaker=speaker_id, dur_tgt=dur_tgt, pitch_tgt=pitch_tgt,
+                             energy_tgt=energy_tgt, pitch_transform=self._ptrf(pitch_mul, pitch_add, pitch_transform),
+                             max_duration=max_duration)
+        return mel[0]                                                   # [80, T]
+
+    @torch.inference_mode()
+    def _ttmel_batch_padded(self, batch, speed, speaker_id, vowelizer, pitch_mul, pitch_add, dur_tgt=None,
+                            pitch_tgt=None, energy_tgt=None, pitch_transform=None, max_duration=75):
+        batch_ids = [torch.LongTensor(text.tokens_to_ids(self._tokenize(line, vowelizer), self.phon_to_id))
+                     for line in batch]
+        ids_pad, lens_sorted, reverse_ids = text_collate_fn(batch_ids)
+        mel, dec_lens, *_ = self.infer(ids_pad, pace=speed, speaker=speaker_id, dur_tgt=dur_tgt, pitch_tgt=pitch_tgt,
+                                       energy_tgt=energy_tgt,
+                                       pitch_transform=self._ptrf(pitch_mul, pitch_add, pitch_transform),
+                                       max_duration=max_duration)
+        return mel, dec_lens, reverse_ids
+
+    @torch.inference_mode()
+    def ttmel_batch(self, batch: List[str], speed: float = 1, speaker_id: int = 0, vowelizer=None,
+                    pitch_mul: float = 1., pitch_add: float = 0., dur_tgt=None, pitch_tgt=None, energy_tgt=None,
+                    pitch_transform=None, max_duration=75):
+        mel, dec_lens, reverse_ids = self._ttmel_batch_padded(batch, speed, speaker_id, vowelizer, pitch_mul,
+                                                              pitch_add, dur_tgt, pitch_tgt, energy_tgt,
+                                                              pitch_transform, max_duration)
+        lens = dec_lens.tolist()
+        return [mel[j, :, :lens[j]] for j in reverse_ids.tolist()]      # original order
+
+    def ttmel(self, text_input: Union[str, List[str]], speed: float = 1, speaker_id: int = 0, batch_size: int = 1,
+              vowelizer=None, pitch_mul: float = 1., pitch_add: float = 0.):
+        kw = dict(speed=speed, speaker_id=speaker_id, vowelizer=vowelizer, pitch_mul=pitch_mul, pitch_add=pitch_add)
+        if isinstance(text_input, str):
+            return self.ttmel_single(text_input, **kw)
+        assert isinstance(text_input, list)
+        if batch_size == 1:
+            return [self.ttmel_single(sample, **kw) for sample in text_input]
+        mel_list = []
+        for k in range(0, len(text_input), batch_size):
+            mel_list += self.ttmel_batch(text_input[k:k + batch_size], **kw)
+        return mel_list
+
+
+class FastPitch2Wave(nn.Module):
+    def __init__(self, model_sd_path: str, vocoder_sd: Optional[str] = None, vocoder_config: Optional[str] = None,
+                 vowelizer: Optional[str] = None, arabic_in: bool = True):
+        super().__init__()
+        self.model = FastPitch(model_sd_path, arabic_in=arabic_in, vowelizer=vowelizer)
+        if vocoder_sd is None or vocoder_config is None:
+            config = get_basic_config()
+            vocoder_sd, vocoder_config = config.vocoder_state_path, config.vocoder_config_path
+        self.vocoder = load_hifigan(vocoder_sd, vocoder_config)
+        self.denoiser = Denoiser(self.vocoder)
+        self.eval()
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, x):
+        return x
+
+    @torch.inference_mode()
+    def tts_single(self, text_buckw: str, speed: float = 1, speaker_id: int = 0, denoise: float = 0,
+                   vowelizer=None, pitch_mul: float = 1., pitch_add: float = 0., return_mel: bool = False):
+        mel_spec = self.model.ttmel_single(text_buckw, speed, speaker_id, vowelizer, pitch_mul=pitch_mul,
+                                           pitch_add=pitch_add)
+        wave = self.vocoder(mel_spec)
+        if denoise > 0:
+            wave = self.denoiser(wave, denoise)
+        if return_mel:
+            return wave[0].cpu(), mel_spec
+        return wave[0].cpu()
+
+    @torch.inference_mode()
+    def tts_batch(self, batch: List[str], speed: float = 1, speaker_id: int = 0, denoise: float = 0, vowelizer=None,
+                  pitch_mul: float = 1., pitch_add: float = 0., return_mel: bool = False):
+        mel, dec_lens, reverse_ids = self.model._ttmel_batch_padded(batch, speed, speaker_id, vowelizer, pitch_mul,
+                                                                    pitch_add)
+        wave = self.vocoder.engine().forward(mel, dec_lens)             # one ragged batched launch sequence
+        n = (dec_lens * self.vocoder.engine().hop)
+        if denoise > 0:
+            wave = self.denoiser.forward_batch(wave, n, denoise)
+        wave, n = wave.cpu(), n.tolist()                                 # one D2H for the whole batch
+        # NB the reference silently ignores return_mel here (:347-350); so do we
+        return [wave[j, :n[j]].clone() for j in reverse_ids.tolist()]
+
+    def tts(self, text_input: Union[str, List[str]], speed: float = 1., denoise: float = 0.005, speaker_id: int = 0,
+            batch_size: int = 2, vowelizer=None, pitch_mul: float = 1., pitch_add: float = 0.,
+            return_mel: bool = False) -> Union[torch.Tensor, List[torch.Tensor]]:
+        """Same contract as the reference (:352-435): str -> Tensor[n_samples] (CPU);
+        list -> list of tensors, chunked by `batch_size`."""
+        kw = dict(speaker_id=speaker_id, speed=speed, denoise=denoise, vowelizer=vowelizer, pitch_mul=pitch_mul,
+                  pitch_add=pitch_add, return_mel=return_mel)
+        if isinstance(text_input, str):
+            return self.tts_single(text_input, **kw)
+        assert isinstance(text_input, list)
+        if batch_size == 1:
+            return [self.tts_single(sample, **kw) for sample in text_input]
+        wav_list = []
+        for k in range(0, len(text_input), batch_size):
+            wav_list += self.tts_batch(text_input[k:k + batch_size], **kw)
+        return wav_list

@@ -176,6 +176,50 @@ class FastPitchEngine:
         return out + (idx,) if return_idx else out
 
 
+class DenoiserEngine:
+    """Handle over ttsamd_denoiser_* (replaces vocoder.hifigan.denoiser.Denoiser)."""
+
+    def __init__(self, device='cuda'):
+        self.lib = _require_gpu()
+        self.device = torch.device(device if device != 'cuda' else 'cuda:0')
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ttsamd_denoiser_create(C.byref(handle)), 'denoiser_create')
+        self.handle = handle
+        self.ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, 'handle', None):
+            self.lib.ttsamd_denoiser_destroy(self.handle)
+            self.handle = None
+
+    def bias_spec(self, audio):
+        """audio [n] (vocoder output for a zero mel) -> |STFT| of frame 0, shape [1, 513, 1]."""
+        audio = _f32(audio, self.device).reshape(-1)
+        n = audio.numel()
+        out = torch.empty(513, dtype=torch.float32, device=self.device)
+        n_dev = torch.tensor([n], dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            nb = self.lib.ttsamd_denoiser_workspace_bytes(1, n)
+            ws = self.ws.get(nb, self.device)
+            L.check(self.lib.ttsamd_denoiser_bias_spec(self.handle, _ptr(audio), _ptr(n_dev), n, _ptr(out), _ptr(ws), nb,
+                                                       _stream()), 'denoiser_bias_spec')
+        return out.reshape(1, 513, 1)
+
+    def denoise(self, wave, nsamples, bias_spec, strength):
+        """wave [B, n_max] (modified in place and returned), nsamples int64 [B] on the device."""
+        assert wave.is_contiguous() and wave.dtype == torch.float32
+        B, n_max = wave.shape
+        nsamples = nsamples.to(device=self.device, dtype=torch.int64).contiguous()
+        bias = _f32(bias_spec, self.device).reshape(-1)
+        with torch.cuda.device(self.device):
+            nb = self.lib.ttsamd_denoiser_workspace_bytes(B, n_max)
+            ws = self.ws.get(nb, self.device)
+            L.check(self.lib.ttsamd_denoise(self.handle, _ptr(wave), n_max, _ptr(nsamples), B, n_max, _ptr(bias),
+                                            float(strength), _ptr(ws), nb, _stream()), 'denoise')
+        return wave
+
+
 def conv1d(x, w, bias=None, lens=None, dilation=1, in_slope=1.0, relu_out=False):
     """Kernel-level entry (parity tests / roofline bench): y = conv1d(lrelu(x), w) + b, 'same' padding."""
     lib = _require_gpu()
