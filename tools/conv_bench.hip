@@ -1,0 +1,45 @@
+// Standalone micro-benchmark of the MFMA conv engine (kernel experiments; not part of the product).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DTTS_...] tools/conv_bench.hip -o /tmp/conv_bench
+#include "../tts-arabic-pytorch_amd/csrc/conv_mfma.hip"
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+namespace ttsamd {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) { char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); g_err = buf; fprintf(stderr, "ERR %s\n", buf); }
+}
+using namespace ttsamd;
+int main(int argc, char** argv) {
+    struct Shape { int B, cin, cout, k, dil, L; };
+    std::vector<Shape> shapes = {{8, 1024, 128, 3, 1, 28672}, {8, 1024, 128, 11, 5, 28672}, {32, 128, 128, 3, 1, 28672},
+                                 {32, 128, 128, 7, 3, 28672}, {32, 64, 64, 3, 1, 57344}, {32, 32, 32, 3, 1, 114688}, {32, 32, 32, 11, 5, 114688}};
+    for (auto s : shapes) {
+        const int cp = cout_padded(s.cout);
+        float *x, *w, *y, *b;
+        size_t nx = (size_t)s.B * s.cin * s.L, ny = (size_t)s.B * s.cout * s.L, nw = (size_t)s.cin * s.k * cp;
+        hipMalloc(&x, nx * 4); hipMalloc(&y, ny * 4); hipMalloc(&w, nw * 4); hipMalloc(&b, cp * 4);
+        std::vector<float> hx(1 << 20), hw(nw);
+        for (auto& v : hx) v = (float)rand() / RAND_MAX - 0.5f;
+        for (auto& v : hw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.05f;
+        for (size_t o = 0; o < nx; o += hx.size()) hipMemcpy(x + o, hx.data(), std::min(hx.size(), nx - o) * 4, hipMemcpyHostToDevice);
+        hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice); hipMemset(b, 0, cp * 4);
+        ConvParams p; std::memset(&p, 0, sizeof p);
+        p.x = x; p.x_bs = (int64_t)s.cin * s.L; p.x_cs = s.L; p.w = w; p.bias = b;
+        p.y = y; p.y_bs = (int64_t)s.cout * s.L; p.y_cs = s.L; p.y_ts = 1;
+        p.res = x; p.r_bs = p.x_bs; p.r_cs = s.L;      // residual read like c2 (cin>=cout here)
+        p.len_in_mul = p.len_out_mul = 1; p.Lin = p.Nout = s.L; p.Cin = s.cin; p.Cout = s.cout; p.CoutP = cp; p.K = s.k;
+        p.dil = s.dil; p.pad = (s.k * s.dil - s.dil) / 2; p.n_phase = 1; p.in_slope = 0.1f; p.div = 1.f; p.batch = s.B;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int i = 0; i < 2; ++i) launch_conv(p, 0);
+        hipEventRecord(e0, 0);
+        const int n = 5;
+        for (int i = 0; i < n; ++i) launch_conv(p, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= n;
+        double fl = 2.0 * s.cout * s.cin * s.k * (double)s.B * s.L;
+        printf("B%d cin%d cout%d k%d d%d L%d: %.3f ms %.1f TF\n", s.B, s.cin, s.cout, s.k, s.dil, s.L, ms, fl / ms / 1e9);
+        hipFree(x); hipFree(y); hipFree(w); hipFree(b);
+    }
+    return 0;
+}

@@ -25,7 +25,19 @@ constexpr int DMAX = 5;  // largest |dilation| the LDS row is sized for
 
 // Input channels staged per LDS chunk: KC*K ~ 48 (ci,tap) rows so that every chunk carries
 // the same ~6k cycles of MFMA work per wave between two barriers.
-template <int K> struct ChunkOf { static constexpr int KC = K >= 7 ? 4 : (K >= 3 ? 8 : 16); };
+#ifndef TTS_KC3
+#define TTS_KC3 8
+#endif
+#ifndef TTS_KC7
+#define TTS_KC7 4
+#endif
+#ifndef TTS_KC11
+#define TTS_KC11 4
+#endif
+#ifndef TTS_MINWAVES
+#define TTS_MINWAVES 3
+#endif
+template <int K> struct ChunkOf { static constexpr int KC = K >= 11 ? TTS_KC11 : (K >= 7 ? TTS_KC7 : (K >= 3 ? TTS_KC3 : 16)); };
 
 template <int K, int NT_BLK, int CO_BLK>
 struct Geo {
@@ -42,7 +54,7 @@ struct Geo {
 };
 
 template <int K, int MT, int NTL, int WM, int WN>
-__global__ __launch_bounds__(256, 3) void conv1d_mfma_f32(const ConvParams p) {
+__global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_BLK = WM * MT * 32;
     constexpr int NT_BLK = WN * NTL * 32;
@@ -139,49 +151,96 @@ __global__ __launch_bounds__(256, 3) void conv1d_mfma_f32(const ConvParams p) {
         }                                                                                           \
     }
 
-    // One barrier per chunk:
-    // [issue loads of chunk c+1] -> [MFMAs of chunk c from LDS] -> [write chunk c+1 to LDS] -> barrier
+    // 3-stage LDS ring, one barrier per chunk, MFMA stream continuous across chunk boundaries:
+    //   top of chunk c : issue the global loads of chunk c+2 (registers)
+    //   steps 0..N-1   : MFMAs of chunk c from stage c%3; the operands of step s+1 are fetched
+    //                    from LDS before the MFMAs of step s are issued (register ping-pong);
+    //                    the LAST step fetches step 0 of chunk c+1 (stage (c+1)%3, made visible
+    //                    by the previous barrier), so no wave ever drains at a chunk boundary
+    //                    (waves of a SIMD run in lockstep: occupancy cannot hide such a bubble)
+    //   before the last step: write chunk c+2 into stage (c+2)%3 (last read in chunk c-1)
+    //   barrier        : covered by the 4 MFMAs just issued
     // Waves whose whole time range lies past n_out still run the MFMAs (results discarded):
-    // keeping the MFMA block unconditional lets the accumulators live in AGPRs across chunks.
+    // keeping the MFMA block unconditional lets the accumulators stay in registers across chunks.
+    constexpr int NSTEP = (KC / 2) * K;
+    const float* sx0 = smem + kk * WS + soff;
+    const float* sw0 = smem + G::X_FLOATS + kk * K * CO_BLK + wm * MT * 32 + l31;
+    float a[2][MT], bq[2][NTL];
+
     TTS_STAGE_LOAD(0)
     TTS_STAGE_WRITE(0)
+    if (n_chunks > 1) {
+        TTS_STAGE_LOAD(1)
+        TTS_STAGE_WRITE(1)
+    }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[0][i] = sw0[i * 32];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) bq[0][j] = sx0[j * 32];
+
+    int stage = 0;                                   // c % 3
     for (int c = 0; c < n_chunks; ++c) {
-        const bool more = c + 1 < n_chunks;
-        if (more) TTS_STAGE_LOAD(c + 1)
-        {
-            const float* sx_ = smem + (c & 1) * G::BUF_FLOATS + kk * WS + soff;
-            const float* sw_ = smem + (c & 1) * G::BUF_FLOATS + G::X_FLOATS + kk * K * CO_BLK + wm * MT * 32 + l31;
-            // software-pipelined operand fetch: the LDS reads of step s+1 are issued before the
-            // MFMAs of step s (register ping-pong), so the ~100-cycle LDS latency hides under
-            // the 4 x 64-cycle MFMAs instead of stalling every quad.
-            constexpr int NSTEP = (KC / 2) * K;
-            float a[2][MT], bq[2][NTL];
+        const bool more2 = c + 2 < n_chunks;
+#ifndef TTS_EXP_NOLOAD
+        if (more2) TTS_STAGE_LOAD(c + 2)
+#endif
+        const float* sx_ = sx0 + stage * G::BUF_FLOATS;
+        const float* sw_ = sw0 + stage * G::BUF_FLOATS;
+        const int stage1 = stage == 2 ? 0 : stage + 1;   // (c+1) % 3
+        const int stage2 = stage == 0 ? 2 : stage - 1;   // (c+2) % 3
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[0][i] = sw_[i * 32];
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) bq[0][j] = sx_[j * 32];
-#pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
-                const int cur = st & 1, nxt = cur ^ 1;
-                if (st + 1 < NSTEP) {
-                    const int pr = (st + 1) / K, tap = (st + 1) % K;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) a[nxt][i] = sw_[((2 * pr) * K + tap) * CO_BLK + i * 32];
-#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            if (st + 1 < NSTEP) {
+                const int pr = (st + 1) / K, tap = (st + 1) % K;
+#if defined(TTS_EXP_B64)   /* timing-only experiment: wrong addresses */
+                if constexpr (MT == 2 && NTL == 2) {
+                    const float2 ta = *reinterpret_cast<const float2*>(sw_ + ((2 * pr) * K + tap) * CO_BLK + l31);
+                    a[nxt][0] = ta.x; a[nxt][1] = ta.y;
+#if TTS_EXP_B64 >= 2
+                    const float2 tb = *reinterpret_cast<const float2*>(sx_ + (2 * pr) * WS + 2 * tap + l31);
+                    bq[nxt][0] = tb.x; bq[nxt][1] = tb.y;
+#else
                     for (int j = 0; j < NTL; ++j) bq[nxt][j] = sx_[(2 * pr) * WS + tap * dil + j * 32];
+#endif
+                } else
+#endif
+                {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[nxt][i] = sw_[((2 * pr) * K + tap) * CO_BLK + i * 32];
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) bq[nxt][j] = sx_[(2 * pr) * WS + tap * dil + j * 32];
                 }
-                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
+            } else {
+#ifndef TTS_EXP_NOWRITE
+                if (more2) TTS_STAGE_WRITE(stage2)
+#endif
+                // step 0 of the next chunk (clamped re-read of a valid stage on the last chunk)
+                const int sn = (c + 1 < n_chunks) ? stage1 : stage;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i) a[nxt][i] = sw0[sn * G::BUF_FLOATS + i * 32];
 #pragma unroll
-                    for (int j = 0; j < NTL; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bq[cur][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < NTL; ++j) bq[nxt][j] = sx0[sn * G::BUF_FLOATS + j * 32];
             }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bq[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) TTS_STAGE_WRITE((c + 1) & 1)
+        if (NSTEP & 1) {                               // odd step count: operands of the next chunk sit in slot 1
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[0][i] = a[1][i];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bq[0][j] = bq[1][j];
+        }
+#ifndef TTS_EXP_NOBARRIER
         __syncthreads();
+#endif
+        stage = stage1;
     }
 #undef TTS_STAGE_LOAD
 #undef TTS_STAGE_WRITE
@@ -237,7 +296,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
     using G = Geo<K, NT_BLK, CO_BLK>;
     TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
-    const size_t lds = (size_t)2 * G::BUF_FLOATS * sizeof(float);
+    const size_t lds = (size_t)3 * G::BUF_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_f32<K, MT, NTL, WM, WN>,
