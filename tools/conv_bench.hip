@@ -20,8 +20,9 @@ int main(int argc, char** argv) {
         size_t nx = (size_t)s.B * s.cin * s.L, ny = (size_t)s.B * s.cout * s.L, nw = (size_t)s.cin * s.k * cp;
         hipMalloc(&x, nx * 4); hipMalloc(&y, ny * 4); hipMalloc(&w, nw * 4); hipMalloc(&b, cp * 4);
         std::vector<float> hx(1 << 20), hw(nw);
-        for (auto& v : hx) v = (float)rand() / RAND_MAX - 0.5f;
-        for (auto& v : hw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.05f;
+        const bool zero = getenv("ZERO") != nullptr;
+        for (auto& v : hx) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f;
+        for (auto& v : hw) v = zero ? 0.f : ((float)rand() / RAND_MAX - 0.5f) * 0.05f;
         for (size_t o = 0; o < nx; o += hx.size()) hipMemcpy(x + o, hx.data(), std::min(hx.size(), nx - o) * 4, hipMemcpyHostToDevice);
         hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice); hipMemset(b, 0, cp * 4);
         ConvParams p; std::memset(&p, 0, sizeof p);

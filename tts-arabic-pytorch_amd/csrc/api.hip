@@ -75,13 +75,16 @@ int32_t fastpitch_decode(const FastPitch*, float*, const int64_t*, int32_t, int3
 
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int cout, int cin, int k, int cp,
                                         float* __restrict__ out) {
+    // same layout as pack_conv_weight (conv_mfma.hip): [cin/8][k][2][cp][4]
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n = (int64_t)cin * k * cp;
     if (i >= n) return;
-    const int co = (int)(i % cp);
-    const int t = (int)((i / cp) % k);
-    const int ci = (int)(i / ((int64_t)cp * k));
-    out[i] = co < cout ? w[((int64_t)co * cin + ci) * k + t] : 0.f;
+    const int pq = (int)(i % 4);
+    const int co = (int)((i / 4) % cp);
+    const int kk = (int)((i / (4 * (int64_t)cp)) % 2);
+    const int t = (int)((i / (8 * (int64_t)cp)) % k);
+    const int o = (int)(i / (8 * (int64_t)cp * k));
+    out[i] = co < cout ? w[((int64_t)co * cin + (8 * o + 2 * pq + kk)) * k + t] : 0.f;
 }
 
 }  // namespace ttsamd

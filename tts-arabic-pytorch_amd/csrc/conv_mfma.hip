@@ -4,17 +4,32 @@
 // Replaces every F.conv1d / F.conv_transpose1d / F.linear the reference issues on the hot
 // path: HiFi-GAN conv_pre / ups / ResBlock1 convs (vocoder/hifigan/models.py:46-53,
 // 111-127), FastPitch conv-FF, qkv/o_net/proj, predictor convs
-// (models/fastpitch/fastpitch/transformer.py:59-65,122,148; model.py:54-57,406).
+// (models/fastpitch/fastpitch/transformer.py:59-65,122,148; model.py:54-57,406) and the
+// two DFT GEMMs of the denoiser.
 //
-// GEMM view per utterance b:  Y[co][q] = sum_{ci,tap} Wp[ci][tap][co] * X[ci][q + tap*dil - pad]
-//   M = co (weights, A operand, read straight from L2 — all blocks share them),
-//   N = q  (time, B operand, staged once per 16-channel chunk in LDS with the input
-//           activation (leaky-relu) and the utterance-edge zero padding applied on load),
-//   K = (ci, tap) walked two input channels per MFMA.
-// Activations are channel-first [B][C][T] so a wave's 32 N-lanes read 32 consecutive time
-// steps (coalesced HBM, conflict-free LDS).  A block is 4 waves tiled WM x WN, each wave
-// owning MT x NTL 32x32 accumulators.  Ragged batches: positions >= lens_in[b] read as
-// zero at the INPUT of every layer, tiles past lens_out[b] exit early.
+// GEMM view per utterance b:  Y[co][q] = sum_{ci,tap} W[co][ci][tap] * X[ci][q + tap*dil - pad]
+//   M = co (A operand = weights), N = q (time, B operand = activations), K = (ci, tap).
+// Activations are channel-first [B][C][T]: a wave's 32 N-lanes are 32 consecutive time steps.
+// A block is 4 waves tiled WM x WN, each wave owning MT x NTL 32x32 accumulators.
+//
+// Operand feeding (what the roofline fraction hinges on):
+//  * both operands live in LDS as float4 = FOUR consecutive channel pairs, so ONE
+//    ds_read_b128 per operand tile feeds four MFMA k-steps (16 MFMAs per 4 LDS reads at
+//    MT = NTL = 2, no address VALU: 16-bit immediate offsets).  The k-pair of an MFMA is
+//    (ci = 8o+2p, 8o+2p+1), p = float4 component, lanes 32-63 take the odd channel:
+//      X_lds[o][kk][col][p]      W_lds[o][tap][kk][co][p]     (kk = lane >> 5)
+//    and the weights are stored in exactly that order in HBM (pack_conv_weight) so their
+//    staging is a linear float4 copy;
+//  * a ring of NSTAGE (3 when it fits) LDS stages: the global loads of chunk c+NSTAGE-1 are
+//    issued at the top of chunk c and written to LDS inside its last operand group, one
+//    barrier per chunk; operand registers ping-pong one group ahead (pinned with
+//    sched_barrier — hipcc otherwise re-uses the registers and exposes the LDS latency) and
+//    with 3 stages the last group of a chunk already fetches the first operands of the next
+//    chunk, so the MFMA stream never drains at a chunk boundary;
+//  * input activation (leaky-relu) and the utterance-edge zero padding are applied once on
+//    the LDS write; bias / residual / ReLU / ResBlock sum and /3 are fused in the epilogue.
+// Ragged batches: positions >= lens_in[b] read as zero at the INPUT of every layer
+// (SURVEY.md §3.4-5), tiles past lens_out[b] exit early.
 #include "common.hpp"
 
 namespace ttsamd {
@@ -23,43 +38,41 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int DMAX = 5;  // largest |dilation| the LDS row is sized for
 
-// Input channels staged per LDS chunk: KC*K ~ 48 (ci,tap) rows so that every chunk carries
-// the same ~6k cycles of MFMA work per wave between two barriers.
-#ifndef TTS_KC3
-#define TTS_KC3 8
-#endif
-#ifndef TTS_KC7
-#define TTS_KC7 4
-#endif
-#ifndef TTS_KC11
-#define TTS_KC11 4
-#endif
 #ifndef TTS_MINWAVES
-#define TTS_MINWAVES 3
+#define TTS_MINWAVES 2
 #endif
-template <int K> struct ChunkOf { static constexpr int KC = K >= 11 ? TTS_KC11 : (K >= 7 ? TTS_KC7 : (K >= 3 ? TTS_KC3 : 16)); };
+
+// octets (8 input channels) staged per chunk
+#ifndef TTS_NOCT3
+#define TTS_NOCT3 1
+#endif
+template <int K> struct OctsOf { static constexpr int NOCT = K == 1 ? 4 : (K == 2 ? 2 : (K == 3 ? TTS_NOCT3 : 1)); };
 
 template <int K, int NT_BLK, int CO_BLK>
 struct Geo {
-    static constexpr int KC = ChunkOf<K>::KC;
-    static constexpr int WS = ((NT_BLK + (K - 1) * DMAX + 3) / 4) * 4;  // X row stride (floats)
-    static constexpr int NJ = (NT_BLK + (K - 1) * DMAX + 63) / 64;      // 64-wide column steps
-    static constexpr int XROWS = (KC + 3) / 4;                          // X rows per wave
-    static constexpr int NX = XROWS * NJ;                               // staged X floats / thread
-    static constexpr int W4 = KC * K * CO_BLK / 4;                      // float4s of the W chunk
-    static constexpr int NW = (W4 + 255) / 256;                         // staged W float4s / thread
-    static constexpr int X_FLOATS = KC * WS;
-    static constexpr int W_FLOATS = KC * K * CO_BLK;
-    static constexpr int BUF_FLOATS = X_FLOATS + W_FLOATS;              // one pipeline stage
+    static constexpr int NOCT = OctsOf<K>::NOCT;
+    static constexpr int KC = 8 * NOCT;                       // input channels per chunk
+    static constexpr int WS = NT_BLK + (K - 1) * DMAX;        // staged columns (one float4 each)
+    static constexpr int XI = 2 * NOCT * WS;                  // X float4s per stage
+    static constexpr int NXI = (XI + 255) / 256;              // ... per thread
+    static constexpr int W4 = NOCT * K * 2 * CO_BLK;          // W float4s per stage
+    static constexpr int NW = (W4 + 255) / 256;               // ... per thread
+    static constexpr int BUF4 = XI + W4;                      // float4s per stage
+#ifdef TTS_FORCE_NSTAGE
+    static constexpr int NSTAGE = TTS_FORCE_NSTAGE;
+#else
+    static constexpr int NSTAGE = (3 * BUF4 * 16 <= 80 * 1024) ? 3 : 2;
+#endif
+    static constexpr int NGRP = NOCT * K;                     // operand groups per chunk
 };
 
 template <int K, int MT, int NTL, int WM, int WN>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     constexpr int CO_BLK = WM * MT * 32;
     constexpr int NT_BLK = WN * NTL * 32;
     using G = Geo<K, NT_BLK, CO_BLK>;
-    constexpr int KC = G::KC, WS = G::WS, NJ = G::NJ, NX = G::NX, NW = G::NW, XROWS = G::XROWS;
+    constexpr int KC = G::KC, WS = G::WS, NXI = G::NXI, NW = G::NW, NGRP = G::NGRP, NSTAGE = G::NSTAGE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int b = blockIdx.z;
@@ -79,13 +92,15 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     if (p.n_phase > 1) pad = -((phase + p.phase_p) / p.n_phase);
     const int span = (K - 1) * (dil < 0 ? -dil : dil);
     const int lo = (dil < 0 ? (K - 1) * dil : 0) - pad;  // first input position relative to q0
-    const int W = NT_BLK + span;                          // staged row length (<= WS)
+    const int W = NT_BLK + span;                          // staged columns actually used (<= WS)
 
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
-    const float* __restrict__ wp = p.w + (int64_t)phase * p.Cin * K * p.CoutP + co_blk0;
+    // packed weights: [phase][octet][tap][kk][CoutP][4]
+    const float4* __restrict__ wp4 =
+        reinterpret_cast<const float4*>(p.w) + (int64_t)phase * (p.Cin / 8) * K * 2 * p.CoutP + co_blk0;
     const float in_slope = p.in_slope;
     const int n_chunks = p.Cin / KC;
-    const int x_cs = p.x_cs, CoutP = p.CoutP;   // locals: the lambdas below must not capture `p`
+    const int x_cs = p.x_cs, CoutP = p.CoutP;
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -98,156 +113,165 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     const int qw0 = wn * NTL * 32;
     const bool wave_active = (q0 + qw0) < n_out;   // wave-uniform
     const int kk = lane >> 5, l31 = lane & 31;
-    const int soff = qw0 + l31 - pad - lo;         // >= 0
 
-    // ---- staging registers: X rows (wave w owns rows w, w+4, ..; lanes walk the row) and
-    // the W chunk (a linear float4 copy).  All loads are unconditional (clamped address +
-    // select) so they issue back to back and are only waited for at the end of the chunk.
-    float sx[NX];
-    float sw[4 * NW];
-    bool st_ok[NJ];
-    int st_pos[NJ];
+    // ---- staging registers.  X item it = (oc, kk, col): the 4 channels 8*oc + 2p + kk, p = 0..3,
+    // at one input position -> one float4; W is a linear float4 copy.  Loads are unconditional
+    // (clamped address + select) so they issue back to back and are waited for only where the
+    // chunk is written to LDS.
+    float sx[4 * NXI], sw[4 * NW];   // scalar arrays: float4 arrays end up in scratch
+    bool st_ok[NXI], st_in[NXI];
+    int st_off[NXI];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = lane + 64 * j;
+    for (int i = 0; i < NXI; ++i) {
+        const int it = tid + 256 * i;
+        const int ockk = min(it / WS, 2 * G::NOCT - 1), col = it % WS;
         const int pos = q0 + lo + col;
-        st_ok[j] = (col < W) && (pos >= 0) && (pos < in_len);
-        st_pos[j] = min(max(pos, 0), max(in_len - 1, 0));
-    }
-#define TTS_STAGE_LOAD(CH)                                                                          \
-    {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < XROWS; ++i) {                                         \
-            const int r = min(wid + 4 * i, KC - 1);                                                 \
-            const float* __restrict__ xc = xb + (int64_t)((CH)*KC + r) * x_cs;                      \
-            _Pragma("unroll") for (int j = 0; j < NJ; ++j) sx[i * NJ + j] = xc[st_pos[j]];          \
-        }                                                                                           \
-        const float* __restrict__ wc = wp + (int64_t)(CH)*KC * K * CoutP;                           \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                            \
-            const int e = min(tid + 256 * i, G::W4 - 1);                                            \
-            const int row = e / (CO_BLK / 4), c4 = e % (CO_BLK / 4);                                \
-            const float4 t4 = *reinterpret_cast<const float4*>(wc + (int64_t)row * CoutP + 4 * c4); \
-            sw[4 * i + 0] = t4.x; sw[4 * i + 1] = t4.y; sw[4 * i + 2] = t4.z; sw[4 * i + 3] = t4.w; \
-        }                                                                                           \
-    }
-#define TTS_STAGE_WRITE(BUF)                                                                        \
-    {                                                                                               \
-        float* sb = smem + (BUF)*G::BUF_FLOATS;                                                     \
-        _Pragma("unroll") for (int i = 0; i < XROWS; ++i) {                                         \
-            if (wid + 4 * i < KC) {                                                                 \
-                _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                    \
-                    const int col = lane + 64 * j;                                                  \
-                    if (col < WS) {                                                                 \
-                        float v = sx[i * NJ + j];                                                   \
-                        v = v > 0.f ? v : v * in_slope;                                             \
-                        sb[(wid + 4 * i) * WS + col] = st_ok[j] ? v : 0.f;                          \
-                    }                                                                               \
-                }                                                                                   \
-            }                                                                                       \
-        }                                                                                           \
-        float4* swp = reinterpret_cast<float4*>(sb + G::X_FLOATS);                                  \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                            \
-            const int e = tid + 256 * i;                                                            \
-            if (e < G::W4) swp[e] = make_float4(sw[4 * i], sw[4 * i + 1], sw[4 * i + 2], sw[4 * i + 3]); \
-        }                                                                                           \
+        st_in[i] = it < G::XI;
+        st_ok[i] = st_in[i] && (col < W) && (pos >= 0) && (pos < in_len);
+        st_off[i] = ((ockk >> 1) * 8 + (ockk & 1)) * x_cs + min(max(pos, 0), max(in_len - 1, 0));
     }
 
-    // 3-stage LDS ring, one barrier per chunk, MFMA stream continuous across chunk boundaries:
-    //   top of chunk c : issue the global loads of chunk c+2 (registers)
-    //   steps 0..N-1   : MFMAs of chunk c from stage c%3; the operands of step s+1 are fetched
-    //                    from LDS before the MFMAs of step s are issued (register ping-pong);
-    //                    the LAST step fetches step 0 of chunk c+1 (stage (c+1)%3, made visible
-    //                    by the previous barrier), so no wave ever drains at a chunk boundary
-    //                    (waves of a SIMD run in lockstep: occupancy cannot hide such a bubble)
-    //   before the last step: write chunk c+2 into stage (c+2)%3 (last read in chunk c-1)
-    //   barrier        : covered by the 4 MFMAs just issued
-    // Waves whose whole time range lies past n_out still run the MFMAs (results discarded):
-    // keeping the MFMA block unconditional lets the accumulators stay in registers across chunks.
-    constexpr int NSTEP = (KC / 2) * K;
-    const float* sx0 = smem + kk * WS + soff;
-    const float* sw0 = smem + G::X_FLOATS + kk * K * CO_BLK + wm * MT * 32 + l31;
-    float a[2][MT], bq[2][NTL];
+    // One staging "job" = one memory instruction (+ its VALU).  Jobs are spread one by one
+    // over the gaps between MFMAs (an MFMA occupies the matrix pipe for 64 cycles, during
+    // which the wave can issue ~50 cycles of other work for free); every gap is pinned with
+    // sched_barrier(0).  Load jobs of chunk c+NSTAGE-1 go into the first NGRP-1 operand
+    // groups of chunk c, write jobs into its last group.
+    constexpr int NLJ = 4 * NXI + NW;          // load jobs per chunk
+    constexpr int NWJ = NXI + NW;              // write jobs per chunk
+    constexpr int NM = 4 * MT * NTL;           // MFMAs per operand group
+    constexpr int NF = MT + NTL;               // ds_read_b128 per operand fetch
+    constexpr int GL = (NGRP - 1) * NM;        // gaps carrying load jobs
+    static_assert(NGRP >= 2 && NF <= NM, "operand group layout");
+#define TTS_LOAD_JOB(J)                                                                              \
+    {                                                                                                \
+        if ((J) < 4 * NXI) {                                                                         \
+            sx[(J)] = xc[st_off[(J) / 4] + 2 * ((J) % 4) * x_cs];                                    \
+        } else {                                                                                     \
+            const int i_ = (J)-4 * NXI;                                                              \
+            const int e = min(tid + 256 * i_, G::W4 - 1);                                            \
+            const float4 t4 = wc[(int64_t)(e / CO_BLK) * CoutP + (e % CO_BLK)];                      \
+            sw[4 * i_] = t4.x; sw[4 * i_ + 1] = t4.y; sw[4 * i_ + 2] = t4.z; sw[4 * i_ + 3] = t4.w;  \
+        }                                                                                            \
+    }
+#define TTS_LRELU(v) ((v) > 0.f ? (v) : (v)*in_slope)
+#define TTS_WRITE_JOB(J, SB)                                                                         \
+    {                                                                                                \
+        if ((J) < NXI) {                                                                             \
+            const int i_ = (J);                                                                      \
+            if (st_in[i_]) {                                                                         \
+                const float v0 = sx[4 * i_], v1 = sx[4 * i_ + 1], v2 = sx[4 * i_ + 2], v3 = sx[4 * i_ + 3]; \
+                (SB)[tid + 256 * i_] =                                                               \
+                    st_ok[i_] ? make_float4(TTS_LRELU(v0), TTS_LRELU(v1), TTS_LRELU(v2), TTS_LRELU(v3)) \
+                              : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+            }                                                                                        \
+        } else {                                                                                     \
+            const int i_ = (J)-NXI;                                                                  \
+            const int e = tid + 256 * i_;                                                            \
+            if (e < G::W4)                                                                           \
+                (SB)[G::XI + e] = make_float4(sw[4 * i_], sw[4 * i_ + 1], sw[4 * i_ + 2], sw[4 * i_ + 3]); \
+        }                                                                                            \
+    }
+    // part PART (< NF) of the operand fetch of group GRP of stage STG into register slot SLOT
+#define TTS_FETCH_PART(SLOT, STG, GRP, PART)                                                         \
+    {                                                                                                \
+        if ((PART) < MT) {                                                                           \
+            const float4 t4 = sA[(STG)*G::BUF4 + (GRP)*2 * CO_BLK + (PART)*32];                      \
+            a[SLOT][(PART) % MT][0] = t4.x; a[SLOT][(PART) % MT][1] = t4.y;                          \
+            a[SLOT][(PART) % MT][2] = t4.z; a[SLOT][(PART) % MT][3] = t4.w;                          \
+        } else {                                                                                     \
+            const int j_ = ((PART)-MT) % NTL;                                                        \
+            const float4 t4 = sB[(STG)*G::BUF4 + ((GRP) / K) * 2 * WS + ((GRP) % K) * dil + j_ * 32]; \
+            bq[SLOT][j_][0] = t4.x; bq[SLOT][j_][1] = t4.y; bq[SLOT][j_][2] = t4.z; bq[SLOT][j_][3] = t4.w; \
+        }                                                                                            \
+    }
 
-    TTS_STAGE_LOAD(0)
-    TTS_STAGE_WRITE(0)
-    if (n_chunks > 1) {
-        TTS_STAGE_LOAD(1)
-        TTS_STAGE_WRITE(1)
+    const float4* sB = smem4 + kk * WS + (qw0 + l31 - pad - lo);
+    const float4* sA = smem4 + G::XI + kk * CO_BLK + wm * MT * 32 + l31;
+    float a[2][MT][4], bq[2][NTL][4];
+
+    // prologue: fill NSTAGE-1 stages (bulk), fetch the first operands
+    for (int c0 = 0; c0 < NSTAGE - 1 && c0 < n_chunks; ++c0) {
+        const float* __restrict__ xc = xb + (int64_t)c0 * KC * x_cs;
+        const float4* __restrict__ wc = wp4 + (int64_t)c0 * G::NOCT * K * 2 * CoutP;
+        float4* sbp = smem4 + c0 * G::BUF4;
+#pragma unroll
+        for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
+#pragma unroll
+        for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, sbp)
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a[0][i] = sw0[i * 32];
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) bq[0][j] = sx0[j * 32];
+    for (int P = 0; P < NF; ++P) TTS_FETCH_PART(0, 0, 0, P)
 
-    int stage = 0;                                   // c % 3
+    int stage = 0;  // c % NSTAGE
     for (int c = 0; c < n_chunks; ++c) {
-        const bool more2 = c + 2 < n_chunks;
-#ifndef TTS_EXP_NOLOAD
-        if (more2) TTS_STAGE_LOAD(c + 2)
-#endif
-        const float* sx_ = sx0 + stage * G::BUF_FLOATS;
-        const float* sw_ = sw0 + stage * G::BUF_FLOATS;
-        const int stage1 = stage == 2 ? 0 : stage + 1;   // (c+1) % 3
-        const int stage2 = stage == 0 ? 2 : stage - 1;   // (c+2) % 3
+        // chunk to stage during this chunk (clamped: at the tail the last chunk is re-staged
+        // into a dead stage, which keeps the loop body branch-free)
+        const int cl = min(c + NSTAGE - 1, n_chunks - 1);
+        const float* __restrict__ xc = xb + (int64_t)cl * KC * x_cs;
+        const float4* __restrict__ wc = wp4 + (int64_t)cl * G::NOCT * K * 2 * CoutP;
+        const int stage_next = (stage + 1 == NSTAGE) ? 0 : stage + 1;           // chunk c+1
+        const int stage_fill = (stage == 0) ? NSTAGE - 1 : stage - 1;           // chunk c+NSTAGE-1
+        float4* sbf = smem4 + stage_fill * G::BUF4;
+        const int sn = (c + 1 < n_chunks) ? stage_next : stage;
 #pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            const int cur = st & 1, nxt = cur ^ 1;
-            if (st + 1 < NSTEP) {
-                const int pr = (st + 1) / K, tap = (st + 1) % K;
-#if defined(TTS_EXP_B64)   /* timing-only experiment: wrong addresses */
-                if constexpr (MT == 2 && NTL == 2) {
-                    const float2 ta = *reinterpret_cast<const float2*>(sw_ + ((2 * pr) * K + tap) * CO_BLK + l31);
-                    a[nxt][0] = ta.x; a[nxt][1] = ta.y;
-#if TTS_EXP_B64 >= 2
-                    const float2 tb = *reinterpret_cast<const float2*>(sx_ + (2 * pr) * WS + 2 * tap + l31);
-                    bq[nxt][0] = tb.x; bq[nxt][1] = tb.y;
-#else
-                    for (int j = 0; j < NTL; ++j) bq[nxt][j] = sx_[(2 * pr) * WS + tap * dil + j * 32];
-#endif
-                } else
-#endif
-                {
+        for (int g = 0; g < NGRP; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[nxt][i] = sw_[((2 * pr) * K + tap) * CO_BLK + i * 32];
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) bq[nxt][j] = sx_[(2 * pr) * WS + tap * dil + j * 32];
+            for (int m = 0; m < NM; ++m) {
+                const int pq = m / (MT * NTL), i = (m / NTL) % MT, j = m % NTL;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][pq], bq[cur][j][pq], acc[i][j], 0, 0, 0);
+                // ---- gap work ----
+                if (m < NF) {
+                    if (g + 1 < NGRP) TTS_FETCH_PART(nxt, stage, g + 1, m)
+                    else if (NSTAGE == 3) TTS_FETCH_PART(nxt, sn, 0, m)
                 }
-            } else {
-#ifndef TTS_EXP_NOWRITE
-                if (more2) TTS_STAGE_WRITE(stage2)
+#if !defined(TTS_EXP_NOLOAD)
+                if (g + 1 < NGRP) {
+
+                    const int t = g * NM + m;
+#pragma unroll
+                    for (int J = 0; J < NLJ; ++J)
+                        if (J >= t * NLJ / GL && J < (t + 1) * NLJ / GL) TTS_LOAD_JOB(J)
+                }
 #endif
-                // step 0 of the next chunk (clamped re-read of a valid stage on the last chunk)
-                const int sn = (c + 1 < n_chunks) ? stage1 : stage;
+#if !defined(TTS_EXP_NOWRITE)
+                if (g + 1 == NGRP) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[nxt][i] = sw0[sn * G::BUF_FLOATS + i * 32];
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) bq[nxt][j] = sx0[sn * G::BUF_FLOATS + j * 32];
+                    for (int J = 0; J < NWJ; ++J)
+                        if (J >= m * NWJ / NM && J < (m + 1) * NWJ / NM) TTS_WRITE_JOB(J, sbf)
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bq[cur][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (NSTEP & 1) {                               // odd step count: operands of the next chunk sit in slot 1
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[0][i] = a[1][i];
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) bq[0][j] = bq[1][j];
         }
 #ifndef TTS_EXP_NOBARRIER
         __syncthreads();
 #endif
-        stage = stage1;
+        if (NSTAGE == 3) {
+            if ((NGRP & 1) != 0) {   // the prefetched group sits in slot 1: next chunk starts from slot 0
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[0][i][e] = a[1][i][e];
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bq[0][j][e] = bq[1][j][e];
+            }
+        } else if (c + 1 < n_chunks) {
+#pragma unroll
+            for (int P = 0; P < NF; ++P) TTS_FETCH_PART(0, stage_next, 0, P)
+        }
+        stage = stage_next;
     }
-#undef TTS_STAGE_LOAD
-#undef TTS_STAGE_WRITE
+#undef TTS_LOAD_JOB
+#undef TTS_WRITE_JOB
+#undef TTS_FETCH_PART
+#undef TTS_LRELU
 
-    // epilogue: bias, residual, activation, accumulate modes.  Per 32x32 tile all loads
-    // (bias, residual, previous y) are issued first and only then consumed, so a tile costs
-    // one memory round trip instead of sixteen.
+    // epilogue: bias, residual, activation, accumulate modes.  Per half tile all loads
+    // (bias, residual, previous y) are issued first and only then consumed.
     if (!wave_active) return;
     const int co_w0 = co_blk0 + wm * MT * 32;
     float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
@@ -296,7 +320,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
     using G = Geo<K, NT_BLK, CO_BLK>;
     TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
-    const size_t lds = (size_t)3 * G::BUF_FLOATS * sizeof(float);
+    const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(float4);
     static bool attr_set = false;
     if (!attr_set) {
         TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_f32<K, MT, NTL, WM, WN>,
@@ -312,15 +336,27 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
 template <int K>
 static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
     const bool is_long = p.Nout > 96;
-    if (p.CoutP % 128 == 0) {
+    if (p.CoutP % 128 == 0 && (K < 11 || !is_long)) {
+#ifdef TTS_BIGTILE
+        if (is_long) return launch_cfg<K, 2, 4, 2, 2>(p, stream);   // 128 co x 256 t
+#else
         if (is_long) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
+#endif
         return launch_cfg<K, 1, 2, 4, 1>(p, stream);                // 128 co x  64 t
     }
     if (p.CoutP % 64 == 0) {
+#ifdef TTS_BIGTILE
+        if (is_long) return launch_cfg<K, 2, 4, 1, 4>(p, stream);   //  64 co x 512 t
+#else
         if (is_long) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
+#endif
         return launch_cfg<K, 1, 1, 2, 2>(p, stream);                //  64 co x  64 t
     }
+#ifdef TTS_BIGTILE
+    if (is_long) return launch_cfg<K, 1, 4, 1, 4>(p, stream);       //  32 co x 512 t
+#else
     if (is_long) return launch_cfg<K, 1, 2, 1, 4>(p, stream);       //  32 co x 256 t
+#endif
     return launch_cfg<K, 1, 1, 1, 4>(p, stream);                    //  32 co x 128 t
 }
 
@@ -341,29 +377,39 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     }
 }
 
+// torch Conv1d weight [Cout][Cin][K] -> [Cin/8][K][2][CoutP][4]:
+//   out[(((o*K + t)*2 + kk)*CoutP + co)*4 + p] = w[co][8*o + 2*p + kk][t]
 void pack_conv_weight(const float* w, int cout, int cin, int k, float* out) {
     const int cp = cout_padded(cout);
-    for (int ci = 0; ci < cin; ++ci)
-        for (int t = 0; t < k; ++t) {
-            float* o = out + ((int64_t)ci * k + t) * cp;
-            for (int co = 0; co < cp; ++co)
-                o[co] = co < cout ? w[((int64_t)co * cin + ci) * k + t] : 0.f;
-        }
+    for (int o = 0; o < cin / 8; ++o)
+        for (int t = 0; t < k; ++t)
+            for (int kk = 0; kk < 2; ++kk) {
+                float* dst = out + (((int64_t)o * k + t) * 2 + kk) * cp * 4;
+                for (int co = 0; co < cp; ++co)
+                    for (int pq = 0; pq < 4; ++pq)
+                        dst[co * 4 + pq] = co < cout ? w[((int64_t)co * cin + (8 * o + 2 * pq + kk)) * k + t] : 0.f;
+            }
 }
 
 // ConvTranspose1d(stride u, kernel Kt = 2u, padding p): y[co][q*u+rho] =
 //   sum_ci W[ci][co][ka] x[ci][q+delta] + W[ci][co][ka+u] x[ci][q+delta-1],
-//   ka = (rho+p) % u, delta = (rho+p) / u     (vocoder/hifigan/models.py:96-99).
+//   ka = (rho+p) % u, delta = (rho+p) / u     (vocoder/hifigan/models.py:96-99)
+// -> u polyphase 2-tap filters in the layout above: [u][Cin/8][2 taps][2][CoutP][4]
 void pack_convt_weight(const float* w, int cin, int cout, int kt, int u, int p, float* out) {
     const int cp = cout_padded(cout);
     for (int rho = 0; rho < u; ++rho) {
         const int ka = (rho + p) % u;
-        for (int ci = 0; ci < cin; ++ci)
+        for (int o = 0; o < cin / 8; ++o)
             for (int t = 0; t < 2; ++t) {
                 const int kidx = ka + t * u;
-                float* o = out + (((int64_t)rho * cin + ci) * 2 + t) * cp;
-                for (int co = 0; co < cp; ++co)
-                    o[co] = (co < cout && kidx < kt) ? w[((int64_t)ci * cout + co) * kt + kidx] : 0.f;
+                for (int kk = 0; kk < 2; ++kk) {
+                    float* dst = out + ((((int64_t)rho * (cin / 8) + o) * 2 + t) * 2 + kk) * cp * 4;
+                    for (int co = 0; co < cp; ++co)
+                        for (int pq = 0; pq < 4; ++pq)
+                            dst[co * 4 + pq] = (co < cout && kidx < kt)
+                                                   ? w[((int64_t)(8 * o + 2 * pq + kk) * cout + co) * kt + kidx]
+                                                   : 0.f;
+                }
             }
     }
 }

@@ -14,7 +14,6 @@
 namespace ttsamd {
 
 constexpr int NFFT = 1024, HOP = 256, NBIN = NFFT / 2 + 1;        // 513
-constexpr int SPEC_C = 2 * NBIN;                                  // 1026 rows: re | im
 constexpr int SPEC_CP = 1152;                                     // padded to 9 x 128 (co tiles) and % 16
 struct Denoiser {
     float* dev = nullptr;
@@ -28,27 +27,24 @@ int32_t denoiser_create(Denoiser** out) {
     std::vector<double> win(NFFT);
     const double two_pi = 6.283185307179586476925286766559;
     for (int k = 0; k < NFFT; ++k) win[k] = 0.5 - 0.5 * std::cos(two_pi * k / NFFT);   // periodic hann
-    // forward: packed [Cin = k (1024)][1][CoutP = SPEC_CP], column f = re, NBIN + f = im
-    h->w_fwd = 0;
-    blob.resize((size_t)NFFT * SPEC_CP, 0.f);
-    for (int k = 0; k < NFFT; ++k)
-        for (int f = 0; f < NBIN; ++f) {
-            const double ang = two_pi * (double)((int64_t)f * k % NFFT) / NFFT;
-            blob[(size_t)k * SPEC_CP + f] = (float)(win[k] * std::cos(ang));
-            blob[(size_t)k * SPEC_CP + NBIN + f] = (float)(-win[k] * std::sin(ang));
-        }
-    // inverse (irfft * window): packed [Cin = SPEC_CP rows (re|im, zero padded)][1][CoutP = 1024 (k)]
-    h->w_inv = (int64_t)blob.size();
-    blob.resize(blob.size() + (size_t)SPEC_CP * NFFT, 0.f);
-    float* wi = blob.data() + h->w_inv;
-    for (int f = 0; f < NBIN; ++f) {
-        const double cf = (f == 0 || f == NFFT / 2) ? 1.0 : 2.0;
+    // forward DFT as a 1x1 conv: torch-layout weight [Cout = SPEC_CP (re | im | zero pad)][Cin = 1024]
+    std::vector<float> wf((size_t)SPEC_CP * NFFT, 0.f), wi((size_t)NFFT * SPEC_CP, 0.f);
+    for (int f = 0; f < NBIN; ++f)
         for (int k = 0; k < NFFT; ++k) {
             const double ang = two_pi * (double)((int64_t)f * k % NFFT) / NFFT;
-            wi[(size_t)f * NFFT + k] = (float)(cf * std::cos(ang) * win[k] / NFFT);
-            wi[(size_t)(NBIN + f) * NFFT + k] = (float)(-cf * std::sin(ang) * win[k] / NFFT);
+            wf[(size_t)f * NFFT + k] = (float)(win[k] * std::cos(ang));
+            wf[(size_t)(NBIN + f) * NFFT + k] = (float)(-win[k] * std::sin(ang));
+            // inverse (irfft * window): [Cout = 1024 (k)][Cin = SPEC_CP]
+            const double cf = (f == 0 || f == NFFT / 2) ? 1.0 : 2.0;
+            wi[(size_t)k * SPEC_CP + f] = (float)(cf * std::cos(ang) * win[k] / NFFT);
+            wi[(size_t)k * SPEC_CP + NBIN + f] = (float)(-cf * std::sin(ang) * win[k] / NFFT);
         }
-    }
+    h->w_fwd = 0;
+    blob.resize((size_t)NFFT * SPEC_CP);
+    pack_conv_weight(wf.data(), SPEC_CP, NFFT, 1, blob.data());
+    h->w_inv = (int64_t)blob.size();
+    blob.resize(blob.size() + (size_t)SPEC_CP * NFFT);
+    pack_conv_weight(wi.data(), NFFT, SPEC_CP, 1, blob.data() + h->w_inv);
     h->window = (int64_t)blob.size();
     for (int k = 0; k < NFFT; ++k) blob.push_back((float)win[k]);
     hipError_t e = hipMalloc((void**)&h->dev, blob.size() * sizeof(float));
