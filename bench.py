@@ -144,18 +144,24 @@ def main():
 
     if rank == 0:
         conv_ms, n_launch, flop_per_frame = prof[0], prof[1], prof[2]
-        # algorithmic FLOPs of the bracketed MFMA conv launches over the timed region on this rank:
-        # per launch 2*Cout*Cin*K per output position; positions summed per utterance length.
-        # FastPitch encoder launches work on tokens, decoder + vocoder on frames; the library
-        # accumulates FLOP per *unit length* and we scale by the mean units per launch below.
+        # algorithmic FLOPs (2*Cout*Cin*K per output position) of the bracketed MFMA conv launches on
+        # this rank: HiFi-GAN convs process sum(frames)*upsampling positions (ragged, early exit),
+        # FastPitch decoder convs B*T_max positions, encoder/predictor convs B*L positions.
         t_max = int(dec_lens.max().item())
-        # exact accounting: HiFi-GAN convs process sum(frames)*mul positions (ragged, early exit);
-        # FastPitch decoder convs process B*T_max positions, encoder convs B*L positions.
         from ttsamd.config import NET_CONFIG as NC, HIFIGAN_CONFIG as HC
         hg_fpf = hifigan_flops_per_frame(HC)
         dec_fpt, enc_fpt = fastpitch_conv_flops_per_pos(NC)
         flops = args.steps * (hg_fpf * frames + dec_fpt * B * t_max + enc_fpt * B * Lt)
         achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # HBM bytes per conv launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+        # this same command (profiles/r1/traffic.json; collected offline, gpurun forbids mixing PMC with
+        # the timed run); algorithmic bytes = read x + read residual/previous sum + write y.
+        traffic = None
+        try:
+            with open(os.path.join(REPO, 'profiles', 'r1', 'traffic.json')) as f:
+                traffic = json.load(f)['bytes_per_conv_launch_corrected'] if B == 32 and Lt == 64 else None
+        except OSError:
+            pass
         out = {
             'metric': 'audio samples/sec (FastPitch+HiFi-GAN, synthetic 64-phoneme inputs)',
             'value': samples / elapsed, 'unit': 'audio samples/s',
@@ -168,7 +174,7 @@ def main():
                        'frames_per_step_rank0': frames, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': 'conv1d_mfma_f32 (all instantiations)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'B/launch',
                          'launches': int(n_launch), 'avg_launch_ms': conv_ms / max(1.0, n_launch),
                          'kernel_ms_per_step': conv_ms / args.steps},
         }
