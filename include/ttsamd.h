@@ -147,6 +147,24 @@ int32_t ttsamd_denoise(void* handle, float* wave, int64_t wave_stride, const int
                        int32_t batch, int32_t n_max, const float* bias_spec, float strength,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- MelVocos('22k') vocoder: replaces vocoder.vocos.pretrained.MelVocos
+ *      (vocoder/vocos/pretrained.py:34-93; backbone models.py:26-89, ConvNeXtBlock modules.py:8-60,
+ *      ISTFTHead heads.py:26-41, ISTFT "same" spectral_ops.py:33-75).  Weight names are the keys of
+ *      MelVocos.state_dict() (backbone.*, head.out.*). ------------------------------------------- */
+int32_t ttsamd_vocos_create(const ttsamd_tensor* weights, int32_t n_weights, int32_t input_channels,
+                            int32_t dim, int32_t intermediate_dim, int32_t num_layers, void** handle);
+int32_t ttsamd_vocos_destroy(void* handle);
+int64_t ttsamd_vocos_workspace_bytes(void* handle, int32_t batch, int32_t t_max);
+/* bias_vec[513] = clip(exp(log-magnitude of a zero mel [1,80,88]), max 100)[:, frame 0]
+ * (make_denoising_vector, pretrained.py:59-71). */
+int32_t ttsamd_vocos_bias_vec(void* handle, float* bias_vec, void* workspace, int64_t workspace_bytes,
+                              void* stream);
+/* mel [B][80][t_max], lens int64 [B] (device) -> wave [B][256*t_max]; samples >= 256*lens[b] untouched.
+ * mag = clamp(exp(.) - denoise*bias_vec, 0, 100) (pretrained.py:79-88). */
+int32_t ttsamd_vocos_forward(void* handle, const float* mel, const int64_t* lens, int32_t batch,
+                             int32_t t_max, float denoise, const float* bias_vec, float* wave,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- kernel-level entry used by the parity tests and the roofline bench ------------- */
 
 /* One Conv1d through the implicit-GEMM MFMA kernel: y = conv1d(lrelu_slope(x), w) + b.

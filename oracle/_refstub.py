@@ -72,6 +72,8 @@ def install():
         def __init__(self, *a, **k):
             super().__init__()
 
+    fnfn._hz_to_mel = lambda *a, **k: None      # imported by vocoder/vocos/heads.py:5, used only by IMDCT heads
+    fnfn._mel_to_hz = lambda *a, **k: None
     tr.Spectrogram, tr.InverseSpectrogram, tr.MelSpectrogram = \
         Spectrogram, InverseSpectrogram, MelSpectrogram
     ta.transforms, ta.functional = tr, fn

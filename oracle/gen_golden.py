@@ -248,6 +248,26 @@ def main():
     save('e2e_tts', **e2e)
     print('e2e lens', [len(w) for w in waves0], 'amp', [float(w.abs().max()) for w in waves0])
 
+    # ---------------- MelVocos('22k') (config 5 back half) ----------------
+    from vocoder.vocos.pretrained import MelVocos
+    with torch.enable_grad():
+        mv = MelVocos('22k')
+    vsd = synth.vocos_state_dict()
+    digests['vocos_seed0'] = sd_digest(vsd)
+    full = {k: v for k, v in mv.state_dict().items() if k not in vsd}      # window / feature-extractor buffers
+    full.update(t(vsd))
+    mv.load_state_dict(full)                                               # post-hook recomputes bias_vec
+    mv.eval()
+    rngv = np.random.default_rng(13)
+    vg = {'bias_vec': mv.bias_vec}
+    for T in (1, 5, 33):
+        melv = torch.from_numpy((rngv.standard_normal((2, 80, T)) * 1.5 - 4.0).astype(np.float32))
+        vg[f'mel_T{T}'] = melv
+        vg[f'wave_T{T}'] = mv(melv)
+        vg[f'wave_dn_T{T}'] = mv(melv, denoise=0.3)
+    save('vocos_22k', **vg)
+    print('vocos wave amp', float(vg['wave_T33'].abs().max()), 'bias max', float(mv.bias_vec.max()))
+
     with open(os.path.join(OUT, 'digests.json'), 'w') as f:
         json.dump(digests, f, indent=1)
 

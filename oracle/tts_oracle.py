@@ -295,6 +295,64 @@ def denoise(wave, bias_spec, strength):
 
 
 # --------------------------------------------------------------------------------------
+# MelVocos('22k'): ConvNeXt backbone + ISTFT head ("same" padding)
+# --------------------------------------------------------------------------------------
+
+def _vocos_backbone(W, x, n_layers):
+    """vocoder/vocos/models.py:77-89 (VocosBackbone.forward) over ConvNeXtBlock.forward
+    (modules.py:43-60).  x [B,80,T] -> [B,T,512]."""
+    x = F.conv1d(x, W['backbone.embed.weight'], W['backbone.embed.bias'], padding=3)
+    d = x.shape[1]
+    x = F.layer_norm(x.transpose(1, 2), (d,), W['backbone.norm.weight'], W['backbone.norm.bias'], eps=1e-6).transpose(1, 2)
+    for i in range(n_layers):
+        p = f'backbone.convnext.{i}.'
+        res = x
+        y = F.conv1d(x, W[p + 'dwconv.weight'], W[p + 'dwconv.bias'], padding=3, groups=d).transpose(1, 2)
+        y = F.layer_norm(y, (d,), W[p + 'norm.weight'], W[p + 'norm.bias'], eps=1e-6)
+        y = F.linear(y, W[p + 'pwconv1.weight'], W[p + 'pwconv1.bias'])
+        y = F.gelu(y)
+        y = F.linear(y, W[p + 'pwconv2.weight'], W[p + 'pwconv2.bias'])
+        y = W[p + 'gamma'] * y
+        x = res + y.transpose(1, 2)
+    return F.layer_norm(x.transpose(1, 2), (d,), W['backbone.final_layer_norm.weight'],
+                        W['backbone.final_layer_norm.bias'], eps=1e-6)
+
+
+def vocos_bias_vec(w, cfg, dtype=torch.float32):
+    """vocoder/vocos/pretrained.py:59-71 (make_denoising_vector): exp(log-mag) of a zero mel, frame 0."""
+    W = {k: _t(v, dtype) for k, v in w.items()}
+    feats = _vocos_backbone(W, torch.zeros(1, cfg['input_channels'], 88, dtype=dtype), cfg['num_layers'])
+    xb = F.linear(feats, W['head.out.weight'], W['head.out.bias']).transpose(1, 2)
+    mag, _ = xb.chunk(2, dim=1)
+    return torch.clip(torch.exp(mag), max=1e2)[:, :, 0:1]
+
+
+def vocos_forward(w, mel, cfg, denoise=0.0, bias_vec=None, dtype=torch.float32):
+    """vocoder/vocos/pretrained.py:73-93 (MelVocos.forward) + ISTFT 'same' (spectral_ops.py:33-75).
+    mel [B,80,T] -> wave [B, 256*T]."""
+    W = {k: _t(v, dtype) for k, v in w.items()}
+    x = _t(mel, dtype)
+    feats = _vocos_backbone(W, x, cfg['num_layers'])
+    xo = F.linear(feats, W['head.out.weight'], W['head.out.bias']).transpose(1, 2)
+    mag, ph = xo.chunk(2, dim=1)
+    mag = torch.exp(mag)
+    if bias_vec is None:
+        bias_vec = vocos_bias_vec(w, cfg, dtype)
+    mag = torch.clamp(mag - denoise * bias_vec.to(dtype), min=0., max=1e2)
+    S = mag * (torch.cos(ph) + 1j * torch.sin(ph))
+    n_fft, hop = cfg['n_fft'], cfg['hop_length']
+    pad = (n_fft - hop) // 2
+    win = torch.hann_window(n_fft, dtype=dtype)
+    B, N, T = S.shape
+    ifft = torch.fft.irfft(S, n_fft, dim=1, norm='backward') * win[None, :, None]
+    out_size = (T - 1) * hop + n_fft
+    y = F.fold(ifft, output_size=(1, out_size), kernel_size=(1, n_fft), stride=(1, hop))[:, 0, 0, pad:-pad]
+    env = F.fold(win.square().expand(1, T, -1).transpose(1, 2), output_size=(1, out_size), kernel_size=(1, n_fft),
+                 stride=(1, hop)).squeeze()[pad:-pad]
+    return y / env
+
+
+# --------------------------------------------------------------------------------------
 # The whole .tts_batch-equivalent (used for goldens and as bench.py's cpu_baseline)
 # --------------------------------------------------------------------------------------
 

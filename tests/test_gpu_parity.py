@@ -255,3 +255,66 @@ def test_dropin_cpu_device_raises(checkpoints):
     model = FastPitch(checkpoints[0])           # stays on the CPU
     with pytest.raises(TtsAmdError):
         model.ttmel('marHabAF')
+
+
+# ---------------------------------------------------------------------------------------
+# MelVocos('22k') (config 5 back half)
+# ---------------------------------------------------------------------------------------
+
+def test_vocos_golden_and_ragged(dev, golden):
+    import tts_oracle as O
+    from ttsamd import synth
+    from ttsamd.config import VOCOS_22K_CONFIG
+    from vocoder.vocos import MelVocos
+    g = golden('vocos_22k')
+    w = synth.vocos_state_dict()
+    voc = MelVocos('22k')
+    voc.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    voc = voc.to(dev)
+    assert maxabs(voc.bias_vec, g['bias_vec']) < 1e-4
+    for T in (1, 5, 33):
+        mel = torch.from_numpy(g[f'mel_T{T}']).to(dev)
+        assert maxabs(voc(mel), g[f'wave_T{T}']) < WAVE_TOL
+        assert maxabs(voc(mel, denoise=0.3), g[f'wave_dn_T{T}']) < WAVE_TOL
+    # ragged batch == per-utterance exact-length runs of the oracle
+    rng = np.random.default_rng(17)
+    lens = [29, 7, 16]
+    mel = (rng.standard_normal((3, 80, 29)) * 1.5 - 4.0).astype(np.float32)
+    wave = voc(torch.from_numpy(mel).to(dev), lens=torch.tensor(lens).to(dev)).cpu()
+    for b, n in enumerate(lens):
+        ref = O.vocos_forward(w, mel[b:b + 1, :, :n], VOCOS_22K_CONFIG)[0]
+        assert maxabs(wave[b, :256 * n], ref) < WAVE_TOL
+        assert n == 29 or float(wave[b, 256 * n:].abs().max()) == 0.0
+
+
+def test_fastpitch_multispeaker_plus_vocos(dev, golden, synth_weights):
+    """Config 5 wiring (the build's own: the reference never connects them): 4-speaker FastPitch -> Vocos."""
+    import tts_oracle as O
+    from ttsamd import synth
+    from ttsamd.config import NET_CONFIG, VOCOS_22K_CONFIG
+    from ttsamd.engine import FastPitchEngine, VocosEngine
+    g = golden('fastpitch_b3_spk2')
+    fp = FastPitchEngine(synth_weights['fastpitch_spk4'], dict(NET_CONFIG, n_speakers=4))
+    w = synth.vocos_state_dict()
+    voc = VocosEngine(w)
+    mel, dec_lens, *_ = fp.infer(g['ids'], dur_tgt=g['dur_tgt'], speaker=2)
+    wave = voc.forward(mel, dec_lens).cpu()
+    for b in range(3):
+        n = int(g['dec_lens'][b])
+        ref = O.vocos_forward(w, g['mel'][b:b + 1, :, :n], VOCOS_22K_CONFIG)[0]
+        assert maxabs(wave[b, :256 * n], ref) < WAVE_TOL
+
+
+def test_denoiser_strong_setting(dev, golden, hifigan_engine):
+    """A large strength makes consecutive frames inconsistent, so every overlap-add term matters
+    (a weak denoise is nearly the identity and hides frame-range bugs)."""
+    import tts_oracle as O
+    from ttsamd.engine import DenoiserEngine
+    e = golden('e2e_tts')
+    wave = torch.from_numpy(e['single_wave'])[None]
+    bias = torch.from_numpy(e['bias_spec']) * 40.0
+    ref = O.denoise(wave, bias, 1.0)
+    eng = DenoiserEngine()
+    out = eng.denoise(wave.to(dev).clone().contiguous(), torch.tensor([wave.shape[1]]).to(dev), bias, 1.0).cpu()
+    assert float((ref - wave).abs().max()) > 1e-2          # the setting really changes the signal
+    assert maxabs(out[:, :ref.shape[1]], ref) < WAVE_TOL

@@ -128,3 +128,23 @@ def test_end_to_end_tts(golden, synth_weights):
     _, _, wd = O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids2, denoise_strength=0.005, bias_spec=bias)
     for r, i in enumerate(order2):
         assert maxabs(wd[r], e[f'wave_dn{i}']) < 1e-5
+
+
+def test_vocos_22k(golden):
+    """MelVocos('22k') forward (+ denoising vector) of the reference vs the oracle."""
+    from ttsamd import synth
+    from ttsamd.config import VOCOS_22K_CONFIG
+    import hashlib, json, os
+    from conftest import GOLDEN
+    w = synth.vocos_state_dict()
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(k.encode()); h.update(np.ascontiguousarray(w[k]).tobytes())
+    with open(os.path.join(GOLDEN, 'digests.json')) as f:
+        assert h.hexdigest() == json.load(f)['vocos_seed0']
+    g = golden('vocos_22k')
+    bias = O.vocos_bias_vec(w, VOCOS_22K_CONFIG)
+    assert maxabs(bias, g['bias_vec']) < 1e-6
+    for T in (1, 5, 33):
+        assert maxabs(O.vocos_forward(w, g[f'mel_T{T}'], VOCOS_22K_CONFIG, bias_vec=bias), g[f'wave_T{T}']) < 1e-6
+        assert maxabs(O.vocos_forward(w, g[f'mel_T{T}'], VOCOS_22K_CONFIG, denoise=0.3, bias_vec=bias), g[f'wave_dn_T{T}']) < 1e-6

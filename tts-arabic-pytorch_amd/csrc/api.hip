@@ -52,6 +52,14 @@ void prof_end(hipStream_t s) {
 struct HifiGan;
 struct FastPitch;
 struct Denoiser;
+struct Vocos;
+int32_t vocos_create(const ttsamd_tensor*, int32_t, int32_t, int32_t, int32_t, int32_t, Vocos**);
+void vocos_destroy(Vocos*);
+int64_t vocos_workspace_bytes(const Vocos*, int32_t, int32_t);
+int64_t vocos_bias_workspace_bytes(const Vocos*);
+int32_t vocos_bias_vec(const Vocos*, float*, void*, int64_t, hipStream_t);
+int32_t vocos_forward(const Vocos*, const float*, const int64_t*, int32_t, int32_t, float, const float*, float*, void*,
+                      int64_t, hipStream_t);
 int32_t denoiser_create(Denoiser**);
 void denoiser_destroy(Denoiser*);
 int64_t denoiser_workspace_bytes(int32_t, int32_t);
@@ -189,6 +197,32 @@ int32_t ttsamd_denoise(void* handle, float* wave, int64_t wave_stride, const int
                        int64_t workspace_bytes, void* stream) {
     return denoise((Denoiser*)handle, wave, wave_stride, nsamples, batch, n_max, bias_spec, strength, workspace,
                    workspace_bytes, (hipStream_t)stream);
+}
+
+int32_t ttsamd_vocos_create(const ttsamd_tensor* weights, int32_t n, int32_t input_channels, int32_t dim,
+                            int32_t intermediate_dim, int32_t num_layers, void** handle) {
+    Vocos* h = nullptr;
+    const int32_t rc = vocos_create(weights, n, input_channels, dim, intermediate_dim, num_layers, &h);
+    if (rc == 0) *handle = h;
+    return rc;
+}
+int32_t ttsamd_vocos_destroy(void* handle) {
+    vocos_destroy((Vocos*)handle);
+    return 0;
+}
+int64_t ttsamd_vocos_workspace_bytes(void* handle, int32_t batch, int32_t t_max) {
+    if (!handle || batch < 1 || t_max < 1) return 0;
+    const int64_t a = vocos_workspace_bytes((Vocos*)handle, batch, t_max), b = vocos_bias_workspace_bytes((Vocos*)handle);
+    return a > b ? a : b;
+}
+int32_t ttsamd_vocos_bias_vec(void* handle, float* bias_vec, void* workspace, int64_t workspace_bytes, void* stream) {
+    return vocos_bias_vec((Vocos*)handle, bias_vec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int32_t ttsamd_vocos_forward(void* handle, const float* mel, const int64_t* lens, int32_t batch, int32_t t_max,
+                             float denoise, const float* bias_vec, float* wave, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    return vocos_forward((Vocos*)handle, mel, lens, batch, t_max, denoise, bias_vec, wave, workspace, workspace_bytes,
+                         (hipStream_t)stream);
 }
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {

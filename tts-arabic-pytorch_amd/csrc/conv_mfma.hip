@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
     const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs + phase : nullptr;
     const float* __restrict__ bias = p.bias;
+    const float* __restrict__ scale = p.scale;
     const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
     const int y_cs = p.y_cs, y_ts = p.y_ts, r_cs = p.r_cs;
     const float div = p.div;
@@ -289,13 +290,14 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
             const int qc = q_ok ? q : 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float bv[8], rv[8], pv[8];
+                float bv[8], rv[8], pv[8], sv[8];
 #pragma unroll
                 for (int r8 = 0; r8 < 8; ++r8) {
                     const int r = h * 8 + r8;
                     const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                     const int coc = min(co, Cout - 1);
                     bv[r8] = bias ? bias[coc] : 0.f;
+                    sv[r8] = scale ? scale[coc] : 1.f;
                     rv[r8] = rb ? rb[(int64_t)coc * r_cs + (int64_t)qc * y_ts] : 0.f;
                     pv[r8] = mode != 0 ? yb[(int64_t)coc * y_cs + (int64_t)qc * y_ts] : 0.f;
                 }
@@ -304,8 +306,9 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                     const int r = h * 8 + r8;
                     const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                     float v = acc[i][j][r] + bv[r8];
-                    v += rv[r8];
-                    if (relu_out) v = fmaxf(v, 0.f);
+                    if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU()
+                    v = v * sv[r8] + rv[r8];
+                    if (relu_out == 1) v = fmaxf(v, 0.f);
                     if (mode == 1) v = pv[r8] + v;
                     else if (mode == 2) v = (pv[r8] + v) / div;
                     if (q_ok && co < Cout) yb[(int64_t)co * y_cs + (int64_t)q * y_ts] = v;

@@ -20,33 +20,55 @@ struct Denoiser {
     int64_t w_fwd = 0, w_inv = 0, window = 0;
 };
 
+static const double kTwoPi = 6.283185307179586476925286766559;
+
+static void hann(std::vector<double>& win) {
+    win.resize(NFFT);
+    for (int k = 0; k < NFFT; ++k) win[k] = 0.5 - 0.5 * std::cos(kTwoPi * k / NFFT);   // periodic hann
+}
+
+// irfft(n=1024, onesided) * window as a 1x1 conv: torch-layout weight [Cout = 1024 (k)][Cin = SPEC_CP]
+void build_idft_packed(std::vector<float>& packed_inv, std::vector<float>& window) {
+    std::vector<double> win;
+    hann(win);
+    std::vector<float> wi((size_t)NFFT * SPEC_CP, 0.f);
+    for (int f = 0; f < NBIN; ++f) {
+        const double cf = (f == 0 || f == NFFT / 2) ? 1.0 : 2.0;
+        for (int k = 0; k < NFFT; ++k) {
+            const double ang = kTwoPi * (double)((int64_t)f * k % NFFT) / NFFT;
+            wi[(size_t)k * SPEC_CP + f] = (float)(cf * std::cos(ang) * win[k] / NFFT);
+            wi[(size_t)k * SPEC_CP + NBIN + f] = (float)(-cf * std::sin(ang) * win[k] / NFFT);
+        }
+    }
+    packed_inv.resize((size_t)SPEC_CP * NFFT);
+    pack_conv_weight(wi.data(), NFFT, SPEC_CP, 1, packed_inv.data());
+    window.resize(NFFT);
+    for (int k = 0; k < NFFT; ++k) window[k] = (float)win[k];
+}
+
 int32_t denoiser_create(Denoiser** out) {
     TTS_REQUIRE(out, "denoiser_create: null argument");
     auto* h = new Denoiser();
     std::vector<float> blob;
-    std::vector<double> win(NFFT);
-    const double two_pi = 6.283185307179586476925286766559;
-    for (int k = 0; k < NFFT; ++k) win[k] = 0.5 - 0.5 * std::cos(two_pi * k / NFFT);   // periodic hann
+    std::vector<double> win;
+    hann(win);
     // forward DFT as a 1x1 conv: torch-layout weight [Cout = SPEC_CP (re | im | zero pad)][Cin = 1024]
-    std::vector<float> wf((size_t)SPEC_CP * NFFT, 0.f), wi((size_t)NFFT * SPEC_CP, 0.f);
+    std::vector<float> wf((size_t)SPEC_CP * NFFT, 0.f);
     for (int f = 0; f < NBIN; ++f)
         for (int k = 0; k < NFFT; ++k) {
-            const double ang = two_pi * (double)((int64_t)f * k % NFFT) / NFFT;
+            const double ang = kTwoPi * (double)((int64_t)f * k % NFFT) / NFFT;
             wf[(size_t)f * NFFT + k] = (float)(win[k] * std::cos(ang));
             wf[(size_t)(NBIN + f) * NFFT + k] = (float)(-win[k] * std::sin(ang));
-            // inverse (irfft * window): [Cout = 1024 (k)][Cin = SPEC_CP]
-            const double cf = (f == 0 || f == NFFT / 2) ? 1.0 : 2.0;
-            wi[(size_t)k * SPEC_CP + f] = (float)(cf * std::cos(ang) * win[k] / NFFT);
-            wi[(size_t)k * SPEC_CP + NBIN + f] = (float)(-cf * std::sin(ang) * win[k] / NFFT);
         }
     h->w_fwd = 0;
     blob.resize((size_t)NFFT * SPEC_CP);
     pack_conv_weight(wf.data(), SPEC_CP, NFFT, 1, blob.data());
+    std::vector<float> inv, wnd;
+    build_idft_packed(inv, wnd);
     h->w_inv = (int64_t)blob.size();
-    blob.resize(blob.size() + (size_t)SPEC_CP * NFFT);
-    pack_conv_weight(wi.data(), NFFT, SPEC_CP, 1, blob.data() + h->w_inv);
+    blob.insert(blob.end(), inv.begin(), inv.end());
     h->window = (int64_t)blob.size();
-    for (int k = 0; k < NFFT; ++k) blob.push_back((float)win[k]);
+    blob.insert(blob.end(), wnd.begin(), wnd.end());
     hipError_t e = hipMalloc((void**)&h->dev, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -113,18 +135,21 @@ __global__ __launch_bounds__(256) void spec_gain_kernel(float* __restrict__ S, c
     sb[(int64_t)(NBIN + f) * F + t] = oim;
 }
 
-// out[b][m] = sum_t Y[b][m + 512 - t*HOP][t] / sum_t w^2[m + 512 - t*HOP]   for m < HOP*(frames-1)
+// out[b][m] = sum_t Y[b][m + pad - t*HOP][t] / sum_t w^2[m + pad - t*HOP],  m < HOP*frames - (1024 - 2*pad - HOP)...
+// frames_b = frames[b]*frames_mul + frames_add; torch.istft(center) : pad = 512, n_out = HOP*(frames-1);
+// Vocos 'same' (spectral_ops.py:47-75): pad = 384, n_out = HOP*frames.
 __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ Y, const float* __restrict__ win,
-                                                          const int64_t* __restrict__ ns, int F,
+                                                          const int64_t* __restrict__ frames, int frames_mul,
+                                                          int frames_add, int pad, int F,
                                                           float* __restrict__ wave, int64_t wave_bs) {
     const int b = blockIdx.y;
     const int m = blockIdx.x * 256 + threadIdx.x;
-    const int n = (int)ns[b];
-    const int fr = n / HOP + 1;
-    if (m >= HOP * (fr - 1)) return;
-    const int mp = m + NFFT / 2;
+    const int fr = (int)frames[b] * frames_mul + frames_add;
+    const int n_out = (fr - 1) * HOP + NFFT - 2 * pad;
+    if (m >= n_out) return;
+    const int mp = m + pad;
     const int t_hi = min(fr - 1, mp / HOP);
-    const int t_lo = max(0, (mp - NFFT) / HOP + 1);
+    const int t_lo = mp >= NFFT ? (mp - NFFT) / HOP + 1 : 0;   // first frame with mp - t*HOP < NFFT
     float acc = 0.f, env = 0.f;
     for (int t = t_lo; t <= t_hi; ++t) {
         const int k = mp - t * HOP;
@@ -133,6 +158,15 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
         env += win[k] * win[k];
     }
     wave[(int64_t)b * wave_bs + m] = acc / env;
+}
+
+int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* frames, int32_t frames_mul, int32_t frames_add,
+                           int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s) {
+    if (n_max <= 0 || B <= 0) return 0;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3((n_max + 255) / 256, B), dim3(256), 0, s, Y, win, frames, frames_mul,
+                       frames_add, pad, F, wave, wave_bs);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 // |STFT| of frame 0 (denoiser.py:60-64: bias_spec[:, :, 0])
@@ -220,10 +254,8 @@ int32_t denoise(const Denoiser* h, float* wave, int64_t wave_bs, const int64_t* 
     hipLaunchKernelGGL(spec_gain_kernel, dim3((F + 255) / 256, NBIN, B), dim3(256), 0, s, w.S, bias_spec, strength, F);
     TTS_CHECK_HIP(hipGetLastError());
     TTS_TRY(dft_gemm(h, true, w.S, w.X, w.frames, B, F, s));
-    hipLaunchKernelGGL(overlap_add_kernel, dim3((n_max + 255) / 256, B), dim3(256), 0, s, w.X, h->dev + h->window,
-                       nsamples, F, wave, wave_bs);
-    TTS_CHECK_HIP(hipGetLastError());
-    return 0;
+    // center=True: frames = n/HOP + 1 (w.frames), pad = NFFT/2, n_out = HOP*(frames-1)
+    return launch_overlap_add(w.X, h->dev + h->window, w.frames, 1, 0, NFFT / 2, B, F, n_max, wave, wave_bs, s);
 }
 
 }  // namespace ttsamd

@@ -60,6 +60,38 @@ int32_t launch_conv_post(const float* x, int64_t x_bs, int32_t x_cs, const float
 }
 
 // ------------------------------------------------------------------------------------
+// Depthwise Conv1d k=7, p=3 (vocoder/vocos/modules.py:31): HBM-bound, one thread per (c, t).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias,
+                                                      const int64_t* __restrict__ lens, int C, int S,
+                                                      float* __restrict__ y) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= S) return;
+    int n = S;
+    if (lens) n = min(n, (int)lens[b]);
+    const float* xr = x + ((int64_t)b * C + c) * S;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int pos = t + k - 3;
+        const float v = (pos >= 0 && pos < n) ? xr[pos] : 0.f;
+        acc = fmaf(w[c * 7 + k], v, acc);
+    }
+    y[((int64_t)b * C + c) * S + t] = acc + bias[c];
+}
+
+int32_t launch_dwconv7(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t B, int32_t C,
+                       int32_t S, float* y, hipStream_t s) {
+    if (S <= 0 || B <= 0) return 0;
+    dim3 grid((S + 255) / 256, C, B);
+    hipLaunchKernelGGL(dwconv7_kernel, grid, dim3(256), 0, s, x, w, bias, lens, C, S, y);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // LayerNorm over channels of a channel-first tensor.  Block = 64 time steps x 4 channel
 // groups; two-pass mean / variance (biased, eps 1e-5) like torch.nn.LayerNorm.
 // ------------------------------------------------------------------------------------
@@ -67,7 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const int64_t* __restrict__ lens, int apply_mask, int C,
-                                                           int S) {
+                                                           int S, float eps) {
     __shared__ float red[4][64];
     const int b = blockIdx.y;
     const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -93,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     red[g][tl] = sq;
     __syncthreads();
     const float var = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float rstd = 1.0f / sqrtf(var + eps);
     if (!ok) return;
     float m = 1.f;
     if (apply_mask && lens && t >= (int)lens[b]) m = 0.f;
@@ -104,10 +136,10 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
 }
 
 int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const float* beta, const int64_t* lens,
-                            int32_t apply_mask, int32_t B, int32_t C, int32_t S, hipStream_t s) {
+                            int32_t apply_mask, int32_t B, int32_t C, int32_t S, hipStream_t s, float eps) {
     if (S <= 0 || B <= 0) return 0;
     dim3 grid((S + 63) / 64, B);
-    hipLaunchKernelGGL(layernorm_cf_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S);
+    hipLaunchKernelGGL(layernorm_cf_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }

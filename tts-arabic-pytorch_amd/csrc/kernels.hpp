@@ -1,5 +1,7 @@
 // Launchers of the small (HBM-bound / latency-bound) kernels around the MFMA conv engine.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 
 namespace ttsamd {
@@ -15,7 +17,7 @@ int32_t launch_conv_post(const float* x, int64_t x_bs, int32_t x_cs, const float
 // (transformer.py:88,158,174,176; model.py:56).  eps = 1e-5 (torch default).
 int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const float* beta,
                             const int64_t* lens, int32_t apply_mask, int32_t B, int32_t C, int32_t S,
-                            hipStream_t s);
+                            hipStream_t s, float eps = 1e-5f);
 
 // Encoder input: x[b][c][t] = word_emb[ids[b][t]][c] + pos[t][c]*(ids!=pad) + spk[c]
 // (transformer.py:212-219; model.py:355-361).  Also writes lens[b] = #non-pad tokens.
@@ -48,6 +50,16 @@ int32_t launch_regulate_gather(const float* enc, const int64_t* reps, const floa
 // x[b][c][t] += pos[t][c] * (t < lens[b])
 int32_t launch_add_pos(float* x, const float* pos_table, int32_t pos_stride, const int64_t* lens, int32_t B, int32_t C,
                        int32_t S, hipStream_t s);
+
+// Depthwise Conv1d(C,C,k7,p3,groups=C) (vocoder/vocos/modules.py:31,45); input read as zero past lens[b]
+int32_t launch_dwconv7(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t B, int32_t C,
+                       int32_t S, float* y, hipStream_t s);
+
+// inverse-DFT (irfft * hann / N) weights in the conv engine's packed layout + the window; shared by the
+// denoiser and the Vocos ISTFT head
+void build_idft_packed(std::vector<float>& packed_inv, std::vector<float>& window);
+int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* frames, int32_t frames_mul, int32_t frames_add,
+                           int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s);
 
 // Profiling of conv launches (bench roofline)
 void prof_begin(hipStream_t s, double flops);

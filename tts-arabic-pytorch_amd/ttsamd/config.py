@@ -38,5 +38,11 @@ HIFIGAN_CONFIG = {
     'sampling_rate': 22050,
 }
 
+# vocoder/vocos/__init__.py:35-67 (config_22k): backbone + ISTFT head of MelVocos('22k')
+VOCOS_22K_CONFIG = {
+    'input_channels': 80, 'dim': 512, 'intermediate_dim': 1536, 'num_layers': 8,
+    'n_fft': 1024, 'hop_length': 256, 'padding': 'same',
+}
+
 SAMPLE_RATE = 22050
 HOP = 256

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .config import NET_CONFIG, HIFIGAN_CONFIG
+from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG
 
 
 def _require_gpu():
@@ -217,6 +217,59 @@ class DenoiserEngine:
             ws = self.ws.get(nb, self.device)
             L.check(self.lib.ttsamd_denoise(self.handle, _ptr(wave), n_max, _ptr(nsamples), B, n_max, _ptr(bias),
                                             float(strength), _ptr(ws), nb, _stream()), 'denoise')
+        return wave
+
+
+class VocosEngine:
+    """Handle over ttsamd_vocos_* (replaces vocoder.vocos.pretrained.MelVocos('22k'))."""
+
+    def __init__(self, state_dict, config=None, device='cuda'):
+        self.lib = _require_gpu()
+        self.device = torch.device(device if device != 'cuda' else 'cuda:0')
+        c = dict(VOCOS_22K_CONFIG if config is None else config)
+        assert c['n_fft'] == 1024 and c['hop_length'] == 256 and c['padding'] == 'same'
+        self.hop, self.n_mels = c['hop_length'], c['input_channels']
+        arr, keep = L.make_tensors(state_dict)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ttsamd_vocos_create(arr, len(arr), c['input_channels'], c['dim'], c['intermediate_dim'],
+                                                 c['num_layers'], C.byref(handle)), 'vocos_create')
+        self.handle = handle
+        self.ws = _Workspace()
+        self._bias = None
+
+    def __del__(self):
+        if getattr(self, 'handle', None):
+            self.lib.ttsamd_vocos_destroy(self.handle)
+            self.handle = None
+
+    def bias_vec(self):
+        if self._bias is None:
+            out = torch.empty(513, dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                nb = self.lib.ttsamd_vocos_workspace_bytes(self.handle, 1, 88)
+                ws = self.ws.get(nb, self.device)
+                L.check(self.lib.ttsamd_vocos_bias_vec(self.handle, _ptr(out), _ptr(ws), nb, _stream()), 'vocos_bias_vec')
+            self._bias = out.reshape(1, 513, 1)
+        return self._bias
+
+    def forward(self, mel, lens=None, denoise=0.0):
+        """mel [B,80,T] on the GPU, lens int64 [B] or None -> wave [B, 256*T] (zeros past 256*lens[b])."""
+        mel = _f32(mel, self.device)
+        B, M, T = mel.shape
+        assert M == self.n_mels
+        if lens is None:
+            lens = torch.full((B,), T, dtype=torch.int64, device=self.device)
+        lens = lens.to(device=self.device, dtype=torch.int64).contiguous()
+        wave = torch.zeros(B, self.hop * T, dtype=torch.float32, device=self.device)
+        if T == 0:
+            return wave
+        bias = self.bias_vec().reshape(-1) if denoise != 0 else None
+        with torch.cuda.device(self.device):
+            nb = self.lib.ttsamd_vocos_workspace_bytes(self.handle, B, T)
+            ws = self.ws.get(nb, self.device)
+            L.check(self.lib.ttsamd_vocos_forward(self.handle, _ptr(mel), _ptr(lens), B, T, float(denoise), _ptr(bias),
+                                                  _ptr(wave), _ptr(ws), nb, _stream()), 'vocos_forward')
         return wave
 
 

@@ -56,6 +56,11 @@ SYMBOLS = {
     'ttsamd_denoiser_workspace_bytes': (_I64, [_I32, _I32]),
     'ttsamd_denoiser_bias_spec': (_I32, [_P, _P, _P, _I32, _P, _P, _I64, _P]),
     'ttsamd_denoise': (_I32, [_P, _P, _I64, _P, _I32, _I32, _P, _F, _P, _I64, _P]),
+    'ttsamd_vocos_create': (_I32, [C.POINTER(Tensor), _I32, _I32, _I32, _I32, _I32, C.POINTER(_P)]),
+    'ttsamd_vocos_destroy': (_I32, [_P]),
+    'ttsamd_vocos_workspace_bytes': (_I64, [_P, _I32, _I32]),
+    'ttsamd_vocos_bias_vec': (_I32, [_P, _P, _P, _I64, _P]),
+    'ttsamd_vocos_forward': (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _P, _P, _I64, _P]),
     'ttsamd_conv1d_packed_floats': (_I64, [_I32, _I32, _I32]),
     'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     'ttsamd_profile_enable': (_I32, [_I32]),

@@ -13,7 +13,7 @@ import zlib
 
 import numpy as np
 
-from .config import NET_CONFIG, HIFIGAN_CONFIG
+from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG
 
 
 def _rng(seed, name):
@@ -135,6 +135,40 @@ def hifigan_state_dict(config=None, seed=0, weight_norm=True):
                 sd[f'resblocks.{r}.convs2.{m}.bias'] = _normal(seed, f'rb{r}.c2.{m}.b', (ch,), 0.05)
     put('conv_post', (1, ch, 7), ch * 7, 0.4)
     sd['conv_post.bias'] = _normal(seed, 'conv_post.b', (1,), 0.05)
+    return sd
+
+
+def vocos_state_dict(config=None, seed=0):
+    """MelVocos('22k') backbone + head (vocoder/vocos/pretrained.py:34-45; keys as its state_dict).
+    Scaled so that the log-magnitudes stay O(1) and the waveform is O(0.1)."""
+    c = dict(VOCOS_22K_CONFIG if config is None else config)
+    d, di, cin, nl = c['dim'], c['intermediate_dim'], c['input_channels'], c['num_layers']
+    sd = {}
+    sd['backbone.embed.weight'] = _normal(seed, 'vocos.embed.w', (d, cin, 7), 0.25 / np.sqrt(cin * 7))
+    sd['backbone.embed.bias'] = _normal(seed, 'vocos.embed.b', (d,), 0.1)
+    sd['backbone.norm.weight'] = 1.0 + _normal(seed, 'vocos.norm.w', (d,), 0.1)
+    sd['backbone.norm.bias'] = _normal(seed, 'vocos.norm.b', (d,), 0.1)
+    for i in range(nl):
+        p = f'backbone.convnext.{i}.'
+        sd[p + 'gamma'] = (0.5 + 0.1 * _rng(seed, p + 'gamma').standard_normal(d)).astype(np.float32)
+        sd[p + 'dwconv.weight'] = _normal(seed, p + 'dw.w', (d, 1, 7), 1.0 / np.sqrt(7))
+        sd[p + 'dwconv.bias'] = _normal(seed, p + 'dw.b', (d,), 0.1)
+        sd[p + 'norm.weight'] = 1.0 + _normal(seed, p + 'norm.w', (d,), 0.1)
+        sd[p + 'norm.bias'] = _normal(seed, p + 'norm.b', (d,), 0.1)
+        sd[p + 'pwconv1.weight'] = _normal(seed, p + 'pw1.w', (di, d), 1.2 / np.sqrt(d))
+        sd[p + 'pwconv1.bias'] = _normal(seed, p + 'pw1.b', (di,), 0.1)
+        sd[p + 'pwconv2.weight'] = _normal(seed, p + 'pw2.w', (d, di), 1.0 / np.sqrt(di))
+        sd[p + 'pwconv2.bias'] = _normal(seed, p + 'pw2.b', (d,), 0.1)
+    sd['backbone.final_layer_norm.weight'] = 1.0 + _normal(seed, 'vocos.fln.w', (d,), 0.1)
+    sd['backbone.final_layer_norm.bias'] = _normal(seed, 'vocos.fln.b', (d,), 0.1)
+    nout = c['n_fft'] + 2
+    w = _normal(seed, 'vocos.head.w', (nout, d), 1.0 / np.sqrt(d))
+    w[:nout // 2] *= 0.6                                   # log-magnitude rows
+    w[nout // 2:] *= 2.0                                   # phase rows
+    sd['head.out.weight'] = w
+    b = _normal(seed, 'vocos.head.b', (nout,), 0.3)
+    b[:nout // 2] -= 0.3
+    sd['head.out.bias'] = b
     return sd
 
 
