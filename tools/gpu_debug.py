@@ -1,6 +1,6 @@
 """Manual GPU bring-up script (not a test): prints per-stage errors."""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (tools/..)
 sys.path[:0] = [os.path.join(REPO, 'tts-arabic-pytorch_amd'), os.path.join(REPO, 'oracle')]
 import numpy as np, torch
 import tts_oracle as O

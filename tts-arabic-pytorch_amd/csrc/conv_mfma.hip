@@ -336,31 +336,27 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     return 0;
 }
 
+// Tile choice: the largest tile that still gives the chip >= 3 blocks per CU (768); small
+// problems (batch 1, encoder-side S = 64) fall back to smaller tiles to fill the 256 CUs.
 template <int K>
 static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
-    const bool is_long = p.Nout > 96;
-    if (p.CoutP % 128 == 0 && (K < 11 || !is_long)) {
-#ifdef TTS_BIGTILE
-        if (is_long) return launch_cfg<K, 2, 4, 2, 2>(p, stream);   // 128 co x 256 t
-#else
-        if (is_long) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
-#endif
-        return launch_cfg<K, 1, 2, 4, 1>(p, stream);                // 128 co x  64 t
+    auto blocks = [&](int co_blk, int nt_blk) -> int64_t {
+        return (int64_t)((p.Nout + nt_blk - 1) / nt_blk) * (p.CoutP / co_blk) * p.n_phase * p.batch;
+    };
+    const int64_t want = 768;
+    const bool tiny = p.Nout <= 96;
+    if (p.CoutP % 128 == 0) {
+        if (K < 11 && !tiny && blocks(128, 128) >= want) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
+        if (K == 11 && !tiny && blocks(64, 256) >= want) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
+        if (blocks(128, 64) >= want || (tiny && blocks(64, 64) < 2 * want)) return launch_cfg<K, 1, 2, 4, 1>(p, stream);   // 128 co x 64 t
+        return launch_cfg<K, 1, 1, 2, 2>(p, stream);                                                    //  64 co x  64 t
     }
     if (p.CoutP % 64 == 0) {
-#ifdef TTS_BIGTILE
-        if (is_long) return launch_cfg<K, 2, 4, 1, 4>(p, stream);   //  64 co x 512 t
-#else
-        if (is_long) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
-#endif
-        return launch_cfg<K, 1, 1, 2, 2>(p, stream);                //  64 co x  64 t
+        if (!tiny && blocks(64, 256) >= want) return launch_cfg<K, 2, 2, 1, 4>(p, stream);              //  64 co x 256 t
+        return launch_cfg<K, 1, 1, 2, 2>(p, stream);                                                    //  64 co x  64 t
     }
-#ifdef TTS_BIGTILE
-    if (is_long) return launch_cfg<K, 1, 4, 1, 4>(p, stream);       //  32 co x 512 t
-#else
-    if (is_long) return launch_cfg<K, 1, 2, 1, 4>(p, stream);       //  32 co x 256 t
-#endif
-    return launch_cfg<K, 1, 1, 1, 4>(p, stream);                    //  32 co x 128 t
+    if (!tiny && blocks(32, 256) >= want) return launch_cfg<K, 1, 2, 1, 4>(p, stream);                  //  32 co x 256 t
+    return launch_cfg<K, 1, 1, 1, 4>(p, stream);                                                        //  32 co x 128 t
 }
 
 int32_t launch_conv(const ConvParams& p, hipStream_t stream) {

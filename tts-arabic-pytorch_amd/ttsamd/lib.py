@@ -79,6 +79,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise TtsAmdError(f'{LIB_PATH} is missing: build it with `make -C tts-arabic-pytorch_amd/csrc` '
                           '(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback')
+    # torch bundles its own libamdhip64.so.7; it must be the first HIP runtime in the process
+    # (two runtimes = "No HIP GPUs are available"), so pull it in before dlopen-ing ours, which then
+    # binds to the already-loaded SONAME.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
