@@ -67,6 +67,9 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--tokens', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16x3'],
+                    help='MFMA operand precision of the conv/linear GEMMs (f32 = BASELINE config 2; bf16 = config 3; '
+                         'bf16x3 = split bf16, fp32-class accuracy)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -80,7 +83,7 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     from ttsamd import synth, lib as L
-    from ttsamd.engine import FastPitchEngine, HifiGanEngine
+    from ttsamd.engine import FastPitchEngine, HifiGanEngine, set_precision
     import torch.distributed as dist
 
     if world > 1:
@@ -94,6 +97,7 @@ def main():
     else:
         fp_sd, hg_sd = synth.fastpitch_state_dict(), synth.hifigan_state_dict()
 
+    set_precision(args.precision)
     fp = FastPitchEngine(fp_sd, device=dev)
     hg = HifiGanEngine(hg_sd, device=dev)
     B, Lt = args.batch, args.tokens
@@ -153,13 +157,16 @@ def main():
         dec_fpt, enc_fpt = fastpitch_conv_flops_per_pos(NC)
         flops = args.steps * (hg_fpf * frames + dec_fpt * B * t_max + enc_fpt * B * Lt)
         achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # peak of the MFMA instruction actually issued: fp32 157.3; bf16 2500 dense; split bf16 issues
+        # 3 bf16 MFMAs per algorithmic product -> 2500/3 algorithmic TFLOP/s
+        peak = {'f32': PEAK_F32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16x3': 2500.0 / 3}[args.precision]
         # HBM bytes per conv launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
         # this same command (profiles/r1/traffic.json; collected offline, gpurun forbids mixing PMC with
         # the timed run); algorithmic bytes = read x + read residual/previous sum + write y.
         traffic = None
         try:
             with open(os.path.join(REPO, 'profiles', 'r1', 'traffic.json')) as f:
-                traffic = json.load(f)['bytes_per_conv_launch_corrected'] if B == 32 and Lt == 64 else None
+                traffic = json.load(f)['bytes_per_conv_launch_corrected'] if (B == 32 and Lt == 64 and args.precision == 'f32') else None
         except OSError:
             pass
         out = {
@@ -167,14 +174,14 @@ def main():
             'value': samples / elapsed, 'unit': 'audio samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (ids, forced durations, random-init weights)',
+            'vs_baseline': None, 'dtype': {'f32': 'f32', 'bf16': 'bf16', 'bf16x3': 'f32 via split-bf16 (3x bf16 MFMA, fp32 accumulate)'}[args.precision], 'data': 'synthetic (ids, forced durations, random-init weights)',
             'rtf': elapsed / (samples / SAMPLE_RATE),
             'config': {'workload': f'FastPitch+HiFi-GAN, synthetic {Lt}-phoneme x batch{B} per GPU, fp32, '
                                    f'{world}xMI355X', 'batch_per_gpu': B, 'n_tokens': Lt,
                        'frames_per_step_rank0': frames, 'parallelism': f'dp{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv1d_mfma_f32 (all instantiations)',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'B/launch',
+            'roofline': {'bound': 'mfma', 'kernel': ('conv1d_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'B/launch',
                          'launches': int(n_launch), 'avg_launch_ms': conv_ms / max(1.0, n_launch),
                          'kernel_ms_per_step': conv_ms / args.steps},
         }

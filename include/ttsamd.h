@@ -177,6 +177,14 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
                       int32_t lin, float in_slope, int32_t relu_out, float* y, float* packed,
                       void* stream);
 
+/* MFMA operand precision of every conv/linear GEMM launched by the model forwards (process-wide):
+ *   0 (default) exact fp32 (v_mfma_f32_32x32x2_f32) — BASELINE config 2;
+ *   1 bf16 operands, fp32 accumulate (v_mfma_f32_32x32x8_bf16_1k) — config 3;
+ *   2 split bf16 (x = hi + lo, 3 MFMAs per product): fp32-class accuracy at bf16 MFMA rate.
+ * Activations, LayerNorm, softmax, tanh, the DFTs and all integer work stay fp32/int64. */
+int32_t ttsamd_set_precision(int32_t precision);
+int32_t ttsamd_get_precision(void);
+
 /* Timing hooks for bench.py (roofline of the dominant kernel): when enabled, hifigan
  * forward brackets its ResBlock conv launches with HIP events on the launch stream. */
 int32_t ttsamd_profile_enable(int32_t on);

@@ -318,3 +318,46 @@ def test_denoiser_strong_setting(dev, golden, hifigan_engine):
     out = eng.denoise(wave.to(dev).clone().contiguous(), torch.tensor([wave.shape[1]]).to(dev), bias, 1.0).cpu()
     assert float((ref - wave).abs().max()) > 1e-2          # the setting really changes the signal
     assert maxabs(out[:, :ref.shape[1]], ref) < WAVE_TOL
+
+
+# ---------------------------------------------------------------------------------------
+# bf16 MFMA modes (BASELINE config 3): stated tolerances, measured against the fp32 oracle
+# ---------------------------------------------------------------------------------------
+BF16_MEL_TOL, BF16_WAVE_TOL = 6e-2, 4e-2        # plain bf16 operands (8-bit mantissa) through ~75 convs
+X3_MEL_TOL, X3_WAVE_TOL = 1e-3, 1e-4            # split bf16 keeps the fp32 north-star tolerances
+
+
+@pytest.fixture
+def precision():
+    from ttsamd.engine import set_precision
+    yield set_precision
+    set_precision('f32')
+
+
+@pytest.mark.parametrize('mode,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
+def test_conv1d_kernel_bf16_modes(dev, precision, mode, tol):
+    from ttsamd.engine import conv1d
+    precision(mode)
+    g = torch.Generator().manual_seed(5)
+    for (cin, cout, k, dil, lin) in [(128, 128, 11, 5, 515), (32, 32, 3, 1, 300), (384, 1536, 3, 1, 64), (80, 512, 7, 1, 40)]:
+        x = torch.randn(2, cin, lin, generator=g)
+        w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+        b = torch.randn(cout, generator=g)
+        y = conv1d(x.to(dev), w.to(dev), b.to(dev), dilation=dil, in_slope=0.1).cpu()
+        ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x.double(), 0.1), w.double(), b.double(),
+                                         dilation=dil, padding=(k * dil - dil) // 2)
+        assert maxabs(y, ref) < tol, (mode, cin, cout, k)
+
+
+@pytest.mark.parametrize('mode,mel_tol,wave_tol', [('bf16x3', X3_MEL_TOL, X3_WAVE_TOL), ('bf16', BF16_MEL_TOL, BF16_WAVE_TOL)])
+def test_end_to_end_bf16_modes(dev, golden, precision, fastpitch_engine, hifigan_engine, mode, mel_tol, wave_tol):
+    precision(mode)
+    g = golden('fastpitch_b3_durtgt')
+    mel, dec_lens, *_ = fastpitch_engine.infer(g['ids'], dur_tgt=g['dur_tgt'])
+    assert np.array_equal(dec_lens.cpu().numpy(), g['dec_lens'])
+    err_mel = maxabs(mel, g['mel'])
+    h = golden('hifigan_T40')
+    wave = hifigan_engine.forward(torch.from_numpy(h['mel'])[None].to(dev))
+    err_wave = maxabs(wave[0], h['wave'][0])
+    print(f'{mode}: mel max-abs {err_mel:.2e}, wave max-abs {err_wave:.2e}')
+    assert err_mel < mel_tol and err_wave < wave_tol

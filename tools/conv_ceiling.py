@@ -3,7 +3,9 @@ import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'tts-arabic-pytorch_amd'))
 import torch
-from ttsamd.engine import conv1d
+from ttsamd.engine import conv1d, set_precision
+import sys as _s
+set_precision(_s.argv[1] if len(_s.argv) > 1 else 'f32')
 dev = torch.device('cuda:0')
 for (B, cin, cout, k, dil, L) in [(8, 1024, 128, 3, 1, 28672), (8, 1024, 128, 11, 5, 28672), (8, 2048, 64, 3, 1, 28672),
                                   (32, 128, 128, 3, 1, 28672), (32, 128, 128, 11, 5, 28672), (32, 32, 32, 3, 1, 114688),

@@ -19,6 +19,9 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
+static int g_precision = 0;
+int32_t default_precision() { return g_precision; }
+
 // ---- launch timing (HIP events on the launch stream) -------------------------------
 struct Prof {
     std::mutex mu;
@@ -93,6 +96,20 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int cout, i
     const int t = (int)((i / (8 * (int64_t)cp)) % k);
     const int o = (int)(i / (8 * (int64_t)cp * k));
     out[i] = co < cout ? w[((int64_t)co * cin + (8 * o + 2 * pq + kk)) * k + t] : 0.f;
+}
+
+__global__ void split_bf16_kernel(const float* __restrict__ packed, int64_t n, unsigned short* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float f = packed[i];
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    const unsigned h = u >> 16;
+    const float r = f - __uint_as_float(h << 16);
+    unsigned v = __float_as_uint(r);
+    v += 0x7fffu + ((v >> 16) & 1u);
+    out[i] = (unsigned short)h;
+    out[n + i] = (unsigned short)(v >> 16);
 }
 
 }  // namespace ttsamd
@@ -226,7 +243,7 @@ int32_t ttsamd_vocos_forward(void* handle, const float* mel, const int64_t* lens
 }
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {
-    return (int64_t)cin * k * cout_padded(cout);
+    return 2 * (int64_t)cin * k * cout_padded(cout);   // fp32 packed + bf16 hi/lo planes
 }
 
 int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t batch,
@@ -243,6 +260,13 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.x_bs = (int64_t)cin * lin; p.x_cs = lin;
     p.w = packed; p.bias = bias;
+    p.precision = default_precision();
+    if (p.precision != 0) {
+        unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, packed, n, planes);
+        TTS_CHECK_HIP(hipGetLastError());
+        p.w_bf16 = planes;
+    }
     p.y = y; p.y_bs = (int64_t)cout * lin; p.y_cs = lin; p.y_ts = 1;
     p.lens_in = lens; p.lens_out = lens; p.len_in_mul = 1; p.len_out_mul = 1;
     p.Lin = lin; p.Nout = lin; p.Cin = cin; p.Cout = cout; p.CoutP = cp; p.K = k;
@@ -253,6 +277,13 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
     prof_end(s);
     return rc;
 }
+
+int32_t ttsamd_set_precision(int32_t precision) {
+    TTS_REQUIRE(precision >= 0 && precision <= 2, "set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA, 2 = split-bf16 MFMA");
+    g_precision = precision;
+    return 0;
+}
+int32_t ttsamd_get_precision(void) { return g_precision; }
 
 int32_t ttsamd_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);

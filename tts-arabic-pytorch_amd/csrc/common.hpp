@@ -60,7 +60,9 @@ struct ConvParams {
     const float* x;      // [B][Cin][*], element (b,c,t) at x + b*x_bs + c*x_cs + t
     int64_t x_bs;
     int32_t x_cs;
-    const float* w;      // packed [n_phase][Cin][K][CoutP]
+    const float* w;      // packed fp32 weights [n_phase][Cin/8][K][2][CoutP][4]
+    const void* w_bf16;  // same element order as bf16: plane hi then plane lo (nullptr if not packed)
+    int32_t precision;   // 0 fp32 MFMA, 1 bf16 MFMA, 2 split bf16 (3 MFMAs per product)
     const float* bias;   // [>=Cout] or nullptr
     float* y;            // (b,co,q) at y + b*y_bs + co*y_cs + q*y_ts + phase
     int64_t y_bs;
@@ -91,5 +93,8 @@ void pack_conv_weight(const float* w, int cout, int cin, int k, float* out);
 // torch ConvTranspose1d [Cin][Cout][Kt] (Kt = 2u, stride u, padding p) -> [u][Cin][2][CoutP]
 void pack_convt_weight(const float* w, int cin, int cout, int kt, int u, int p, float* out);
 inline int cout_padded(int cout) { return (int)align_up(cout, 32); }
+void split_packed_bf16(const float* packed, int64_t n, uint16_t* out);
+// process-wide default MFMA precision of the model forwards (ttsamd_set_precision)
+int32_t default_precision();
 
 }  // namespace ttsamd

@@ -30,23 +30,14 @@
 //    the LDS write; bias / residual / ReLU / ResBlock sum and /3 are fused in the epilogue.
 // Ragged batches: positions >= lens_in[b] read as zero at the INPUT of every layer
 // (SURVEY.md §3.4-5), tiles past lens_out[b] exit early.
-#include "common.hpp"
+#include <cstring>
+
+#include "conv_mfma_common.hpp"
 
 namespace ttsamd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int DMAX = 5;  // largest |dilation| the LDS row is sized for
-
-#ifndef TTS_MINWAVES
-#define TTS_MINWAVES 2
-#endif
-
 // octets (8 input channels) staged per chunk
-#ifndef TTS_NOCT3
-#define TTS_NOCT3 1
-#endif
-template <int K> struct OctsOf { static constexpr int NOCT = K == 1 ? 4 : (K == 2 ? 2 : (K == 3 ? TTS_NOCT3 : 1)); };
+
 
 template <int K, int NT_BLK, int CO_BLK>
 struct Geo {
@@ -364,6 +355,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.n_phase >= 1 && p.batch >= 1, "conv: bad n_phase/batch");
     TTS_REQUIRE(p.dil >= -DMAX && p.dil <= DMAX && p.dil != 0, "conv: dilation %d outside [-%d,%d]", p.dil, DMAX, DMAX);
     if (p.Nout <= 0) return 0;
+    if (p.precision != 0) return launch_conv_bf16_any(p, stream);
     switch (p.K) {
         case 1: return launch_k<1>(p, stream);
         case 2: return launch_k<2>(p, stream);
@@ -388,6 +380,29 @@ void pack_conv_weight(const float* w, int cout, int cin, int k, float* out) {
                     for (int pq = 0; pq < 4; ++pq)
                         dst[co * 4 + pq] = co < cout ? w[((int64_t)co * cin + (8 * o + 2 * pq + kk)) * k + t] : 0.f;
             }
+}
+
+static inline uint16_t host_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float host_bf16_to_f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// fp32 packed weights (any number of phases) -> two bf16 planes in the same element order:
+// out[0 .. n) = hi = bf16(w), out[n .. 2n) = lo = bf16(w - hi)
+void split_packed_bf16(const float* packed, int64_t n, uint16_t* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t h = host_bf16_rne(packed[i]);
+        out[i] = h;
+        out[n + i] = host_bf16_rne(packed[i] - host_bf16_to_f(h));
+    }
 }
 
 // ConvTranspose1d(stride u, kernel Kt = 2u, padding p): y[co][q*u+rho] =

@@ -1,0 +1,370 @@
+// bf16 / split-bf16 MFMA variants of the implicit-GEMM conv engine.  See conv_mfma.hip for the
+// structure; this file is derived from it (same tiling, LDS ring, gap interleave).
+#include "conv_mfma_common.hpp"
+
+namespace ttsamd {
+
+// ======================================================================================
+// bf16 MFMA variants of the same kernel (config 3: bf16 operands, fp32 accumulate; and the
+// split-bf16 "3x" mode that keeps fp32-class accuracy).  Identical tiling, staging ring and
+// gap interleave; an LDS entry is 4 bf16 (the same 4 channel pairs) and ONE
+// v_mfma_f32_32x32x8_bf16_1k consumes it, so a whole octet x tap costs MT*NTL MFMAs of 8
+// passes instead of 4*MT*NTL fp32 MFMAs of 16 passes.  Activations stay fp32 in HBM and are
+// rounded to bf16 (RNE) on the LDS write; weights are pre-split/packed at create().
+// ======================================================================================
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <int K, int NT_BLK, int CO_BLK, int NPL>
+struct GeoB {
+    static constexpr int NOCT = OctsOf<K>::NOCT;
+    static constexpr int KC = 8 * NOCT;
+    static constexpr int WS = NT_BLK + (K - 1) * DMAX;
+    static constexpr int XI = 2 * NOCT * WS;                  // X entries (uint2) per plane per stage
+    static constexpr int NXI = (XI + 255) / 256;
+    static constexpr int W4 = NOCT * K * 2 * CO_BLK;          // W entries (uint2) per plane per stage
+    static constexpr int NW = (W4 + 255) / 256;
+    static constexpr int BUF4 = NPL * (XI + W4);              // uint2 per stage
+    static constexpr int NSTAGE = (3 * BUF4 * 8 <= 80 * 1024) ? 3 : 2;
+    static constexpr int NGRP = NOCT * K;
+};
+
+template <int K, int MT, int NTL, int WM, int WN, int NPL>
+__global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const ConvParams p) {
+    // NPL = 1: plain bf16 operands; NPL = 2: split bf16 (hi + lo planes, 3 MFMAs per product)
+    extern __shared__ __attribute__((aligned(16))) uint2 smem4[];
+    constexpr int CO_BLK = WM * MT * 32;
+    constexpr int NT_BLK = WN * NTL * 32;
+    using G = GeoB<K, NT_BLK, CO_BLK, NPL>;
+    constexpr int KC = G::KC, WS = G::WS, NXI = G::NXI, NW = G::NW, NGRP = G::NGRP, NSTAGE = G::NSTAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z;
+    const int n_co_tiles = p.CoutP / CO_BLK;
+    const int phase = blockIdx.y / n_co_tiles;
+    const int co_blk0 = (blockIdx.y % n_co_tiles) * CO_BLK;
+    const int q0 = blockIdx.x * NT_BLK;
+
+    int n_out = p.Nout;
+    if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
+    if (q0 >= n_out) return;
+    int in_len = p.Lin;
+    if (p.lens_in) in_len = min(in_len, (int)p.lens_in[b] * p.len_in_mul);
+
+    const int dil = p.dil;
+    int pad = p.pad;
+    if (p.n_phase > 1) pad = -((phase + p.phase_p) / p.n_phase);
+    const int span = (K - 1) * (dil < 0 ? -dil : dil);
+    const int lo = (dil < 0 ? (K - 1) * dil : 0) - pad;  // first input position relative to q0
+    const int W = NT_BLK + span;                          // staged columns actually used (<= WS)
+
+    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+    // packed bf16 weights: [plane][phase][octet][tap][kk][CoutP][4 bf16]
+    const int64_t plane_stride = (int64_t)p.n_phase * (p.Cin / 8) * K * 2 * p.CoutP;     // in uint2
+    const uint2* __restrict__ wp4 =
+        reinterpret_cast<const uint2*>(p.w_bf16) + (int64_t)phase * (p.Cin / 8) * K * 2 * p.CoutP + co_blk0;
+    const float in_slope = p.in_slope;
+    const int n_chunks = p.Cin / KC;
+    const int x_cs = p.x_cs, CoutP = p.CoutP;
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int qw0 = wn * NTL * 32;
+    const bool wave_active = (q0 + qw0) < n_out;   // wave-uniform
+    const int kk = lane >> 5, l31 = lane & 31;
+
+    // ---- staging registers.  X item it = (oc, kk, col): the 4 channels 8*oc + 2p + kk, p = 0..3,
+    // at one input position -> one float4; W is a linear float4 copy.  Loads are unconditional
+    // (clamped address + select) so they issue back to back and are waited for only where the
+    // chunk is written to LDS.
+    float sx[4 * NXI];
+    unsigned sw[2 * NPL * NW];
+    bool st_ok[NXI], st_in[NXI];
+    int st_off[NXI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+        const int it = tid + 256 * i;
+        const int ockk = min(it / WS, 2 * G::NOCT - 1), col = it % WS;
+        const int pos = q0 + lo + col;
+        st_in[i] = it < G::XI;
+        st_ok[i] = st_in[i] && (col < W) && (pos >= 0) && (pos < in_len);
+        st_off[i] = ((ockk >> 1) * 8 + (ockk & 1)) * x_cs + min(max(pos, 0), max(in_len - 1, 0));
+    }
+
+    // One staging "job" = one memory instruction (+ its VALU).  Jobs are spread one by one
+    // over the gaps between MFMAs (an MFMA occupies the matrix pipe for 64 cycles, during
+    // which the wave can issue ~50 cycles of other work for free); every gap is pinned with
+    // sched_barrier(0).  Load jobs of chunk c+NSTAGE-1 go into the first NGRP-1 operand
+    // groups of chunk c, write jobs into its last group.
+    constexpr int NLJ = 4 * NXI + NPL * NW;    // load jobs per chunk
+    constexpr int NWJ = NXI + NPL * NW;        // write jobs per chunk
+    constexpr int NM = (NPL == 2 ? 3 : 1) * MT * NTL;   // MFMAs per operand group
+    constexpr int NF = NPL * (MT + NTL);       // ds_read_b64 per operand fetch
+    constexpr int NFU = NF < NM ? NF : NM;     // fetch parts are spread over the first gaps
+    constexpr int GL = (NGRP - 1) * NM;        // gaps carrying load jobs
+    static_assert(NGRP >= 2, "operand group layout");
+#define TTS_LOAD_JOB(J)                                                                              \
+    {                                                                                                \
+        if ((J) < 4 * NXI) {                                                                         \
+            sx[(J)] = xc[st_off[(J) / 4] + 2 * ((J) % 4) * x_cs];                                    \
+        } else {                                                                                     \
+            const int i_ = ((J)-4 * NXI) % NW, pl_ = ((J)-4 * NXI) / NW;                             \
+            const int e = min(tid + 256 * i_, G::W4 - 1);                                            \
+            const uint2 t2 = wc[pl_ * plane_stride + (int64_t)(e / CO_BLK) * CoutP + (e % CO_BLK)];  \
+            sw[2 * (pl_ * NW + i_)] = t2.x; sw[2 * (pl_ * NW + i_) + 1] = t2.y;                      \
+        }                                                                                            \
+    }
+#define TTS_LRELU(v) ((v) > 0.f ? (v) : (v)*in_slope)
+#define TTS_WRITE_JOB(J, SB)                                                                         \
+    {                                                                                                \
+        if ((J) < NXI) {                                                                             \
+            const int i_ = (J);                                                                      \
+            if (st_in[i_]) {                                                                         \
+                float v0 = sx[4 * i_], v1 = sx[4 * i_ + 1], v2 = sx[4 * i_ + 2], v3 = sx[4 * i_ + 3]; \
+                v0 = st_ok[i_] ? TTS_LRELU(v0) : 0.f; v1 = st_ok[i_] ? TTS_LRELU(v1) : 0.f;           \
+                v2 = st_ok[i_] ? TTS_LRELU(v2) : 0.f; v3 = st_ok[i_] ? TTS_LRELU(v3) : 0.f;           \
+                const unsigned h0 = bf16_rne(v0), h1 = bf16_rne(v1), h2 = bf16_rne(v2), h3 = bf16_rne(v3); \
+                (SB)[tid + 256 * i_] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));                 \
+                if (NPL == 2) {                                                                      \
+                    const unsigned l0 = bf16_rne(v0 - __uint_as_float(h0 << 16)), l1 = bf16_rne(v1 - __uint_as_float(h1 << 16)), \
+                                   l2 = bf16_rne(v2 - __uint_as_float(h2 << 16)), l3 = bf16_rne(v3 - __uint_as_float(h3 << 16)); \
+                    (SB)[G::XI + tid + 256 * i_] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));     \
+                }                                                                                    \
+            }                                                                                        \
+        } else {                                                                                     \
+            const int i_ = ((J)-NXI) % NW, pl_ = ((J)-NXI) / NW;                                     \
+            const int e = tid + 256 * i_;                                                            \
+            if (e < G::W4)                                                                           \
+                (SB)[NPL * G::XI + pl_ * G::W4 + e] = make_uint2(sw[2 * (pl_ * NW + i_)], sw[2 * (pl_ * NW + i_) + 1]); \
+        }                                                                                            \
+    }
+    // part PART (< NF) of the operand fetch of group GRP of stage STG into register slot SLOT
+#define TTS_FETCH_PART(SLOT, STG, GRP, PART)                                                         \
+    {                                                                                                \
+        const int pl_ = (PART) / (MT + NTL), q_ = (PART) % (MT + NTL);                               \
+        if (q_ < MT) {                                                                               \
+            const uint2 t2 = sA[(STG)*G::BUF4 + pl_ * G::W4 + (GRP)*2 * CO_BLK + q_ * 32];           \
+            a[SLOT][pl_][q_][0] = t2.x; a[SLOT][pl_][q_][1] = t2.y;                                  \
+        } else {                                                                                     \
+            const int j_ = q_ - MT;                                                                  \
+            const uint2 t2 = sB[(STG)*G::BUF4 + pl_ * G::XI + ((GRP) / K) * 2 * WS + ((GRP) % K) * dil + j_ * 32]; \
+            bq[SLOT][pl_][j_][0] = t2.x; bq[SLOT][pl_][j_][1] = t2.y;                                \
+        }                                                                                            \
+    }
+
+    const uint2* sB = smem4 + kk * WS + (qw0 + l31 - pad - lo);
+    const uint2* sA = smem4 + NPL * G::XI + kk * CO_BLK + wm * MT * 32 + l31;
+    unsigned a[2][NPL][MT][2], bq[2][NPL][NTL][2];
+
+    // prologue: fill NSTAGE-1 stages (bulk), fetch the first operands
+    for (int c0 = 0; c0 < NSTAGE - 1 && c0 < n_chunks; ++c0) {
+        const float* __restrict__ xc = xb + (int64_t)c0 * KC * x_cs;
+        const uint2* __restrict__ wc = wp4 + (int64_t)c0 * G::NOCT * K * 2 * CoutP;
+        uint2* sbp = smem4 + c0 * G::BUF4;
+#pragma unroll
+        for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
+#pragma unroll
+        for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, sbp)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int P = 0; P < NF; ++P) TTS_FETCH_PART(0, 0, 0, P)
+
+    int stage = 0;  // c % NSTAGE
+    for (int c = 0; c < n_chunks; ++c) {
+        // chunk to stage during this chunk (clamped: at the tail the last chunk is re-staged
+        // into a dead stage, which keeps the loop body branch-free)
+        const int cl = min(c + NSTAGE - 1, n_chunks - 1);
+        const float* __restrict__ xc = xb + (int64_t)cl * KC * x_cs;
+        const uint2* __restrict__ wc = wp4 + (int64_t)cl * G::NOCT * K * 2 * CoutP;
+        const int stage_next = (stage + 1 == NSTAGE) ? 0 : stage + 1;           // chunk c+1
+        const int stage_fill = (stage == 0) ? NSTAGE - 1 : stage - 1;           // chunk c+NSTAGE-1
+        uint2* sbf = smem4 + stage_fill * G::BUF4;
+        const int sn = (c + 1 < n_chunks) ? stage_next : stage;
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int term = m / (MT * NTL), i = (m / NTL) % MT, j = m % NTL;
+                // split bf16: hi*hi + hi*lo + lo*hi (the lo*lo term is below fp32 resolution)
+                const int pa = term == 2 ? 1 : 0, pb = term == 1 ? 1 : 0;
+                {
+                    bf16x4 av, bv;
+                    av[0] = (short)(a[cur][pa][i][0] & 0xffff); av[1] = (short)(a[cur][pa][i][0] >> 16);
+                    av[2] = (short)(a[cur][pa][i][1] & 0xffff); av[3] = (short)(a[cur][pa][i][1] >> 16);
+                    bv[0] = (short)(bq[cur][pb][j][0] & 0xffff); bv[1] = (short)(bq[cur][pb][j][0] >> 16);
+                    bv[2] = (short)(bq[cur][pb][j][1] & 0xffff); bv[3] = (short)(bq[cur][pb][j][1] >> 16);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(av, bv, acc[i][j], 0, 0, 0);
+                }
+                // ---- gap work ----
+#pragma unroll
+                for (int P = 0; P < NF; ++P)
+                    if (P >= m * NF / NM && P < (m + 1) * NF / NM) {
+                        if (g + 1 < NGRP) TTS_FETCH_PART(nxt, stage, g + 1, P)
+                        else if (NSTAGE == 3) TTS_FETCH_PART(nxt, sn, 0, P)
+                    }
+#if !defined(TTS_EXP_NOLOAD)
+                if (g + 1 < NGRP) {
+
+                    const int t = g * NM + m;
+#pragma unroll
+                    for (int J = 0; J < NLJ; ++J)
+                        if (J >= t * NLJ / GL && J < (t + 1) * NLJ / GL) TTS_LOAD_JOB(J)
+                }
+#endif
+#if !defined(TTS_EXP_NOWRITE)
+                if (g + 1 == NGRP) {
+#pragma unroll
+                    for (int J = 0; J < NWJ; ++J)
+                        if (J >= m * NWJ / NM && J < (m + 1) * NWJ / NM) TTS_WRITE_JOB(J, sbf)
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#ifndef TTS_EXP_NOBARRIER
+        __syncthreads();
+#endif
+        if (NSTAGE == 3) {
+            if ((NGRP & 1) != 0) {   // the prefetched group sits in slot 1: next chunk starts from slot 0
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) { a[0][pl][i][0] = a[1][pl][i][0]; a[0][pl][i][1] = a[1][pl][i][1]; }
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) { bq[0][pl][j][0] = bq[1][pl][j][0]; bq[0][pl][j][1] = bq[1][pl][j][1]; }
+                }
+            }
+        } else if (c + 1 < n_chunks) {
+#pragma unroll
+            for (int P = 0; P < NF; ++P) TTS_FETCH_PART(0, stage_next, 0, P)
+        }
+        stage = stage_next;
+    }
+#undef TTS_LOAD_JOB
+#undef TTS_WRITE_JOB
+#undef TTS_FETCH_PART
+#undef TTS_LRELU
+
+    // epilogue: bias, residual, activation, accumulate modes.  Per half tile all loads
+    // (bias, residual, previous y) are issued first and only then consumed.
+    if (!wave_active) return;
+    const int co_w0 = co_blk0 + wm * MT * 32;
+    float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
+    const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs + phase : nullptr;
+    const float* __restrict__ bias = p.bias;
+    const float* __restrict__ scale = p.scale;
+    const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
+    const int y_cs = p.y_cs, y_ts = p.y_ts, r_cs = p.r_cs;
+    const float div = p.div;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int q = q0 + qw0 + j * 32 + l31;
+            const bool q_ok = q < n_out;
+            const int qc = q_ok ? q : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float bv[8], rv[8], pv[8], sv[8];
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = h * 8 + r8;
+                    const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    const int coc = min(co, Cout - 1);
+                    bv[r8] = bias ? bias[coc] : 0.f;
+                    sv[r8] = scale ? scale[coc] : 1.f;
+                    rv[r8] = rb ? rb[(int64_t)coc * r_cs + (int64_t)qc * y_ts] : 0.f;
+                    pv[r8] = mode != 0 ? yb[(int64_t)coc * y_cs + (int64_t)qc * y_ts] : 0.f;
+                }
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = h * 8 + r8;
+                    const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    float v = acc[i][j][r] + bv[r8];
+                    if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU()
+                    v = v * sv[r8] + rv[r8];
+                    if (relu_out == 1) v = fmaxf(v, 0.f);
+                    if (mode == 1) v = pv[r8] + v;
+                    else if (mode == 2) v = (pv[r8] + v) / div;
+                    if (q_ok && co < Cout) yb[(int64_t)co * y_cs + (int64_t)q * y_ts] = v;
+                }
+            }
+        }
+    }
+}
+
+
+template <int K, int MT, int NTL, int WM, int WN, int NPL>
+static int32_t launch_cfg_bf16(const ConvParams& p, hipStream_t stream) {
+    constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
+    using G = GeoB<K, NT_BLK, CO_BLK, NPL>;
+    TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
+    TTS_REQUIRE(p.w_bf16 != nullptr, "conv: bf16 weights were not packed for this layer");
+    const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(uint2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
+    hipLaunchKernelGGL((conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL>), grid, dim3(256), lds, stream, p);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int K, int NPL>
+static int32_t launch_k_bf16(const ConvParams& p, hipStream_t stream) {
+    auto blocks = [&](int co_blk, int nt_blk) -> int64_t {
+        return (int64_t)((p.Nout + nt_blk - 1) / nt_blk) * (p.CoutP / co_blk) * p.n_phase * p.batch;
+    };
+    const int64_t want = 768;
+    const bool tiny = p.Nout <= 96;
+    if (K == 11 && NPL == 2) {   // the 2x2-tile split-bf16 k=11 instantiations spill registers: 1x2 tiles
+        if (!tiny) return launch_cfg_bf16<K, 1, 2, 1, 4, NPL>(p, stream);
+        return launch_cfg_bf16<K, 1, 1, 1, 4, NPL>(p, stream);
+    }
+    if (p.CoutP % 128 == 0) {
+        if (!tiny && blocks(128, 128) >= want) return launch_cfg_bf16<K, 2, 2, 2, 2, NPL>(p, stream);
+        return launch_cfg_bf16<K, 1, 1, 2, 2, NPL>(p, stream);
+    }
+    if (p.CoutP % 64 == 0) {
+        if (!tiny && blocks(64, 256) >= want) return launch_cfg_bf16<K, 2, 2, 1, 4, NPL>(p, stream);
+        return launch_cfg_bf16<K, 1, 1, 2, 2, NPL>(p, stream);
+    }
+    if (!tiny && blocks(32, 256) >= want) return launch_cfg_bf16<K, 1, 2, 1, 4, NPL>(p, stream);
+    return launch_cfg_bf16<K, 1, 1, 1, 4, NPL>(p, stream);
+}
+
+template <int NPL>
+static int32_t launch_conv_bf16(const ConvParams& p, hipStream_t stream) {
+    switch (p.K) {
+        case 1: return launch_k_bf16<1, NPL>(p, stream);
+        case 2: return launch_k_bf16<2, NPL>(p, stream);
+        case 3: return launch_k_bf16<3, NPL>(p, stream);
+        case 7: return launch_k_bf16<7, NPL>(p, stream);
+        case 11: return launch_k_bf16<11, NPL>(p, stream);
+        default:
+            set_error("conv: kernel size %d not instantiated (1,2,3,7,11)", p.K);
+            return TTSAMD_EINVAL;
+    }
+}
+
+int32_t launch_conv_bf16_any(const ConvParams& p, hipStream_t stream) {
+    return p.precision == 2 ? launch_conv_bf16<2>(p, stream) : launch_conv_bf16<1>(p, stream);
+}
+
+}  // namespace ttsamd

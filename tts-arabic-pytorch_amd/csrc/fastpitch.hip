@@ -15,7 +15,7 @@
 namespace ttsamd {
 
 struct PConv {
-    int64_t w_off = 0, b_off = -1;
+    int64_t w_off = 0, b_off = -1, w16_off = 0;
     int cin = 0, cout = 0, k = 0;
 };
 struct FftLayer {
@@ -32,6 +32,7 @@ struct Predictor {
 struct FastPitch {
     ttsamd_fastpitch_cfg cfg;
     float* dev = nullptr;
+    uint16_t* dev16 = nullptr;
     std::vector<FftLayer> enc, dec;
     Predictor dur, pitch, energy;
     int64_t word_emb, pos_enc, pos_dec, spk_emb = -1, proj_b;
@@ -51,6 +52,7 @@ static int64_t numel(const ttsamd_tensor* t) {
 struct Builder {
     const TensorMap& tm;
     std::vector<float> blob;
+    std::vector<uint16_t> blob16;
     int32_t rc = 0;
     explicit Builder(const TensorMap& t) : tm(t) {}
 
@@ -87,6 +89,12 @@ struct Builder {
         c.w_off = (int64_t)blob.size();
         blob.resize(blob.size() + (size_t)cin * k * cout_padded(cout));
         pack_conv_weight(w->data, cout, cin, k, blob.data() + c.w_off);
+        {
+            const int64_t nn = (int64_t)cin * k * cout_padded(cout);
+            c.w16_off = (int64_t)blob16.size();
+            blob16.resize(blob16.size() + 2 * nn);
+            split_packed_bf16(blob.data() + c.w_off, nn, blob16.data() + c.w16_off);
+        }
         blob.resize(align_up((int64_t)blob.size(), 64));
         if (bias) c.b_off = raw(base + ".bias", cout);
         return c;
@@ -185,6 +193,8 @@ int32_t fastpitch_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_f
     if (rc == 0) {
         hipError_t e = hipMalloc((void**)&h->dev, b.blob.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, b.blob.data(), b.blob.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->dev16, b.blob16.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(h->dev16, b.blob16.data(), b.blob16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("fastpitch_create: weight upload failed: %s", hipGetErrorString(e));
             rc = TTSAMD_EHIP;
@@ -192,6 +202,7 @@ int32_t fastpitch_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_f
     }
     if (rc) {
         if (h->dev) (void)hipFree(h->dev);
+        if (h->dev16) (void)hipFree(h->dev16);
         delete h;
         return rc;
     }
@@ -202,6 +213,7 @@ int32_t fastpitch_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_f
 void fastpitch_destroy(FastPitch* h) {
     if (!h) return;
     if (h->dev) (void)hipFree(h->dev);
+    if (h->dev16) (void)hipFree(h->dev16);
     delete h;
 }
 
@@ -217,6 +229,7 @@ static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, floa
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.x_bs = (int64_t)c.cin * S; p.x_cs = S;
     p.w = h->dev + c.w_off; p.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
+    p.w_bf16 = h->dev16 + c.w16_off; p.precision = default_precision();
     p.y = y; p.y_bs = (int64_t)c.cout * S; p.y_cs = S; p.y_ts = 1;
     p.res = res; p.r_bs = (int64_t)c.cout * S; p.r_cs = S;
     p.lens_in = lens_in; p.lens_out = nullptr; p.len_in_mul = 1; p.len_out_mul = 1;

@@ -14,12 +14,14 @@ namespace ttsamd {
 
 struct ConvW {
     int64_t w_off = 0, b_off = 0;  // float offsets into the device weight blob
+    int64_t w16_off = 0, w_n = 0;  // bf16 planes (hi, lo) in the uint16 blob; packed element count
     int cin = 0, cout = 0, k = 0;
 };
 
 struct HifiGan {
     ttsamd_hifigan_cfg cfg;
     float* dev = nullptr;  // one blob with every packed weight and bias
+    uint16_t* dev16 = nullptr;  // bf16 hi/lo planes of the same packed weights
     ConvW conv_pre, conv_post;
     std::vector<ConvW> ups;
     std::vector<ConvW> c1, c2;  // [stage*n_kernels + j][m]
@@ -86,8 +88,15 @@ static int32_t get_bias(const TensorMap& tm, const std::string& base, int n, std
     return 0;
 }
 
+static void add_bf16(std::vector<float>& blob, std::vector<uint16_t>& blob16, ConvW& cw, int64_t n) {
+    cw.w_n = n;
+    cw.w16_off = (int64_t)blob16.size();
+    blob16.resize(blob16.size() + 2 * n);
+    split_packed_bf16(blob.data() + cw.w_off, n, blob16.data() + cw.w16_off);
+}
+
 static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, int cout, int k,
-                        std::vector<float>& blob, ConvW& cw) {
+                        std::vector<float>& blob, std::vector<uint16_t>& blob16, ConvW& cw) {
     std::vector<float> w;
     int64_t shp[3];
     TTS_TRY(folded_weight(tm, base, 3, w, shp));
@@ -97,6 +106,7 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
     cw.w_off = (int64_t)blob.size();
     blob.resize(blob.size() + (size_t)cin * k * cout_padded(cout));
     pack_conv_weight(w.data(), cout, cin, k, blob.data() + cw.w_off);
+    add_bf16(blob, blob16, cw, (int64_t)cin * k * cout_padded(cout));
     blob.resize(align_up((int64_t)blob.size(), 64));
     return get_bias(tm, base, cout, blob, cw.b_off);
 }
@@ -110,8 +120,9 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
     auto* h = new HifiGan();
     h->cfg = *cfg;
     std::vector<float> blob;
+    std::vector<uint16_t> blob16;
     const int c0 = cfg->upsample_initial_channel;
-    int32_t rc = add_conv(tm, "conv_pre", cfg->num_mels, c0, 7, blob, h->conv_pre);
+    int32_t rc = add_conv(tm, "conv_pre", cfg->num_mels, c0, 7, blob, blob16, h->conv_pre);
     int ch = c0, mul = 1;
     h->max_cl = c0;
     for (int i = 0; rc == 0 && i < cfg->n_ups; ++i) {
@@ -137,6 +148,7 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
         cw.w_off = (int64_t)blob.size();
         blob.resize(blob.size() + (size_t)u * cin * 2 * cout_padded(cout));
         pack_convt_weight(w.data(), cin, cout, kt, u, (kt - u) / 2, blob.data() + cw.w_off);
+        add_bf16(blob, blob16, cw, (int64_t)u * cin * 2 * cout_padded(cout));
         blob.resize(align_up((int64_t)blob.size(), 64));
         rc = get_bias(tm, "ups." + std::to_string(i), cout, blob, cw.b_off);
         if (rc) break;
@@ -148,9 +160,9 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
             const int r = i * cfg->n_kernels + j, kk = cfg->resblock_kernel_sizes[j];
             for (int m = 0; rc == 0 && m < cfg->n_dilations; ++m) {
                 ConvW a, b;
-                rc = add_conv(tm, "resblocks." + std::to_string(r) + ".convs1." + std::to_string(m), ch, ch, kk, blob, a);
+                rc = add_conv(tm, "resblocks." + std::to_string(r) + ".convs1." + std::to_string(m), ch, ch, kk, blob, blob16, a);
                 if (rc) break;
-                rc = add_conv(tm, "resblocks." + std::to_string(r) + ".convs2." + std::to_string(m), ch, ch, kk, blob, b);
+                rc = add_conv(tm, "resblocks." + std::to_string(r) + ".convs2." + std::to_string(m), ch, ch, kk, blob, blob16, b);
                 h->c1.push_back(a);
                 h->c2.push_back(b);
             }
@@ -178,6 +190,8 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
     if (rc == 0) {
         hipError_t e = hipMalloc((void**)&h->dev, blob.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->dev16, blob16.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(h->dev16, blob16.data(), blob16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("hifigan_create: weight upload failed: %s", hipGetErrorString(e));
             rc = TTSAMD_EHIP;
@@ -185,6 +199,7 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
     }
     if (rc != 0) {
         if (h->dev) (void)hipFree(h->dev);
+        if (h->dev16) (void)hipFree(h->dev16);
         delete h;
         return rc;
     }
@@ -195,6 +210,7 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
 void hifigan_destroy(HifiGan* h) {
     if (!h) return;
     if (h->dev) (void)hipFree(h->dev);
+    if (h->dev16) (void)hipFree(h->dev16);
     delete h;
 }
 
@@ -226,6 +242,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     int dil, float slope, int mode, float div) -> int32_t {
         p.x = x; p.x_bs = (int64_t)cw.cin * L; p.x_cs = L;
         p.w = h->dev + cw.w_off; p.bias = h->dev + cw.b_off;
+        p.w_bf16 = h->dev16 + cw.w16_off; p.precision = default_precision();
         p.y = y; p.y_bs = (int64_t)cw.cout * L; p.y_cs = L; p.y_ts = 1;
         p.res = res; p.r_bs = (int64_t)cw.cout * L; p.r_cs = L;
         p.len_in_mul = mul; p.len_out_mul = mul; p.Lin = L; p.Nout = L;
@@ -249,6 +266,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         // leaky_relu(0.1) + ConvTranspose1d as u polyphase 2-tap convs (models.py:114-115)
         p.x = cur; p.x_bs = (int64_t)uw.cin * L; p.x_cs = L;
         p.w = h->dev + uw.w_off; p.bias = h->dev + uw.b_off;
+        p.w_bf16 = h->dev16 + uw.w16_off; p.precision = default_precision();
         p.y = ups_out; p.y_bs = (int64_t)uw.cout * L * u; p.y_cs = L * u; p.y_ts = u;
         p.res = nullptr;
         p.len_in_mul = mul; p.len_out_mul = mul; p.Lin = L; p.Nout = L;

@@ -19,7 +19,7 @@ namespace ttsamd {
 constexpr int V_NFFT = 1024, V_HOP = 256, V_NBIN = 513, V_SPEC_CP = 1152;
 
 struct VConv {
-    int64_t w_off = 0, b_off = -1;
+    int64_t w_off = 0, b_off = -1, w16_off = 0;
     int cin = 0, cout = 0, coutp = 0, k = 0;
 };
 struct VBlock {
@@ -28,6 +28,7 @@ struct VBlock {
 };
 struct Vocos {
     float* dev = nullptr;
+    uint16_t* dev16 = nullptr;
     int in_ch = 80, dim = 512, inter = 1536;
     VConv embed, head;
     int64_t n0_g, n0_b, fl_g, fl_b, w_inv, window;
@@ -45,6 +46,7 @@ static int64_t vnumel(const ttsamd_tensor* t) {
 struct VBuilder {
     const TensorMap& tm;
     std::vector<float> blob;
+    std::vector<uint16_t> blob16;
     int32_t rc = 0;
     explicit VBuilder(const TensorMap& t) : tm(t) {}
     const ttsamd_tensor* get(const std::string& name, int64_t n) {
@@ -77,6 +79,12 @@ struct VBuilder {
         c.w_off = (int64_t)blob.size();
         blob.resize(blob.size() + (size_t)cin * k * coutp);
         pack_conv_weight(wp.data(), coutp, cin, k, blob.data() + c.w_off);
+        {
+            const int64_t nn = (int64_t)cin * k * coutp;
+            c.w16_off = (int64_t)blob16.size();
+            blob16.resize(blob16.size() + 2 * nn);
+            split_packed_bf16(blob.data() + c.w_off, nn, blob16.data() + c.w16_off);
+        }
         blob.resize(align_up((int64_t)blob.size(), 64));
         c.b_off = raw(base + ".bias", cout, coutp);
         return c;
@@ -121,6 +129,8 @@ int32_t vocos_create(const ttsamd_tensor* weights, int32_t n, int32_t in_ch, int
         b.blob.insert(b.blob.end(), wnd.begin(), wnd.end());
         hipError_t e = hipMalloc((void**)&h->dev, b.blob.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, b.blob.data(), b.blob.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->dev16, b.blob16.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(h->dev16, b.blob16.data(), b.blob16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("vocos_create: upload failed: %s", hipGetErrorString(e));
             rc = TTSAMD_EHIP;
@@ -138,6 +148,7 @@ int32_t vocos_create(const ttsamd_tensor* weights, int32_t n, int32_t in_ch, int
 void vocos_destroy(Vocos* h) {
     if (!h) return;
     if (h->dev) (void)hipFree(h->dev);
+    if (h->dev16) (void)hipFree(h->dev16);
     delete h;
 }
 
@@ -185,6 +196,7 @@ static int32_t vconv(const Vocos* h, const VConv& c, const float* x, float* y, c
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.x_bs = (int64_t)c.cin * T; p.x_cs = T;
     p.w = h->dev + c.w_off; p.bias = h->dev + c.b_off;
+    p.w_bf16 = h->dev16 + c.w16_off; p.precision = default_precision();
     p.y = y; p.y_bs = (int64_t)c.coutp * T; p.y_cs = T; p.y_ts = 1;
     p.res = res; p.r_bs = (int64_t)c.coutp * T; p.r_cs = T;
     p.scale = scale;

@@ -19,6 +19,21 @@ def _require_gpu():
     return lib
 
 
+PRECISIONS = {'f32': 0, 'bf16': 1, 'bf16x3': 2}
+
+
+def set_precision(name):
+    """MFMA operand precision of all conv/linear GEMMs: 'f32' (default, exact), 'bf16' (config 3),
+    'bf16x3' (split bf16: fp32-class accuracy at bf16 MFMA rate)."""
+    lib = L.load()
+    L.check(lib.ttsamd_set_precision(PRECISIONS[name]), 'set_precision')
+
+
+def get_precision():
+    code = L.load().ttsamd_get_precision()
+    return {v: k for k, v in PRECISIONS.items()}[code]
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 

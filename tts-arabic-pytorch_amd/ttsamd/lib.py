@@ -63,6 +63,8 @@ SYMBOLS = {
     'ttsamd_vocos_forward': (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _P, _P, _I64, _P]),
     'ttsamd_conv1d_packed_floats': (_I64, [_I32, _I32, _I32]),
     'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
+    'ttsamd_set_precision': (_I32, [_I32]),
+    'ttsamd_get_precision': (_I32, []),
     'ttsamd_profile_enable': (_I32, [_I32]),
     'ttsamd_profile_read': (_I32, [C.POINTER(C.c_double)]),
 }
