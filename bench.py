@@ -79,6 +79,11 @@ def main():
         print('bench.py: --gpus N>1 must be launched with torch.distributed.run', file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+    # TTSAMD_BENCH_ONE_DEVICE=1 (debug only): all ranks share GPU 0 over gloo, to exercise the N>1 code
+    # path on a 1-GPU box; the real multi-GPU run is one rank per GPU over RCCL.
+    one_dev = os.environ.get('TTSAMD_BENCH_ONE_DEVICE') == '1'
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -88,7 +93,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if one_dev:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         from ttsamd import dp
         fp_sd = synth.fastpitch_state_dict() if rank == 0 else None
         hg_sd = synth.hifigan_state_dict() if rank == 0 else None

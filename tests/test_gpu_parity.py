@@ -361,3 +361,78 @@ def test_end_to_end_bf16_modes(dev, golden, precision, fastpitch_engine, hifigan
     err_wave = maxabs(wave[0], h['wave'][0])
     print(f'{mode}: mel max-abs {err_mel:.2e}, wave max-abs {err_wave:.2e}')
     assert err_mel < mel_tol and err_wave < wave_tol
+
+
+# ---------------------------------------------------------------------------------------
+# Edge cases and C-ABI error behaviour
+# ---------------------------------------------------------------------------------------
+
+def test_edge_cases_lengths(dev, synth_weights, fastpitch_engine, hifigan_engine):
+    import tts_oracle as O
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    fw = O.to_torch(synth_weights['fastpitch'])
+    # single token, single utterance
+    ids = np.array([[7]], np.int64)
+    mel, dec_lens, dur, *_ = fastpitch_engine.infer(ids)
+    rmel, rlens, rdur, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids)
+    assert np.array_equal(dec_lens.cpu().numpy(), rlens.numpy()) and maxabs(mel, rmel) < MEL_TOL
+    # max_duration clamp and a zero-duration token inside the utterance (reps = 0 -> token skipped)
+    ids = np.array([[3, 9, 4, 12, 0, 0], [5, 6, 0, 0, 0, 0]], np.int64)
+    dur_tgt = np.array([[80.0, 0.0, 2.0, 0.4, 0, 0], [1.0, 0.49, 0, 0, 0, 0]], np.float32)
+    mel, dec_lens, *_ , idx = fastpitch_engine.infer(ids, dur_tgt=dur_tgt, return_idx=True)
+    rmel, rlens, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids, dur_tgt=dur_tgt)
+    _, _, ridx = O.regulate_len_indices(dur_tgt, 1.0)
+    assert np.array_equal(dec_lens.cpu().numpy(), rlens.numpy()) and np.array_equal(idx.cpu().numpy(), ridx)
+    assert maxabs(mel, rmel) < MEL_TOL
+    # vocoder: an utterance of length 0 inside a batch produces silence and does not disturb the others
+    hw = O.fold_weight_norm(synth_weights['hifigan'])
+    rng = np.random.default_rng(23)
+    melv = (rng.standard_normal((3, 80, 6)) * 1.5 - 4.0).astype(np.float32)
+    lens = torch.tensor([6, 0, 2])
+    wave = hifigan_engine.forward(torch.from_numpy(melv).to(dev), lens.to(dev)).cpu()
+    assert float(wave[1].abs().max()) == 0.0
+    for b in (0, 2):
+        n = int(lens[b])
+        assert maxabs(wave[b, :256 * n], O.hifigan_forward(hw, melv[b, :, :n], HIFIGAN_CONFIG)[0]) < WAVE_TOL
+
+
+def test_longest_infer_text_line(dev, golden, synth_weights, fastpitch_engine, hifigan_engine):
+    """Config-1 extreme: the longest data/infer_text.txt line (268 tokens, ~2000 frames) vs the oracle."""
+    import tts_oracle as O
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    t = golden('infer_text_ids')
+    lens = np.diff(t['offsets'])
+    i = int(np.argmax(lens))
+    ids = t['flat'][t['offsets'][i]:t['offsets'][i + 1]][None]
+    assert ids.shape[1] == 268
+    dur = (1 + (np.arange(268) % 9)).astype(np.float32)[None]          # forced durations: index parity exact
+    mel, dec_lens, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
+    rmel, rlens, *_ = O.fastpitch_infer(O.to_torch(synth_weights['fastpitch']), NET_CONFIG, ids, dur_tgt=dur)
+    assert np.array_equal(dec_lens.cpu().numpy(), rlens.numpy())
+    assert maxabs(mel, rmel) < MEL_TOL
+    wave = hifigan_engine.forward(mel, dec_lens).cpu()
+    ref = O.hifigan_forward(O.fold_weight_norm(synth_weights['hifigan']), rmel[0], HIFIGAN_CONFIG)[0]
+    assert maxabs(wave[0], ref) < WAVE_TOL
+
+
+def test_c_abi_error_codes(dev, hifigan_engine):
+    """Negative return codes + thread-local message instead of crashes."""
+    import ctypes as C
+    from ttsamd import lib as L
+    lib = L.load()
+    mel = torch.zeros(1, 80, 4, device=dev)
+    wave = torch.zeros(1, 1024, device=dev)
+    ws = torch.empty(16, dtype=torch.uint8, device=dev)            # far too small
+    rc = lib.ttsamd_hifigan_forward(hifigan_engine.handle, C.c_void_p(mel.data_ptr()), C.c_void_p(0), 1, 4,
+                                    C.c_void_p(wave.data_ptr()), C.c_void_p(ws.data_ptr()), 16, C.c_void_p(0))
+    assert rc == -3 and b'workspace' in lib.ttsamd_last_error()
+    rc = lib.ttsamd_hifigan_forward(hifigan_engine.handle, C.c_void_p(0), C.c_void_p(0), 1, 4, C.c_void_p(0),
+                                    C.c_void_p(0), 0, C.c_void_p(0))
+    assert rc == -1
+    assert lib.ttsamd_set_precision(7) == -1
+    h = C.c_void_p()
+    cfg = L.HifiGanCfg()
+    cfg.n_ups, cfg.n_kernels, cfg.n_dilations = 4, 3, 3
+    arr, keep = L.make_tensors({})
+    assert lib.ttsamd_hifigan_create(arr, 0, C.byref(cfg), C.byref(h)) == -1      # missing tensors
+    assert b'conv_pre' in lib.ttsamd_last_error()
