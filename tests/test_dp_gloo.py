@@ -49,6 +49,19 @@ def _worker(rank, world, port, tmpdir):
                 assert w.shape == ((g + 1) * 10,) and bool((w == g + 1).all())
         else:
             assert out is None
+        # end-to-end sharded tts with a stub model: utterance text 'x'*n -> wave of n samples valued n
+        class Stub:
+            device = torch.device('cpu')
+
+            def tts(self, texts, batch_size=2, **kw):
+                return [torch.full((len(t),), float(len(t))) for t in texts]
+        texts = ['x' * n for n in (5, 9, 3, 7, 1)]
+        res = dp.tts_sharded(Stub(), texts, batch_size=2)
+        if rank == 0:
+            assert [w.numel() for w in res] == [5, 9, 3, 7, 1]
+            assert all(bool((w == w.numel()).all()) for w in res)
+        else:
+            assert res is None
         with open(os.path.join(tmpdir, f'ok{rank}'), 'w') as f:
             f.write('ok')
     finally:

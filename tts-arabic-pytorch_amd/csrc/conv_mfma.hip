@@ -336,6 +336,16 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
     };
     const int64_t want = 768;
     const bool tiny = p.Nout <= 96;
+#ifdef TTS_FORCE_CFG   /* tile autotuning with tools/conv_bench.hip */
+    switch (TTS_FORCE_CFG) {
+        case 0: if (p.CoutP % 128 == 0) return launch_cfg<K, 2, 2, 2, 2>(p, stream); break;
+        case 1: if (p.CoutP % 128 == 0) return launch_cfg<K, 1, 2, 4, 1>(p, stream); break;
+        case 2: if (p.CoutP % 64 == 0) return launch_cfg<K, 2, 2, 1, 4>(p, stream); break;
+        case 3: if (p.CoutP % 64 == 0) return launch_cfg<K, 1, 1, 2, 2>(p, stream); break;
+        case 4: return launch_cfg<K, 1, 2, 1, 4>(p, stream);
+        case 5: return launch_cfg<K, 1, 1, 1, 4>(p, stream);
+    }
+#endif
     if (p.CoutP % 128 == 0) {
         if (K < 11 && !tiny && blocks(128, 128) >= want) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
         if (K == 11 && !tiny && blocks(64, 256) >= want) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t

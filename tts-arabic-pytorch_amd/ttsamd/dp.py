@@ -66,3 +66,33 @@ def gather_audio(wave, lens, dst=0):
         for i in range(int(metas[r][0])):
             out.append(bufs[r][i, :int(all_lens[r][i])])
     return out
+
+
+def tts_sharded(model, texts, batch_size=32, dst=0, **tts_kwargs):
+    """Data-parallel `FastPitch2Wave.tts(list)`: every rank calls this with the SAME list.
+    Utterances are ordered by length (so each rank's padded sub-batches are tight), dealt out in
+    contiguous shards (`shard_bounds`), synthesised locally with `model.tts(shard, batch_size=...)`
+    and gathered to rank `dst`, which returns the waves in the original order (other ranks: None).
+    NB padded-batch FastPitch results depend on batch composition: an utterance's
+    wave equals the single-GPU result for the same sub-batch, not for a different batching."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))
+    lo, hi = shard_bounds(len(order), world, rank)
+    mine = [texts[i] for i in order[lo:hi]]
+    waves = model.tts(mine, batch_size=batch_size, **tts_kwargs) if mine else []
+    dev = getattr(model, 'device', torch.device('cpu'))
+    if dist.get_backend() == 'gloo':
+        dev = torch.device('cpu')
+    n_max = max([w.numel() for w in waves], default=1)
+    pad = torch.zeros(len(waves), n_max, dtype=torch.float32, device=dev)
+    lens = torch.zeros(len(waves), dtype=torch.int64, device=dev)
+    for i, w in enumerate(waves):
+        pad[i, :w.numel()] = w.to(dev)
+        lens[i] = w.numel()
+    gathered = gather_audio(pad, lens, dst=dst)
+    if rank != dst:
+        return None
+    out = [None] * len(texts)
+    for pos, w in zip(order, gathered):          # gathered is in rank order = sorted order
+        out[pos] = w.cpu()
+    return out
