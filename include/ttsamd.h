@@ -67,6 +67,28 @@ typedef struct ttsamd_fastpitch_cfg {
     float speaker_emb_weight;
 } ttsamd_fastpitch_cfg;
 
+/* models/tacotron2/tacotron2_ms.py:121-153 (Tacotron2MS.__init__ defaults), inference fields only */
+typedef struct ttsamd_tacotron2_cfg {
+    int32_t n_symbol;                       /* 40 */
+    int32_t num_speakers;                   /* 1: no speaker embedding */
+    int32_t speaker_embedding_dim;          /* 128 (used when num_speakers > 1) */
+    int32_t symbol_embedding_dim;           /* 512 */
+    int32_t encoder_embedding_dim;          /* 512 */
+    int32_t encoder_n_convolution;          /* 3 */
+    int32_t encoder_kernel_size;            /* 5 */
+    int32_t n_mels;                         /* 80 */
+    int32_t prenet_dim;                     /* 256 */
+    int32_t attention_rnn_dim;              /* 1024 */
+    int32_t decoder_rnn_dim;                /* 1024 */
+    int32_t attention_hidden_dim;           /* 128 */
+    int32_t attention_location_n_filter;    /* 32 */
+    int32_t attention_location_kernel_size; /* 31 */
+    int32_t postnet_n_convolution;          /* 5 */
+    int32_t postnet_kernel_size;            /* 5 */
+    int32_t postnet_embedding_dim;          /* 512 */
+    float gate_threshold;                   /* 0.5 */
+} ttsamd_tacotron2_cfg;
+
 const char* ttsamd_last_error(void);
 int32_t ttsamd_version(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
@@ -164,6 +186,27 @@ int32_t ttsamd_vocos_bias_vec(void* handle, float* bias_vec, void* workspace, in
 int32_t ttsamd_vocos_forward(void* handle, const float* mel, const int64_t* lens, int32_t batch,
                              int32_t t_max, float denoise, const float* bias_vec, float* wave,
                              void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- Tacotron2MS.infer: replaces models/tacotron2/tacotron2_ms.py:279-332 (encoder, speaker
+ *      concat, autoregressive _Decoder.infer, postnet).  Weight names are the keys of
+ *      Tacotron2MS.state_dict() (embedding.weight, speaker_embedding.weight, encoder.*, decoder.*,
+ *      postnet.*); BatchNorm layers are folded on the host (eval mode). --------------------------- */
+int32_t ttsamd_tacotron2_create(const ttsamd_tensor* weights, int32_t n_weights,
+                                const ttsamd_tacotron2_cfg* cfg, void** handle);
+int32_t ttsamd_tacotron2_destroy(void* handle);
+int64_t ttsamd_tacotron2_workspace_bytes(void* handle, int32_t batch, int32_t n_tokens, int32_t max_step);
+/* tokens int64 [B][n_tokens] (zero-padded), lengths int64 [B] sorted descending or not (packed-sequence
+ * semantics per utterance), speaker_ids int64 [B] or NULL (num_speakers == 1); all DEVICE pointers.
+ * Outputs (device): mel_post / mel_raw [B][n_mels][max_step] (row stride max_step; frames >= *n_steps
+ * are untouched), mel_lens int32 [B], alignments [B][max_step][n_tokens].  *n_steps (HOST) = number of
+ * decoder steps the reference loop would have run (it stops once every utterance's gate fired, or at
+ * max_step).  dropout_seed < 0 disables the prenet dropout; >= 0 applies the always-on p=0.5 dropout of
+ * torchaudio's _Prenet with a counter-based hash (seed, layer, step, b, j) instead of torch's RNG. */
+int32_t ttsamd_tacotron2_infer(void* handle, const int64_t* tokens, const int64_t* lengths,
+                               const int64_t* speaker_ids, int32_t batch, int32_t n_tokens, int32_t max_step,
+                               int64_t dropout_seed, float* mel_post, int32_t* mel_lens, float* alignments,
+                               float* mel_raw, int32_t* n_steps, void* workspace, int64_t workspace_bytes,
+                               void* stream);
 
 /* ---- kernel-level entry used by the parity tests and the roofline bench ------------- */
 

@@ -63,6 +63,12 @@ int64_t vocos_bias_workspace_bytes(const Vocos*);
 int32_t vocos_bias_vec(const Vocos*, float*, void*, int64_t, hipStream_t);
 int32_t vocos_forward(const Vocos*, const float*, const int64_t*, int32_t, int32_t, float, const float*, float*, void*,
                       int64_t, hipStream_t);
+struct Taco2;
+int32_t tacotron2_create(const ttsamd_tensor*, int32_t, const ttsamd_tacotron2_cfg*, Taco2**);
+void tacotron2_destroy(Taco2*);
+int64_t tacotron2_workspace_bytes(const Taco2*, int32_t, int32_t, int32_t);
+int32_t tacotron2_infer(const Taco2*, const int64_t*, const int64_t*, const int64_t*, int32_t, int32_t, int32_t, int64_t,
+                        float*, int32_t*, float*, float*, int32_t*, void*, int64_t, hipStream_t);
 int32_t denoiser_create(Denoiser**);
 void denoiser_destroy(Denoiser*);
 int64_t denoiser_workspace_bytes(int32_t, int32_t);
@@ -240,6 +246,29 @@ int32_t ttsamd_vocos_forward(void* handle, const float* mel, const int64_t* lens
                              int64_t workspace_bytes, void* stream) {
     return vocos_forward((Vocos*)handle, mel, lens, batch, t_max, denoise, bias_vec, wave, workspace, workspace_bytes,
                          (hipStream_t)stream);
+}
+
+int32_t ttsamd_tacotron2_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_tacotron2_cfg* cfg, void** handle) {
+    TTS_REQUIRE(handle, "tacotron2_create: null handle");
+    Taco2* h = nullptr;
+    const int32_t rc = tacotron2_create(weights, n, cfg, &h);
+    if (rc == 0) *handle = h;
+    return rc;
+}
+int32_t ttsamd_tacotron2_destroy(void* handle) {
+    tacotron2_destroy((Taco2*)handle);
+    return 0;
+}
+int64_t ttsamd_tacotron2_workspace_bytes(void* handle, int32_t batch, int32_t n_tokens, int32_t max_step) {
+    if (!handle || batch < 1 || n_tokens < 1 || max_step < 1) return 0;
+    return tacotron2_workspace_bytes((Taco2*)handle, batch, n_tokens, max_step);
+}
+int32_t ttsamd_tacotron2_infer(void* handle, const int64_t* tokens, const int64_t* lengths, const int64_t* speaker_ids,
+                               int32_t batch, int32_t n_tokens, int32_t max_step, int64_t dropout_seed, float* mel_post,
+                               int32_t* mel_lens, float* alignments, float* mel_raw, int32_t* n_steps, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    return tacotron2_infer((Taco2*)handle, tokens, lengths, speaker_ids, batch, n_tokens, max_step, dropout_seed, mel_post,
+                           mel_lens, alignments, mel_raw, n_steps, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {

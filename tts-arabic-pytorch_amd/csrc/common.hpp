@@ -80,7 +80,7 @@ struct ConvParams {
     int32_t phase_p;     // transposed conv padding p: delta = (phase+p)/n_phase, pad = -delta
     float in_slope;      // leaky-relu slope applied to the input on load (1 = identity)
     const float* scale;  // per-output-channel factor applied after the bias, before the residual (nullptr = 1)
-    int32_t relu_out;    // output activation: 0 none, 1 ReLU, 2 GELU (erf)
+    int32_t relu_out;    // output activation: 0 none, 1 ReLU, 2 GELU (erf), 3 tanh (after the residual)
     int32_t mode;        // 0: y=v   1: y=y+v   2: y=(y+v)/div
     float div;
     int32_t batch;

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                     if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU()
                     v = v * sv[r8] + rv[r8];
                     if (relu_out == 1) v = fmaxf(v, 0.f);
+                    else if (relu_out == 3) v = tanhf(v);
                     if (mode == 1) v = pv[r8] + v;
                     else if (mode == 2) v = (pv[r8] + v) / div;
                     if (q_ok && co < Cout) yb[(int64_t)co * y_cs + (int64_t)q * y_ts] = v;
@@ -370,10 +371,11 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
         case 1: return launch_k<1>(p, stream);
         case 2: return launch_k<2>(p, stream);
         case 3: return launch_k<3>(p, stream);
+        case 5: return launch_k<5>(p, stream);
         case 7: return launch_k<7>(p, stream);
         case 11: return launch_k<11>(p, stream);
         default:
-            set_error("conv: kernel size %d not instantiated (1,2,3,7,11)", p.K);
+            set_error("conv: kernel size %d not instantiated (1,2,3,5,7,11)", p.K);
             return TTSAMD_EINVAL;
     }
 }

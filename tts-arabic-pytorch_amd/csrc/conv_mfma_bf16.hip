@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
                     if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU()
                     v = v * sv[r8] + rv[r8];
                     if (relu_out == 1) v = fmaxf(v, 0.f);
+                    else if (relu_out == 3) v = tanhf(v);
                     if (mode == 1) v = pv[r8] + v;
                     else if (mode == 2) v = (pv[r8] + v) / div;
                     if (q_ok && co < Cout) yb[(int64_t)co * y_cs + (int64_t)q * y_ts] = v;
@@ -355,10 +356,11 @@ static int32_t launch_conv_bf16(const ConvParams& p, hipStream_t stream) {
         case 1: return launch_k_bf16<1, NPL>(p, stream);
         case 2: return launch_k_bf16<2, NPL>(p, stream);
         case 3: return launch_k_bf16<3, NPL>(p, stream);
+        case 5: return launch_k_bf16<5, NPL>(p, stream);
         case 7: return launch_k_bf16<7, NPL>(p, stream);
         case 11: return launch_k_bf16<11, NPL>(p, stream);
         default:
-            set_error("conv: kernel size %d not instantiated (1,2,3,7,11)", p.K);
+            set_error("conv: kernel size %d not instantiated (1,2,3,5,7,11)", p.K);
             return TTSAMD_EINVAL;
     }
 }

@@ -1,0 +1,647 @@
+// Tacotron2MS.infer on the MI355X (BASELINE config 4).
+// Replaces models/tacotron2/tacotron2_ms.py:279-332 and the torchaudio.models.tacotron2 private
+// classes it instantiates (:188-207: _Encoder, _Decoder.infer, _Postnet) — restated from the
+// published architecture because torchaudio is not vendored (parity unpinned).
+//   encoder : embedding gather -> 3 x [Conv1d k5 + BatchNorm(eval, folded) + ReLU] on the MFMA conv
+//             engine -> input projections of both LSTM directions as one 1x1 conv -> a persistent
+//             BiLSTM kernel (one block per (utterance, direction), packed-sequence semantics)
+//   decoder : one autoregressive step = prenet (dropout from a counter-based hash) -> attention
+//             LSTMCell -> location-sensitive attention -> decoder LSTMCell -> mel/gate projection;
+//             the LSTM cells are weight-streaming GEMVs (75 MB of fp32 weights per step, resident
+//             in L2/MALL), one wave64 per hidden unit; the stop test is read back every 8 steps
+//   postnet : 5 x [Conv1d k5 + BatchNorm folded (+ tanh)] on the conv engine, residual fused.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace ttsamd {
+
+struct TConv {
+    int64_t w_off = 0, b_off = 0, w16_off = 0;
+    int cin = 0, cout = 0, k = 0;
+};
+
+struct Taco2 {
+    ttsamd_tacotron2_cfg cfg;
+    float* dev = nullptr;
+    uint16_t* dev16 = nullptr;
+    int64_t emb = 0, spk = -1;
+    std::vector<TConv> enc_convs, post_convs;
+    TConv enc_xproj;
+    int64_t enc_whhT[2];
+    int64_t pre0T, pre1T;
+    int64_t att_wih, att_whh, att_b, dec_wih, dec_whh, dec_b;
+    int64_t wqT, wmT, v, loc_conv, loc_denseT;
+    int64_t proj_w, proj_b;
+    int mem_dim = 0;
+};
+
+using TensorMap = std::map<std::string, const ttsamd_tensor*>;
+
+static int64_t tnumel(const ttsamd_tensor* t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+}
+
+struct TBuilder {
+    const TensorMap& tm;
+    std::vector<float> blob;
+    std::vector<uint16_t> blob16;
+    int32_t rc = 0;
+    explicit TBuilder(const TensorMap& t) : tm(t) {}
+    const float* get(const std::string& name, int64_t n) {
+        if (rc) return nullptr;
+        auto it = tm.find(name);
+        if (it == tm.end() || tnumel(it->second) != n) {
+            set_error("tacotron2: missing or mis-sized tensor '%s' (expected %lld elements)", name.c_str(), (long long)n);
+            rc = TTSAMD_EINVAL;
+            return nullptr;
+        }
+        return it->second->data;
+    }
+    int64_t push(const float* p, int64_t n) {
+        const int64_t off = (int64_t)blob.size();
+        if (p) blob.insert(blob.end(), p, p + n);
+        blob.resize(align_up((int64_t)blob.size(), 64));
+        return off;
+    }
+    int64_t raw(const std::string& name, int64_t n) { return push(get(name, n), n); }
+    // [rows][cols] row-major -> [cols][rows]
+    int64_t transposed(const std::string& name, int rows, int cols) {
+        const float* p = get(name, (int64_t)rows * cols);
+        if (!p) return 0;
+        std::vector<float> t((size_t)rows * cols);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = p[(size_t)r * cols + c];
+        return push(t.data(), (int64_t)t.size());
+    }
+    int64_t bias_sum(const std::string& a, const std::string& b2, int n) {
+        const float *pa = get(a, n), *pb = get(b2, n);
+        if (!pa || !pb) return 0;
+        std::vector<float> t(n);
+        for (int i = 0; i < n; ++i) t[i] = pa[i] + pb[i];
+        return push(t.data(), n);
+    }
+    TConv conv_packed(const float* w, const float* bias, int cin, int cout, int k) {
+        TConv c;
+        c.cin = cin; c.cout = cout; c.k = k;
+        const int64_t nn = (int64_t)cin * k * cout_padded(cout);
+        c.w_off = (int64_t)blob.size();
+        blob.resize(blob.size() + nn);
+        pack_conv_weight(w, cout, cin, k, blob.data() + c.w_off);
+        c.w16_off = (int64_t)blob16.size();
+        blob16.resize(blob16.size() + 2 * nn);
+        split_packed_bf16(blob.data() + c.w_off, nn, blob16.data() + c.w16_off);
+        blob.resize(align_up((int64_t)blob.size(), 64));
+        c.b_off = push(bias, cout);
+        return c;
+    }
+    // Conv1d followed by BatchNorm1d in eval mode, folded: w' = w*s, b' = (b - mean)*s + beta, s = gamma/sqrt(var+eps)
+    TConv conv_bn(const std::string& base, int cin, int cout, int k) {
+        const float* w = get(base + ".0.weight", (int64_t)cout * cin * k);
+        const float* b = get(base + ".0.bias", cout);
+        const float* g = get(base + ".1.weight", cout);
+        const float* be = get(base + ".1.bias", cout);
+        const float* mu = get(base + ".1.running_mean", cout);
+        const float* var = get(base + ".1.running_var", cout);
+        if (rc) return TConv();
+        std::vector<float> wf((size_t)cout * cin * k), bf(cout);
+        for (int co = 0; co < cout; ++co) {
+            const float s = g[co] / std::sqrt(var[co] + 1e-5f);
+            for (int64_t i = 0; i < (int64_t)cin * k; ++i) wf[(size_t)co * cin * k + i] = w[(size_t)co * cin * k + i] * s;
+            bf[co] = (b[co] - mu[co]) * s + be[co];
+        }
+        return conv_packed(wf.data(), bf.data(), cin, cout, k);
+    }
+};
+
+int32_t tacotron2_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_tacotron2_cfg* cfg, Taco2** out) {
+    TTS_REQUIRE(weights && cfg && out, "tacotron2_create: null argument");
+    const int E = cfg->encoder_embedding_dim, S = cfg->num_speakers > 1 ? cfg->speaker_embedding_dim : 0;
+    const int M = E + S, P = cfg->prenet_dim, A = cfg->attention_rnn_dim, D = cfg->decoder_rnn_dim;
+    const int Hd = cfg->attention_hidden_dim, NF = cfg->attention_location_n_filter, KS = cfg->attention_location_kernel_size;
+    TTS_REQUIRE(cfg->symbol_embedding_dim == E && E % 16 == 0 && (E / 2) == 256 && A % 4 == 0 && D % 4 == 0 && Hd == 128 &&
+                NF == 32 && KS <= 63 && P == 256 && cfg->n_mels == 80,
+                "tacotron2_create: only the shipped geometry is built (512/256/1024/1024/128/32/80)");
+    TensorMap tm;
+    for (int i = 0; i < n; ++i) tm[weights[i].name] = &weights[i];
+    TBuilder b(tm);
+    auto* h = new Taco2();
+    h->cfg = *cfg;
+    h->mem_dim = M;
+    h->emb = b.raw("embedding.weight", (int64_t)cfg->n_symbol * E);
+    if (S) h->spk = b.raw("speaker_embedding.weight", (int64_t)cfg->num_speakers * S);
+    for (int i = 0; i < cfg->encoder_n_convolution && !b.rc; ++i)
+        h->enc_convs.push_back(b.conv_bn("encoder.convolutions." + std::to_string(i), E, E, cfg->encoder_kernel_size));
+    {   // both directions' input projections as one 1x1 conv: rows [fwd i,f,g,o | bwd i,f,g,o], bias = b_ih + b_hh
+        const int Hh = E / 2;
+        const float* wf = b.get("encoder.lstm.weight_ih_l0", (int64_t)4 * Hh * E);
+        const float* wb = b.get("encoder.lstm.weight_ih_l0_reverse", (int64_t)4 * Hh * E);
+        const float* bif = b.get("encoder.lstm.bias_ih_l0", 4 * Hh);
+        const float* bhf = b.get("encoder.lstm.bias_hh_l0", 4 * Hh);
+        const float* bib = b.get("encoder.lstm.bias_ih_l0_reverse", 4 * Hh);
+        const float* bhb = b.get("encoder.lstm.bias_hh_l0_reverse", 4 * Hh);
+        if (!b.rc) {
+            std::vector<float> w((size_t)8 * Hh * E), bias(8 * Hh);
+            std::memcpy(w.data(), wf, (size_t)4 * Hh * E * sizeof(float));
+            std::memcpy(w.data() + (size_t)4 * Hh * E, wb, (size_t)4 * Hh * E * sizeof(float));
+            for (int i = 0; i < 4 * Hh; ++i) {
+                bias[i] = bif[i] + bhf[i];
+                bias[4 * Hh + i] = bib[i] + bhb[i];
+            }
+            h->enc_xproj = b.conv_packed(w.data(), bias.data(), E, 8 * Hh, 1);
+        }
+        h->enc_whhT[0] = b.transposed("encoder.lstm.weight_hh_l0", 4 * Hh, Hh);
+        h->enc_whhT[1] = b.transposed("encoder.lstm.weight_hh_l0_reverse", 4 * Hh, Hh);
+    }
+    h->pre0T = b.transposed("decoder.prenet.layers.0.weight", P, cfg->n_mels);
+    h->pre1T = b.transposed("decoder.prenet.layers.1.weight", P, P);
+    h->att_wih = b.raw("decoder.attention_rnn.weight_ih", (int64_t)4 * A * (P + M));
+    h->att_whh = b.raw("decoder.attention_rnn.weight_hh", (int64_t)4 * A * A);
+    h->att_b = b.bias_sum("decoder.attention_rnn.bias_ih", "decoder.attention_rnn.bias_hh", 4 * A);
+    h->wqT = b.transposed("decoder.attention_layer.query_layer.weight", Hd, A);
+    h->wmT = b.transposed("decoder.attention_layer.memory_layer.weight", Hd, M);
+    h->v = b.raw("decoder.attention_layer.v.weight", Hd);
+    h->loc_conv = b.raw("decoder.attention_layer.location_layer.location_conv.weight", (int64_t)NF * 2 * KS);
+    h->loc_denseT = b.transposed("decoder.attention_layer.location_layer.location_dense.weight", Hd, NF);
+    h->dec_wih = b.raw("decoder.decoder_rnn.weight_ih", (int64_t)4 * D * (A + M));
+    h->dec_whh = b.raw("decoder.decoder_rnn.weight_hh", (int64_t)4 * D * D);
+    h->dec_b = b.bias_sum("decoder.decoder_rnn.bias_ih", "decoder.decoder_rnn.bias_hh", 4 * D);
+    {   // mel projection rows 0..79 and the gate as row 80
+        const float* pw = b.get("decoder.linear_projection.weight", (int64_t)cfg->n_mels * (D + M));
+        const float* pb = b.get("decoder.linear_projection.bias", cfg->n_mels);
+        const float* gw = b.get("decoder.gate_layer.weight", D + M);
+        const float* gb = b.get("decoder.gate_layer.bias", 1);
+        if (!b.rc) {
+            std::vector<float> w((size_t)(cfg->n_mels + 1) * (D + M)), bias(cfg->n_mels + 1);
+            std::memcpy(w.data(), pw, (size_t)cfg->n_mels * (D + M) * sizeof(float));
+            std::memcpy(w.data() + (size_t)cfg->n_mels * (D + M), gw, (size_t)(D + M) * sizeof(float));
+            std::memcpy(bias.data(), pb, cfg->n_mels * sizeof(float));
+            bias[cfg->n_mels] = gb[0];
+            h->proj_w = b.push(w.data(), (int64_t)w.size());
+            h->proj_b = b.push(bias.data(), (int64_t)bias.size());
+        }
+    }
+    for (int i = 0; i < cfg->postnet_n_convolution && !b.rc; ++i) {
+        const int cin = i == 0 ? cfg->n_mels : cfg->postnet_embedding_dim;
+        const int cout = i == cfg->postnet_n_convolution - 1 ? cfg->n_mels : cfg->postnet_embedding_dim;
+        h->post_convs.push_back(b.conv_bn("postnet.convolutions." + std::to_string(i), cin, cout, cfg->postnet_kernel_size));
+    }
+    int32_t rc = b.rc;
+    if (rc == 0) {
+        hipError_t e = hipMalloc((void**)&h->dev, b.blob.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(h->dev, b.blob.data(), b.blob.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->dev16, b.blob16.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(h->dev16, b.blob16.data(), b.blob16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("tacotron2_create: upload failed: %s", hipGetErrorString(e));
+            rc = TTSAMD_EHIP;
+        }
+    }
+    if (rc) {
+        if (h->dev) (void)hipFree(h->dev);
+        if (h->dev16) (void)hipFree(h->dev16);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void tacotron2_destroy(Taco2* h) {
+    if (!h) return;
+    if (h->dev) (void)hipFree(h->dev);
+    if (h->dev16) (void)hipFree(h->dev16);
+    delete h;
+}
+
+// ------------------------------------------------------------------------------------ kernels
+
+__global__ __launch_bounds__(256) void taco_embed_kernel(const int64_t* __restrict__ tok, const float* __restrict__ emb,
+                                                         int E, int L, float* __restrict__ x) {
+    const int b = blockIdx.y, tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    if (t >= L) return;
+    const float* er = emb + tok[(int64_t)b * L + t] * E;
+    for (int c = g; c < E; c += 4) x[((int64_t)b * E + c) * L + t] = er[c];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Packed-sequence BiLSTM (hidden 256 per direction): block = (utterance, direction), thread = hidden unit.
+// xproj [B][2048][L] already holds W_ih x + b_ih + b_hh; whhT [256][1024]; memory [B][L][M] (pre-zeroed).
+__global__ __launch_bounds__(256) void taco_bilstm_kernel(const float* __restrict__ xproj,
+                                                          const float* __restrict__ whhT_f,
+                                                          const float* __restrict__ whhT_b,
+                                                          const int64_t* __restrict__ lens, int L, int M,
+                                                          float* __restrict__ memory) {
+    __shared__ float hs[256];
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    const float* __restrict__ wT = dir ? whhT_b : whhT_f;
+    const int n = min((int)lens[b], L);
+    float c = 0.f;
+    hs[j] = 0.f;
+    __syncthreads();
+    const float* xp = xproj + ((int64_t)b * 2048 + dir * 1024) * L;
+    for (int s = 0; s < n; ++s) {
+        const int t = dir ? n - 1 - s : s;
+        float g0 = xp[(int64_t)(0 * 256 + j) * L + t], g1 = xp[(int64_t)(1 * 256 + j) * L + t];
+        float g2 = xp[(int64_t)(2 * 256 + j) * L + t], g3 = xp[(int64_t)(3 * 256 + j) * L + t];
+        for (int k = 0; k < 256; ++k) {
+            const float hk = hs[k];
+            const float* wr = wT + (int64_t)k * 1024 + j;
+            g0 = fmaf(wr[0], hk, g0);
+            g1 = fmaf(wr[256], hk, g1);
+            g2 = fmaf(wr[512], hk, g2);
+            g3 = fmaf(wr[768], hk, g3);
+        }
+        c = sigmoidf_(g1) * c + sigmoidf_(g0) * tanhf(g2);
+        const float hn = sigmoidf_(g3) * tanhf(c);
+        __syncthreads();
+        hs[j] = hn;
+        memory[((int64_t)b * L + t) * M + dir * 256 + j] = hn;
+        __syncthreads();
+    }
+}
+
+__global__ void taco_spk_kernel(float* __restrict__ memory, const float* __restrict__ spk, const int64_t* __restrict__ sids,
+                                int L, int M, int E, int S) {
+    const int b = blockIdx.y, t = blockIdx.x, j = threadIdx.x;
+    if (j < S) memory[((int64_t)b * L + t) * M + E + j] = spk[sids[b] * S + j];
+}
+
+// pm[b][t][h] = sum_m memory[b][t][m] * wmT[m][h]      (attention memory_layer, no bias)
+__global__ __launch_bounds__(128) void taco_pm_kernel(const float* __restrict__ memory, const float* __restrict__ wmT,
+                                                      int L, int M, float* __restrict__ pm) {
+    const int b = blockIdx.y, t = blockIdx.x, hh = threadIdx.x;
+    const float* mr = memory + ((int64_t)b * L + t) * M;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc = fmaf(mr[m], wmT[(int64_t)m * 128 + hh], acc);
+    pm[((int64_t)b * L + t) * 128 + hh] = acc;
+}
+
+__device__ __forceinline__ float taco_keep(unsigned seed, unsigned layer, unsigned step, unsigned b, unsigned j) {
+    unsigned x = seed * 0x9E3779B1u + layer * 0x85EBCA77u + step * 0xC2B2AE3Du + b * 0x27D4EB2Fu + j * 0x165667B1u;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return (x & 1u) ? 2.0f : 0.0f;
+}
+
+// prenet: 2 x [Linear(no bias) + ReLU + dropout(p=0.5, always on upstream)]; one block per utterance
+__global__ __launch_bounds__(256) void taco_prenet_kernel(const float* __restrict__ dec_in, const float* __restrict__ w0T,
+                                                          const float* __restrict__ w1T, int n_mels, long long seed,
+                                                          int step, float* __restrict__ out) {
+    __shared__ float xin[128], h0[256];
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j < n_mels) xin[j] = dec_in[(int64_t)b * n_mels + j];
+    __syncthreads();
+    float a = 0.f;
+    for (int k = 0; k < n_mels; ++k) a = fmaf(w0T[(int64_t)k * 256 + j], xin[k], a);
+    a = fmaxf(a, 0.f);
+    if (seed >= 0) a *= taco_keep((unsigned)seed, 0u, (unsigned)step, (unsigned)b, (unsigned)j);
+    h0[j] = a;
+    __syncthreads();
+    float c = 0.f;
+    for (int k = 0; k < 256; ++k) c = fmaf(w1T[(int64_t)k * 256 + j], h0[k], c);
+    c = fmaxf(c, 0.f);
+    if (seed >= 0) c *= taco_keep((unsigned)seed, 1u, (unsigned)step, (unsigned)b, (unsigned)j);
+    out[(int64_t)b * 256 + j] = c;
+}
+
+// LSTMCell as a weight-streaming GEMV: one wave64 per hidden unit (its 4 gate rows), 4 units per block.
+// x = [x1 (n1) | x2 (n2)], gates = W_ih x + W_hh h + bias (= b_ih + b_hh); c updated in place, h ping-pong.
+__global__ __launch_bounds__(256) void taco_lstm_kernel(const float* __restrict__ x1, int n1,
+                                                        const float* __restrict__ x2, int n2,
+                                                        const float* __restrict__ h_in, float* __restrict__ c,
+                                                        const float* __restrict__ wih, const float* __restrict__ whh,
+                                                        const float* __restrict__ bias, float* __restrict__ h_out,
+                                                        int B, int H) {
+    const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= H) return;
+    const int K1 = n1 + n2;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[4][8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) acc[g][bb] = 0.f;
+        for (int k = lane; k < K1; k += 64) {
+            float wv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wv[g] = wih[((int64_t)g * H + u) * K1 + k];
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const int b = min(b0 + bb, B - 1);
+                const float xv = k < n1 ? x1[(int64_t)b * n1 + k] : x2[(int64_t)b * n2 + (k - n1)];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g][bb] = fmaf(wv[g], xv, acc[g][bb]);
+            }
+        }
+        for (int k = lane; k < H; k += 64) {
+            float wv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wv[g] = whh[((int64_t)g * H + u) * H + k];
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const int b = min(b0 + bb, B - 1);
+                const float hv = h_in[(int64_t)b * H + k];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g][bb] = fmaf(wv[g], hv, acc[g][bb]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb)
+                for (int o = 32; o > 0; o >>= 1) acc[g][bb] += __shfl_xor(acc[g][bb], o);
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            if (lane == bb && b0 + bb < B) {
+                const int b = b0 + bb;
+                const float gi = acc[0][bb] + bias[u], gf = acc[1][bb] + bias[H + u];
+                const float gg = acc[2][bb] + bias[2 * H + u], go = acc[3][bb] + bias[3 * H + u];
+                const float cn = sigmoidf_(gf) * c[(int64_t)b * H + u] + sigmoidf_(gi) * tanhf(gg);
+                c[(int64_t)b * H + u] = cn;
+                h_out[(int64_t)b * H + u] = sigmoidf_(go) * tanhf(cn);
+            }
+        }
+    }
+}
+
+// Location-sensitive attention, one block per utterance.
+constexpr int TACO_LMAX = 1024;
+__global__ __launch_bounds__(256) void taco_attention_kernel(const float* __restrict__ att_h, int A,
+                                                             const float* __restrict__ wqT,
+                                                             const float* __restrict__ pm,
+                                                             const float* __restrict__ loc_conv, int KS,
+                                                             const float* __restrict__ loc_denseT,
+                                                             const float* __restrict__ v,
+                                                             const float* __restrict__ memory, int M,
+                                                             const int64_t* __restrict__ lens, int L,
+                                                             float* __restrict__ aw, float* __restrict__ aw_cum,
+                                                             float* __restrict__ ctx, float* __restrict__ align_out,
+                                                             int Tcap, int step) {
+    __shared__ float pq[128], pqh[128], aws[TACO_LMAX + 64], cums[TACO_LMAX + 64], es[TACO_LMAX], red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min((int)lens[b], L);
+    const int half = (KS - 1) / 2;
+    {   // processed query: 128 outputs, K = A split over two thread halves
+        const int hh = tid & 127, part = tid >> 7;
+        const float* ah = att_h + (int64_t)b * A;
+        float a = 0.f;
+        for (int k = part * (A / 2); k < (part + 1) * (A / 2); ++k) a = fmaf(wqT[(int64_t)k * 128 + hh], ah[k], a);
+        if (part) pqh[hh] = a;
+        __syncthreads();
+        if (!part) pq[hh] = a + pqh[hh];
+    }
+    for (int t = tid; t < L + 2 * half; t += 256) {
+        const int s = t - half;
+        aws[t] = (s >= 0 && s < L) ? aw[(int64_t)b * L + s] : 0.f;
+        cums[t] = (s >= 0 && s < L) ? aw_cum[(int64_t)b * L + s] : 0.f;
+    }
+    __syncthreads();
+    for (int t = tid; t < L; t += 256) {
+        float f[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) f[q] = 0.f;
+        for (int k = 0; k < KS; ++k) {
+            const float a0 = aws[t + k], a1 = cums[t + k];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) f[q] = fmaf(loc_conv[(q * 2 + 0) * KS + k], a0, fmaf(loc_conv[(q * 2 + 1) * KS + k], a1, f[q]));
+        }
+        const float* pmr = pm + ((int64_t)b * L + t) * 128;
+        float e = 0.f;
+        for (int hh = 0; hh < 128; ++hh) {
+            float pl = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) pl = fmaf(loc_denseT[q * 128 + hh], f[q], pl);
+            e = fmaf(v[hh], tanhf(pq[hh] + pl + pmr[hh]), e);
+        }
+        es[t] = t < n ? e : -INFINITY;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = tid; t < L; t += 256) mx = fmaxf(mx, es[t]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sm = 0.f;
+    for (int t = tid; t < L; t += 256) {
+        const float p = expf(es[t] - mx);
+        es[t] = p;
+        sm += p;
+    }
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sm;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int t = tid; t < L; t += 256) {
+        const float w = es[t] * inv;
+        es[t] = w;
+        aw[(int64_t)b * L + t] = w;
+        aw_cum[(int64_t)b * L + t] += w;
+        align_out[((int64_t)b * Tcap + step) * L + t] = w;
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += 256) {
+        float a = 0.f;
+        for (int t = 0; t < n; ++t) a = fmaf(es[t], memory[((int64_t)b * L + t) * M + m], a);
+        ctx[(int64_t)b * M + m] = a;
+    }
+}
+
+// mel projection (rows 0..79) + gate (row 80) from [dec_h | ctx]; stop bookkeeping as torchaudio's
+// _Decoder.infer: lengths[~finished] += 1, then finished |= sigmoid(gate) > threshold.
+__global__ __launch_bounds__(256) void taco_proj_kernel(const float* __restrict__ dec_h, int D,
+                                                        const float* __restrict__ ctx, int M,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int n_mels, float thr, int step, int Tcap,
+                                                        float* __restrict__ mel_out, float* __restrict__ dec_in,
+                                                        int32_t* __restrict__ mel_lens, int32_t* __restrict__ finished) {
+    __shared__ float gate_s;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int K = D + M;
+    for (int r = wid; r <= n_mels; r += 4) {
+        const float* wr = w + (int64_t)r * K;
+        float a = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float xv = k < D ? dec_h[(int64_t)b * D + k] : ctx[(int64_t)b * M + (k - D)];
+            a = fmaf(wr[k], xv, a);
+        }
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) {
+            a += bias[r];
+            if (r < n_mels) {
+                mel_out[((int64_t)b * n_mels + r) * Tcap + step] = a;
+                dec_in[(int64_t)b * n_mels + r] = a;
+            } else {
+                gate_s = a;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!finished[b]) mel_lens[b] += 1;
+        if (sigmoidf_(gate_s) > thr) finished[b] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------ host
+
+struct TWs {
+    float *x0, *x1, *xproj, *memory, *pm, *pre, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
+    float *post0, *post1;
+    int32_t* finished;
+};
+
+static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
+    const ttsamd_tacotron2_cfg& c = h->cfg;
+    const int E = c.encoder_embedding_dim, M = h->mem_dim;
+    w.x0 = a.take<float>((int64_t)B * E * L);
+    w.x1 = a.take<float>((int64_t)B * E * L);
+    w.xproj = a.take<float>((int64_t)B * 4 * E * L);
+    w.memory = a.take<float>((int64_t)B * L * M);
+    w.pm = a.take<float>((int64_t)B * L * 128);
+    w.pre = a.take<float>((int64_t)B * c.prenet_dim);
+    for (int i = 0; i < 2; ++i) w.att_h[i] = a.take<float>((int64_t)B * c.attention_rnn_dim);
+    w.att_c = a.take<float>((int64_t)B * c.attention_rnn_dim);
+    for (int i = 0; i < 2; ++i) w.dec_h[i] = a.take<float>((int64_t)B * c.decoder_rnn_dim);
+    w.dec_c = a.take<float>((int64_t)B * c.decoder_rnn_dim);
+    w.aw = a.take<float>((int64_t)B * L);
+    w.aw_cum = a.take<float>((int64_t)B * L);
+    w.ctx = a.take<float>((int64_t)B * M);
+    w.dec_in = a.take<float>((int64_t)B * c.n_mels);
+    w.post0 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
+    w.post1 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
+    w.finished = a.take<int32_t>(B);
+}
+
+int64_t tacotron2_workspace_bytes(const Taco2* h, int32_t B, int32_t L, int32_t Tcap) {
+    Arena a(nullptr, 0);
+    TWs w;
+    tcarve(h, a, B, L, Tcap, w);
+    return a.off;
+}
+
+static int32_t tconv(const Taco2* h, const TConv& c, const float* x, int64_t x_bs, int x_cs, float* y, int64_t y_bs,
+                     int y_cs, const float* res, int B, int T, int act, hipStream_t s) {
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x; p.x_bs = x_bs; p.x_cs = x_cs;
+    p.w = h->dev + c.w_off; p.bias = h->dev + c.b_off;
+    p.w_bf16 = h->dev16 + c.w16_off; p.precision = default_precision();
+    p.y = y; p.y_bs = y_bs; p.y_cs = y_cs; p.y_ts = 1;
+    p.res = res; p.r_bs = y_bs; p.r_cs = y_cs;
+    p.len_in_mul = 1; p.len_out_mul = 1; p.Lin = T; p.Nout = T;
+    p.Cin = c.cin; p.Cout = c.cout; p.CoutP = cout_padded(c.cout); p.K = c.k;
+    p.dil = 1; p.pad = c.k / 2; p.n_phase = 1; p.in_slope = 1.f; p.relu_out = act; p.mode = 0; p.div = 1.f; p.batch = B;
+    prof_begin(s, 2.0 * c.cout * c.cin * c.k);
+    const int32_t rc = launch_conv(p, s);
+    prof_end(s);
+    return rc;
+}
+
+int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* lengths, const int64_t* speaker_ids,
+                        int32_t B, int32_t L, int32_t max_step, int64_t dropout_seed, float* mel_post,
+                        int32_t* mel_lens, float* alignments, float* mel_raw, int32_t* n_steps_out, void* ws,
+                        int64_t ws_bytes, hipStream_t s) {
+    TTS_REQUIRE(h && tokens && lengths && mel_post && mel_lens && alignments && mel_raw && n_steps_out,
+                "tacotron2_infer: null argument");
+    TTS_REQUIRE(B >= 1 && L >= 1 && L <= TACO_LMAX && max_step >= 1, "tacotron2_infer: bad batch/length/max_step");
+    const ttsamd_tacotron2_cfg& c = h->cfg;
+    TTS_REQUIRE(c.num_speakers <= 1 || speaker_ids, "tacotron2_infer: speaker_ids is null");
+    Arena a(ws, ws_bytes);
+    TWs w;
+    const int Tcap = max_step;
+    tcarve(h, a, B, L, Tcap, w);
+    if (!ws || !a.ok) {
+        set_error("tacotron2_infer: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
+        return TTSAMD_ENOMEM;
+    }
+    const int E = c.encoder_embedding_dim, M = h->mem_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, P = c.prenet_dim;
+    const float* W = h->dev;
+    // ---- encoder
+    hipLaunchKernelGGL(taco_embed_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, tokens, W + h->emb, E, L, w.x0);
+    TTS_CHECK_HIP(hipGetLastError());
+    float *cur = w.x0, *nxt = w.x1;
+    for (const TConv& cv : h->enc_convs) {
+        TTS_TRY(tconv(h, cv, cur, (int64_t)E * L, L, nxt, (int64_t)E * L, L, nullptr, B, L, 1, s));
+        std::swap(cur, nxt);
+    }
+    TTS_TRY(tconv(h, h->enc_xproj, cur, (int64_t)E * L, L, w.xproj, (int64_t)4 * E * L, L, nullptr, B, L, 0, s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.memory, 0, (size_t)B * L * M * sizeof(float), s));
+    hipLaunchKernelGGL(taco_bilstm_kernel, dim3(B, 2), dim3(256), 0, s, w.xproj, W + h->enc_whhT[0], W + h->enc_whhT[1],
+                       lengths, L, M, w.memory);
+    if (c.num_speakers > 1)
+        hipLaunchKernelGGL(taco_spk_kernel, dim3(L, B), dim3(128), 0, s, w.memory, W + h->spk, speaker_ids, L, M, E,
+                           c.speaker_embedding_dim);
+    hipLaunchKernelGGL(taco_pm_kernel, dim3(L, B), dim3(128), 0, s, w.memory, W + h->wmT, L, M, w.pm);
+    TTS_CHECK_HIP(hipGetLastError());
+    // ---- decoder state
+    TTS_CHECK_HIP(hipMemsetAsync(w.att_h[0], 0, (size_t)B * A * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.att_c, 0, (size_t)B * A * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.dec_h[0], 0, (size_t)B * D * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.dec_c, 0, (size_t)B * D * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.aw, 0, (size_t)B * L * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.aw_cum, 0, (size_t)B * L * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.ctx, 0, (size_t)B * M * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.dec_in, 0, (size_t)B * c.n_mels * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.finished, 0, (size_t)B * sizeof(int32_t), s));
+    TTS_CHECK_HIP(hipMemsetAsync(mel_lens, 0, (size_t)B * sizeof(int32_t), s));
+    std::vector<int32_t> fin(B);
+    int steps = 0;
+    for (int step = 0; step < max_step; ++step) {
+        const int pi = step & 1, po = pi ^ 1;
+        hipLaunchKernelGGL(taco_prenet_kernel, dim3(B), dim3(256), 0, s, w.dec_in, W + h->pre0T, W + h->pre1T, c.n_mels,
+                           (long long)dropout_seed, step, w.pre);
+        hipLaunchKernelGGL(taco_lstm_kernel, dim3((A + 3) / 4), dim3(256), 0, s, w.pre, P, w.ctx, M, w.att_h[pi], w.att_c,
+                           W + h->att_wih, W + h->att_whh, W + h->att_b, w.att_h[po], B, A);
+        hipLaunchKernelGGL(taco_attention_kernel, dim3(B), dim3(256), 0, s, w.att_h[po], A, W + h->wqT, w.pm,
+                           W + h->loc_conv, c.attention_location_kernel_size, W + h->loc_denseT, W + h->v, w.memory, M,
+                           lengths, L, w.aw, w.aw_cum, w.ctx, alignments, Tcap, step);
+        hipLaunchKernelGGL(taco_lstm_kernel, dim3((D + 3) / 4), dim3(256), 0, s, w.att_h[po], A, w.ctx, M, w.dec_h[pi],
+                           w.dec_c, W + h->dec_wih, W + h->dec_whh, W + h->dec_b, w.dec_h[po], B, D);
+        hipLaunchKernelGGL(taco_proj_kernel, dim3(B), dim3(256), 0, s, w.dec_h[po], D, w.ctx, M, W + h->proj_w,
+                           W + h->proj_b, c.n_mels, c.gate_threshold, step, Tcap, mel_raw, w.dec_in, mel_lens, w.finished);
+        TTS_CHECK_HIP(hipGetLastError());
+        steps = step + 1;
+        if ((steps % 8) == 0 || steps == max_step) {          // the reference breaks as soon as all are finished
+            TTS_CHECK_HIP(hipMemcpyAsync(fin.data(), w.finished, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            TTS_CHECK_HIP(hipStreamSynchronize(s));
+            bool all = true;
+            for (int b = 0; b < B; ++b) all = all && fin[b];
+            if (all) break;
+        }
+    }
+    // number of frames the reference would have produced: it stops at the step the last utterance finishes
+    std::vector<int32_t> lens_h(B);
+    TTS_CHECK_HIP(hipMemcpyAsync(lens_h.data(), mel_lens, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TTS_CHECK_HIP(hipStreamSynchronize(s));
+    int T = 0;
+    for (int b = 0; b < B; ++b) T = std::max(T, (int)lens_h[b]);
+    T = std::min(T, steps);
+    *n_steps_out = T;
+    // ---- postnet on [B][80][T] (row stride Tcap), residual fused into the last conv
+    const float* px = mel_raw;
+    int64_t px_bs = (int64_t)c.n_mels * Tcap;
+    int px_cs = Tcap;
+    float* bufs[2] = {w.post0, w.post1};
+    const int np_ = (int)h->post_convs.size();
+    for (int i = 0; i < np_; ++i) {
+        const TConv& cv = h->post_convs[i];
+        const bool last = i == np_ - 1;
+        float* y = last ? mel_post : bufs[i & 1];
+        const int64_t y_bs = last ? (int64_t)c.n_mels * Tcap : (int64_t)cv.cout * T;
+        const int y_cs = last ? Tcap : T;
+        TTS_TRY(tconv(h, cv, px, px_bs, px_cs, y, y_bs, y_cs, last ? mel_raw : nullptr, B, T, last ? 0 : 3, s));
+        px = y; px_bs = y_bs; px_cs = y_cs;
+    }
+    return 0;
+}
+
+}  // namespace ttsamd

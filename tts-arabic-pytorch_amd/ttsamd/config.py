@@ -44,5 +44,16 @@ VOCOS_22K_CONFIG = {
     'n_fft': 1024, 'hop_length': 256, 'padding': 'same',
 }
 
+# models/tacotron2/tacotron2_ms.py:152-205 constructor defaults as instantiated by
+# models/tacotron2/networks.py:71-82 (n_symbol=40, decoder_max_step=3000)
+TACOTRON2_CONFIG = {
+    'n_mels': 80, 'n_symbol': 40, 'num_speakers': 40, 'speaker_embedding_dim': 128,
+    'symbol_embedding_dim': 512, 'encoder_embedding_dim': 512, 'encoder_n_convolution': 3,
+    'encoder_kernel_size': 5, 'decoder_rnn_dim': 1024, 'decoder_max_step': 3000,
+    'attention_rnn_dim': 1024, 'attention_hidden_dim': 128, 'attention_location_n_filter': 32,
+    'attention_location_kernel_size': 31, 'prenet_dim': 256, 'postnet_n_convolution': 5,
+    'postnet_kernel_size': 5, 'postnet_embedding_dim': 512, 'gate_threshold': 0.5,
+}
+
 SAMPLE_RATE = 22050
 HOP = 256

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG
+from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG, TACOTRON2_CONFIG
 
 
 def _require_gpu():
@@ -286,6 +286,64 @@ class VocosEngine:
             L.check(self.lib.ttsamd_vocos_forward(self.handle, _ptr(mel), _ptr(lens), B, T, float(denoise), _ptr(bias),
                                                   _ptr(wave), _ptr(ws), nb, _stream()), 'vocos_forward')
         return wave
+
+
+class Tacotron2Engine:
+    """Handle over ttsamd_tacotron2_* (replaces Tacotron2MS.infer, models/tacotron2/tacotron2_ms.py:279-332)."""
+
+    def __init__(self, state_dict, config=None, device='cuda'):
+        self.lib = _require_gpu()
+        self.device = torch.device(device if device != 'cuda' else 'cuda:0')
+        c = dict(TACOTRON2_CONFIG if config is None else config)
+        self.config = c
+        cfg = L.Tacotron2Cfg()
+        for name, _ in L.Tacotron2Cfg._fields_:
+            setattr(cfg, name, c[name])
+        arr, keep = L.make_tensors(state_dict)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ttsamd_tacotron2_create(arr, len(arr), C.byref(cfg), C.byref(handle)), 'tacotron2_create')
+        self.handle = handle
+        self.ws = _Workspace()
+        self.n_mels = c['n_mels']
+        self.max_decoder_steps = c.get('decoder_max_step', 2000)
+
+    def __del__(self):
+        if getattr(self, 'handle', None):
+            self.lib.ttsamd_tacotron2_destroy(self.handle)
+            self.handle = None
+
+    def infer(self, tokens, speaker_ids=None, lengths=None, max_step=None, dropout_seed=-1):
+        """tokens int64 [B,L] -> (mel_postnet [B,80,T], mel_lens int32 [B], alignments [B,T,L]);
+        dropout_seed None draws a fresh seed per call (the reference's always-on prenet dropout)."""
+        tokens = tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        B, Ltok = tokens.shape
+        if lengths is None:
+            lengths = torch.full((B,), Ltok, dtype=torch.int64)
+        lengths = lengths.to(device=self.device, dtype=torch.int64).contiguous()
+        if self.config['num_speakers'] > 1:
+            if speaker_ids is None:
+                speaker_ids = torch.zeros(B, dtype=torch.int64)
+            speaker_ids = speaker_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        else:
+            speaker_ids = None
+        max_step = int(self.max_decoder_steps if max_step is None else max_step)
+        if dropout_seed is None:
+            dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        mel_post = torch.zeros(B, self.n_mels, max_step, dtype=torch.float32, device=self.device)
+        mel_raw = torch.zeros(B, self.n_mels, max_step, dtype=torch.float32, device=self.device)
+        mel_lens = torch.zeros(B, dtype=torch.int32, device=self.device)
+        align = torch.zeros(B, max_step, Ltok, dtype=torch.float32, device=self.device)
+        n_steps = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            nb = self.lib.ttsamd_tacotron2_workspace_bytes(self.handle, B, Ltok, max_step)
+            ws = self.ws.get(nb, self.device)
+            L.check(self.lib.ttsamd_tacotron2_infer(self.handle, _ptr(tokens), _ptr(lengths), _ptr(speaker_ids), B, Ltok,
+                                                    max_step, int(dropout_seed), _ptr(mel_post), _ptr(mel_lens),
+                                                    _ptr(align), _ptr(mel_raw), C.byref(n_steps), _ptr(ws), nb,
+                                                    _stream()), 'tacotron2_infer')
+        T = n_steps.value
+        return mel_post[:, :, :T], mel_lens, align[:, :T]
 
 
 def conv1d(x, w, bias=None, lens=None, dilation=1, in_slope=1.0, relu_out=False):

@@ -33,6 +33,15 @@ class FastPitchCfg(C.Structure):
         'n_speakers')] + [('speaker_emb_weight', C.c_float)]
 
 
+class Tacotron2Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'n_symbol', 'num_speakers', 'speaker_embedding_dim', 'symbol_embedding_dim', 'encoder_embedding_dim',
+        'encoder_n_convolution', 'encoder_kernel_size', 'n_mels', 'prenet_dim', 'attention_rnn_dim',
+        'decoder_rnn_dim', 'attention_hidden_dim', 'attention_location_n_filter',
+        'attention_location_kernel_size', 'postnet_n_convolution', 'postnet_kernel_size',
+        'postnet_embedding_dim')] + [('gate_threshold', C.c_float)]
+
+
 # every symbol include/ttsamd.h declares: name -> (restype, argtypes)
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -61,6 +70,11 @@ SYMBOLS = {
     'ttsamd_vocos_workspace_bytes': (_I64, [_P, _I32, _I32]),
     'ttsamd_vocos_bias_vec': (_I32, [_P, _P, _P, _I64, _P]),
     'ttsamd_vocos_forward': (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _P, _P, _I64, _P]),
+    'ttsamd_tacotron2_create': (_I32, [C.POINTER(Tensor), _I32, C.POINTER(Tacotron2Cfg), C.POINTER(_P)]),
+    'ttsamd_tacotron2_destroy': (_I32, [_P]),
+    'ttsamd_tacotron2_workspace_bytes': (_I64, [_P, _I32, _I32, _I32]),
+    'ttsamd_tacotron2_infer': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P, _P,
+                                      C.POINTER(_I32), _P, _I64, _P]),
     'ttsamd_conv1d_packed_floats': (_I64, [_I32, _I32, _I32]),
     'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     'ttsamd_set_precision': (_I32, [_I32]),

@@ -13,7 +13,7 @@ import zlib
 
 import numpy as np
 
-from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG
+from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG, TACOTRON2_CONFIG
 
 
 def _rng(seed, name):
@@ -169,6 +169,67 @@ def vocos_state_dict(config=None, seed=0):
     b = _normal(seed, 'vocos.head.b', (nout,), 0.3)
     b[:nout // 2] -= 0.3
     sd['head.out.bias'] = b
+    return sd
+
+
+def _bn(sd, seed, name, n):
+    sd[name + '.weight'] = 1.0 + _normal(seed, name + '.w', (n,), 0.1)
+    sd[name + '.bias'] = _normal(seed, name + '.b', (n,), 0.1)
+    sd[name + '.running_mean'] = _normal(seed, name + '.rm', (n,), 0.1)
+    sd[name + '.running_var'] = (1.0 + 0.2 * _rng(seed, name + '.rv').random(n)).astype(np.float32)
+
+
+def _lstm(sd, seed, name, n_in, n_h, suffixes=('',)):
+    k = 1.0 / np.sqrt(n_h)
+    for sfx in suffixes:
+        sd[f'{name}.weight_ih{sfx}'] = ((_rng(seed, f'{name}.wih{sfx}').random((4 * n_h, n_in)) * 2 - 1) * k).astype(np.float32)
+        sd[f'{name}.weight_hh{sfx}'] = ((_rng(seed, f'{name}.whh{sfx}').random((4 * n_h, n_h)) * 2 - 1) * k).astype(np.float32)
+        sd[f'{name}.bias_ih{sfx}'] = ((_rng(seed, f'{name}.bih{sfx}').random(4 * n_h) * 2 - 1) * k).astype(np.float32)
+        sd[f'{name}.bias_hh{sfx}'] = ((_rng(seed, f'{name}.bhh{sfx}').random(4 * n_h) * 2 - 1) * k).astype(np.float32)
+
+
+def tacotron2_state_dict(config=None, seed=0, gate_bias=-2.0):
+    """Tacotron2MS state_dict (models/tacotron2/tacotron2_ms.py:152-212) with the parameter names of
+    torchaudio.models.tacotron2's private _Encoder/_Decoder/_Postnet as publicly documented
+    (embedding, encoder.convolutions.i.{0,1}, encoder.lstm.*_l0[_reverse], decoder.prenet.layers.i,
+    decoder.attention_rnn, decoder.attention_layer.{query_layer,memory_layer,v,location_layer.*},
+    decoder.decoder_rnn, decoder.linear_projection, decoder.gate_layer, postnet.convolutions.i.{0,1},
+    speaker_embedding).  torchaudio is absent here, so these names are NOT verified against it."""
+    c = dict(TACOTRON2_CONFIG if config is None else config)
+    sd = {}
+    E, S = c['encoder_embedding_dim'], c['speaker_embedding_dim']
+    M = E + (S if c['num_speakers'] > 1 else 0)
+    sd['embedding.weight'] = _normal(seed, 'taco.emb', (c['n_symbol'], c['symbol_embedding_dim']), 0.5)
+    if c['num_speakers'] > 1:
+        sd['speaker_embedding.weight'] = _normal(seed, 'taco.spk', (c['num_speakers'], S), 0.5)
+    k = c['encoder_kernel_size']
+    for i in range(c['encoder_n_convolution']):
+        sd[f'encoder.convolutions.{i}.0.weight'] = _normal(seed, f'taco.enc.conv{i}.w', (E, E, k), 1.4 / np.sqrt(E * k))
+        sd[f'encoder.convolutions.{i}.0.bias'] = _normal(seed, f'taco.enc.conv{i}.b', (E,), 0.1)
+        _bn(sd, seed, f'encoder.convolutions.{i}.1', E)
+    _lstm(sd, seed, 'encoder.lstm', E, E // 2, ('_l0', '_l0_reverse'))
+    P, A, D, H = c['prenet_dim'], c['attention_rnn_dim'], c['decoder_rnn_dim'], c['attention_hidden_dim']
+    sd['decoder.prenet.layers.0.weight'] = _normal(seed, 'taco.pre0', (P, c['n_mels']), 1.4 / np.sqrt(c['n_mels']))
+    sd['decoder.prenet.layers.1.weight'] = _normal(seed, 'taco.pre1', (P, P), 1.4 / np.sqrt(P))
+    _lstm(sd, seed, 'decoder.attention_rnn', P + M, A)
+    sd['decoder.attention_layer.query_layer.weight'] = _normal(seed, 'taco.att.q', (H, A), 1.0 / np.sqrt(A))
+    sd['decoder.attention_layer.memory_layer.weight'] = _normal(seed, 'taco.att.m', (H, M), 1.0 / np.sqrt(M))
+    sd['decoder.attention_layer.v.weight'] = _normal(seed, 'taco.att.v', (1, H), 3.0 / np.sqrt(H))
+    nf, ks = c['attention_location_n_filter'], c['attention_location_kernel_size']
+    sd['decoder.attention_layer.location_layer.location_conv.weight'] = _normal(seed, 'taco.att.lc', (nf, 2, ks), 1.0)
+    sd['decoder.attention_layer.location_layer.location_dense.weight'] = _normal(seed, 'taco.att.ld', (H, nf), 1.0 / np.sqrt(nf))
+    _lstm(sd, seed, 'decoder.decoder_rnn', A + M, D)
+    sd['decoder.linear_projection.weight'] = _normal(seed, 'taco.proj.w', (c['n_mels'], D + M), 2.0 / np.sqrt(D + M))
+    sd['decoder.linear_projection.bias'] = _normal(seed, 'taco.proj.b', (c['n_mels'],), 0.5)
+    sd['decoder.gate_layer.weight'] = _normal(seed, 'taco.gate.w', (1, D + M), 6.0 / np.sqrt(D + M))
+    sd['decoder.gate_layer.bias'] = np.full((1,), gate_bias, np.float32)
+    PE, pk, n = c['postnet_embedding_dim'], c['postnet_kernel_size'], c['postnet_n_convolution']
+    for i in range(n):
+        cin = c['n_mels'] if i == 0 else PE
+        cout = c['n_mels'] if i == n - 1 else PE
+        sd[f'postnet.convolutions.{i}.0.weight'] = _normal(seed, f'taco.post{i}.w', (cout, cin, pk), 1.0 / np.sqrt(cin * pk))
+        sd[f'postnet.convolutions.{i}.0.bias'] = _normal(seed, f'taco.post{i}.b', (cout,), 0.1)
+        _bn(sd, seed, f'postnet.convolutions.{i}.1', cout)
     return sd
 
 
