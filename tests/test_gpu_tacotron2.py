@@ -145,7 +145,7 @@ def taco_ckpt(tmp_path_factory, synth_weights):
     import text
     from ttsamd.config import HIFIGAN_CONFIG
     d = tmp_path_factory.mktemp('taco')
-    _, sd = _weights(gate_bias=-0.5, seed=1)
+    _, sd = _weights(gate_bias=-0.5, seed=4)   # a seed whose attention peaks on the separator after frame 0
     torch.save({'model': {k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd.items()},
                 'symbols': list(text.symbols)}, d / 'taco.pth')
     torch.save({'generator': {k: torch.from_numpy(v.copy()) for k, v in synth_weights['hifigan'].items()}}, d / 'hg.pth')
@@ -154,7 +154,7 @@ def taco_ckpt(tmp_path_factory, synth_weights):
     return str(d / 'taco.pth'), str(d / 'hg.pth'), str(d / 'config.json')
 
 
-LINES = ["اَلسَّلامُ عَلَيكُم يَا صَدِيقِي", "صِفر", "أَربَعَة", "ثَلاثَة"]
+LINES = ["اَلسَّلامُ عَلَيكُم يَا صَدِيقِي", "صِفر", "أَربَعَة", "كِتَاب", "ثَلاثَة"]
 
 
 def test_dropin_tacotron2_ttmel(dev, taco_ckpt):
@@ -222,7 +222,7 @@ def test_dropin_tacotron2wave_tts(dev, taco_ckpt):
     model.model.dropout_seed = -1
     # the one ragged vocoder launch of tts_batch == the reference's per-mel loop (:340-346)
     mels = model.model.ttmel_batch(LINES)
-    batched = model.tts(LINES, batch_size=4, denoise=0.005)
+    batched = model.tts(LINES, batch_size=8, denoise=0.005)
     assert len(batched) == len(LINES)
     for mel, wav in zip(mels, batched):
         one = model.denoiser(model.vocoder(mel), 0.005)[0].cpu()
