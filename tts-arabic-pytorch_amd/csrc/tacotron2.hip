@@ -35,7 +35,7 @@ struct Taco2 {
     int64_t enc_whhT[2];
     int64_t pre0T, pre1T;
     int64_t att_wih, att_whh, att_b, dec_wih, dec_whh, dec_b;
-    int64_t wqT, wmT, v, loc_conv, loc_denseT;
+    int64_t wq, wmT, v, loc_conv, loc_denseT;
     int64_t proj_w, proj_b;
     int mem_dim = 0;
 };
@@ -164,7 +164,7 @@ int32_t tacotron2_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_t
     h->att_wih = b.raw("decoder.attention_rnn.weight_ih", (int64_t)4 * A * (P + M));
     h->att_whh = b.raw("decoder.attention_rnn.weight_hh", (int64_t)4 * A * A);
     h->att_b = b.bias_sum("decoder.attention_rnn.bias_ih", "decoder.attention_rnn.bias_hh", 4 * A);
-    h->wqT = b.transposed("decoder.attention_layer.query_layer.weight", Hd, A);
+    h->wq = b.raw("decoder.attention_layer.query_layer.weight", (int64_t)Hd * A);
     h->wmT = b.transposed("decoder.attention_layer.memory_layer.weight", Hd, M);
     h->v = b.raw("decoder.attention_layer.v.weight", Hd);
     h->loc_conv = b.raw("decoder.attention_layer.location_layer.location_conv.weight", (int64_t)NF * 2 * KS);
@@ -312,189 +312,226 @@ __global__ __launch_bounds__(256) void taco_prenet_kernel(const float* __restric
     out[(int64_t)b * 256 + j] = c;
 }
 
-// LSTMCell as a weight-streaming GEMV: one wave64 per hidden unit (its 4 gate rows), 4 units per block.
-// x = [x1 (n1) | x2 (n2)], gates = W_ih x + W_hh h + bias (= b_ih + b_hh); c updated in place, h ping-pong.
+// ---- block-level GEMV pieces of the decoder step ------------------------------------------------
+// The decoder's matrices (75 MB of fp32 LSTM weights, 0.5 MB query, 0.5 MB projection) are streamed once per
+// step: a 256-thread block owns NR output rows, the K axis is split over the threads as float4 and the BC
+// batch columns ride along in registers (x is tiny and L2-resident), then a shuffle + LDS reduction.
+constexpr int TACO_BC = 8;
+
+template <int NR>
+__device__ __forceinline__ void block_dots_acc(const float* __restrict__ w, int64_t row_stride, int K,
+                                               const float* __restrict__ x, int x_stride, int b0, int B,
+                                               float (&acc)[NR][TACO_BC]) {
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        float4 wv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) wv[r] = *reinterpret_cast<const float4*>(w + r * row_stride + k);
+#pragma unroll
+        for (int bb = 0; bb < TACO_BC; ++bb) {
+            const int b = min(b0 + bb, B - 1);
+            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)b * x_stride + k);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                acc[r][bb] = fmaf(wv[r].x, xv.x, fmaf(wv[r].y, xv.y, fmaf(wv[r].z, xv.z, fmaf(wv[r].w, xv.w, acc[r][bb]))));
+        }
+    }
+}
+
+// sums acc over the 256 threads; the totals land in red[r][bb] (valid after the trailing barrier)
+template <int NR>
+__device__ __forceinline__ void block_dots_reduce(float (&acc)[NR][TACO_BC], float (*red)[TACO_BC], float (*part)[NR][TACO_BC]) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int bb = 0; bb < TACO_BC; ++bb) {
+            float v = acc[r][bb];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) part[wid][r][bb] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < NR * TACO_BC) {
+        const int r = threadIdx.x / TACO_BC, bb = threadIdx.x % TACO_BC;
+        red[r][bb] = part[0][r][bb] + part[1][r][bb] + part[2][r][bb] + part[3][r][bb];
+    }
+    __syncthreads();
+}
+
+// LSTMCell: block = hidden unit u (its 4 gate rows); x = [x1 (n1) | x2 (n2)], gates = W_ih x + W_hh h + bias
+// (= b_ih + b_hh); c updated in place, h ping-pong.  n1, n2, H multiples of 4.
 __global__ __launch_bounds__(256) void taco_lstm_kernel(const float* __restrict__ x1, int n1,
                                                         const float* __restrict__ x2, int n2,
                                                         const float* __restrict__ h_in, float* __restrict__ c,
                                                         const float* __restrict__ wih, const float* __restrict__ whh,
                                                         const float* __restrict__ bias, float* __restrict__ h_out,
                                                         int B, int H) {
-    const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= H) return;
+    __shared__ float red[4][TACO_BC], part[4][4][TACO_BC];
+    const int u = blockIdx.x;
     const int K1 = n1 + n2;
-    for (int b0 = 0; b0 < B; b0 += 8) {
-        float acc[4][8];
+    for (int b0 = 0; b0 < B; b0 += TACO_BC) {
+        float acc[4][TACO_BC];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) acc[g][bb] = 0.f;
-        for (int k = lane; k < K1; k += 64) {
-            float wv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) wv[g] = wih[((int64_t)g * H + u) * K1 + k];
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                const int b = min(b0 + bb, B - 1);
-                const float xv = k < n1 ? x1[(int64_t)b * n1 + k] : x2[(int64_t)b * n2 + (k - n1)];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g][bb] = fmaf(wv[g], xv, acc[g][bb]);
-            }
+            for (int bb = 0; bb < TACO_BC; ++bb) acc[g][bb] = 0.f;
+        block_dots_acc<4>(wih + (int64_t)u * K1, (int64_t)H * K1, n1, x1, n1, b0, B, acc);
+        block_dots_acc<4>(wih + (int64_t)u * K1 + n1, (int64_t)H * K1, n2, x2, n2, b0, B, acc);
+        block_dots_acc<4>(whh + (int64_t)u * H, (int64_t)H * H, H, h_in, H, b0, B, acc);
+        block_dots_reduce<4>(acc, red, part);
+        if (threadIdx.x < TACO_BC && b0 + threadIdx.x < B) {
+            const int bb = threadIdx.x, b = b0 + bb;
+            const float gi = red[0][bb] + bias[u], gf = red[1][bb] + bias[H + u];
+            const float gg = red[2][bb] + bias[2 * H + u], go = red[3][bb] + bias[3 * H + u];
+            const float cn = sigmoidf_(gf) * c[(int64_t)b * H + u] + sigmoidf_(gi) * tanhf(gg);
+            c[(int64_t)b * H + u] = cn;
+            h_out[(int64_t)b * H + u] = sigmoidf_(go) * tanhf(cn);
         }
-        for (int k = lane; k < H; k += 64) {
-            float wv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) wv[g] = whh[((int64_t)g * H + u) * H + k];
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                const int b = min(b0 + bb, B - 1);
-                const float hv = h_in[(int64_t)b * H + k];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g][bb] = fmaf(wv[g], hv, acc[g][bb]);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb)
-                for (int o = 32; o > 0; o >>= 1) acc[g][bb] += __shfl_xor(acc[g][bb], o);
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            if (lane == bb && b0 + bb < B) {
-                const int b = b0 + bb;
-                const float gi = acc[0][bb] + bias[u], gf = acc[1][bb] + bias[H + u];
-                const float gg = acc[2][bb] + bias[2 * H + u], go = acc[3][bb] + bias[3 * H + u];
-                const float cn = sigmoidf_(gf) * c[(int64_t)b * H + u] + sigmoidf_(gi) * tanhf(gg);
-                c[(int64_t)b * H + u] = cn;
-                h_out[(int64_t)b * H + u] = sigmoidf_(go) * tanhf(cn);
-            }
-        }
+        __syncthreads();
     }
 }
 
-// Location-sensitive attention, one block per utterance.
+// processed query pq[b][r] = sum_k wq[r][k] att_h[b][k]   (query_layer, no bias); 4 rows per block
+__global__ __launch_bounds__(256) void taco_query_kernel(const float* __restrict__ att_h, int A,
+                                                         const float* __restrict__ wq, float* __restrict__ pq, int B) {
+    __shared__ float red[4][TACO_BC], part[4][4][TACO_BC];
+    const int r0 = blockIdx.x * 4;
+    for (int b0 = 0; b0 < B; b0 += TACO_BC) {
+        float acc[4][TACO_BC];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int bb = 0; bb < TACO_BC; ++bb) acc[g][bb] = 0.f;
+        block_dots_acc<4>(wq + (int64_t)r0 * A, A, A, att_h, A, b0, B, acc);
+        block_dots_reduce<4>(acc, red, part);
+        if (threadIdx.x < 4 * TACO_BC) {
+            const int r = threadIdx.x / TACO_BC, bb = threadIdx.x % TACO_BC;
+            if (b0 + bb < B) pq[(int64_t)(b0 + bb) * 128 + r0 + r] = red[r][bb];
+        }
+        __syncthreads();
+    }
+}
+
+// Location-sensitive attention energies, one wave64 per (utterance, token):
+//   f[q]  = sum_k lc[q][0][k] aw[t+k-h] + lc[q][1][k] cum[t+k-h]        (32 filters; lane halves = the 2 channels)
+//   e[t]  = sum_h v[h] tanh(pq[h] + sum_q ldT[q][h] f[q] + pm[t][h])      (128 hidden units, 2 per lane)
 constexpr int TACO_LMAX = 1024;
-__global__ __launch_bounds__(256) void taco_attention_kernel(const float* __restrict__ att_h, int A,
-                                                             const float* __restrict__ wqT,
-                                                             const float* __restrict__ pm,
-                                                             const float* __restrict__ loc_conv, int KS,
-                                                             const float* __restrict__ loc_denseT,
-                                                             const float* __restrict__ v,
-                                                             const float* __restrict__ memory, int M,
-                                                             const int64_t* __restrict__ lens, int L,
-                                                             float* __restrict__ aw, float* __restrict__ aw_cum,
-                                                             float* __restrict__ ctx, float* __restrict__ align_out,
-                                                             int Tcap, int step) {
-    __shared__ float pq[128], pqh[128], aws[TACO_LMAX + 64], cums[TACO_LMAX + 64], es[TACO_LMAX], red[8];
+__global__ __launch_bounds__(256) void taco_energy_kernel(const float* __restrict__ pq, const float* __restrict__ pm,
+                                                          const float* __restrict__ loc_conv, int KS,
+                                                          const float* __restrict__ loc_denseT,
+                                                          const float* __restrict__ v, const float* __restrict__ aw,
+                                                          const float* __restrict__ aw_cum, int L,
+                                                          float* __restrict__ e) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= L) return;
+    const int q = lane & 31, ch = lane >> 5, half = (KS - 1) / 2;
+    const float* src = (ch ? aw_cum : aw) + (int64_t)b * L;
+    const float* lc = loc_conv + (q * 2 + ch) * KS;
+    float f = 0.f;
+    for (int k = 0; k < KS; ++k) {
+        const int sidx = t + k - half;
+        const float a = (sidx >= 0 && sidx < L) ? src[sidx] : 0.f;
+        f = fmaf(lc[k], a, f);
+    }
+    f += __shfl_xor(f, 32);
+    float pl0 = 0.f, pl1 = 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 32; ++qq) {
+        const float fq = __shfl(f, qq);
+        pl0 = fmaf(loc_denseT[qq * 128 + lane], fq, pl0);
+        pl1 = fmaf(loc_denseT[qq * 128 + 64 + lane], fq, pl1);
+    }
+    const float* pmr = pm + ((int64_t)b * L + t) * 128;
+    const float* pqr = pq + (int64_t)b * 128;
+    float acc = v[lane] * tanhf(pqr[lane] + pl0 + pmr[lane]) + v[64 + lane] * tanhf(pqr[64 + lane] + pl1 + pmr[64 + lane]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) e[(int64_t)b * L + t] = acc;
+}
+
+// masked softmax over the tokens + context vector; grid (B, ceil(M/128)): every block redoes the (tiny)
+// softmax, block y == 0 also publishes aw, aw_cum += aw and the alignment row.
+__global__ __launch_bounds__(128) void taco_context_kernel(const float* __restrict__ e, const float* __restrict__ memory,
+                                                           int M, const int64_t* __restrict__ lens, int L,
+                                                           float* __restrict__ aw, float* __restrict__ aw_cum,
+                                                           float* __restrict__ ctx, float* __restrict__ align_out,
+                                                           int Tcap, int step) {
+    __shared__ float ws[TACO_LMAX], red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = min((int)lens[b], L);
-    const int half = (KS - 1) / 2;
-    {   // processed query: 128 outputs, K = A split over two thread halves
-        const int hh = tid & 127, part = tid >> 7;
-        const float* ah = att_h + (int64_t)b * A;
-        float a = 0.f;
-        for (int k = part * (A / 2); k < (part + 1) * (A / 2); ++k) a = fmaf(wqT[(int64_t)k * 128 + hh], ah[k], a);
-        if (part) pqh[hh] = a;
-        __syncthreads();
-        if (!part) pq[hh] = a + pqh[hh];
-    }
-    for (int t = tid; t < L + 2 * half; t += 256) {
-        const int s = t - half;
-        aws[t] = (s >= 0 && s < L) ? aw[(int64_t)b * L + s] : 0.f;
-        cums[t] = (s >= 0 && s < L) ? aw_cum[(int64_t)b * L + s] : 0.f;
-    }
-    __syncthreads();
-    for (int t = tid; t < L; t += 256) {
-        float f[32];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) f[q] = 0.f;
-        for (int k = 0; k < KS; ++k) {
-            const float a0 = aws[t + k], a1 = cums[t + k];
-#pragma unroll
-            for (int q = 0; q < 32; ++q) f[q] = fmaf(loc_conv[(q * 2 + 0) * KS + k], a0, fmaf(loc_conv[(q * 2 + 1) * KS + k], a1, f[q]));
-        }
-        const float* pmr = pm + ((int64_t)b * L + t) * 128;
-        float e = 0.f;
-        for (int hh = 0; hh < 128; ++hh) {
-            float pl = 0.f;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) pl = fmaf(loc_denseT[q * 128 + hh], f[q], pl);
-            e = fmaf(v[hh], tanhf(pq[hh] + pl + pmr[hh]), e);
-        }
-        es[t] = t < n ? e : -INFINITY;
-    }
-    __syncthreads();
     float mx = -INFINITY;
-    for (int t = tid; t < L; t += 256) mx = fmaxf(mx, es[t]);
+    for (int t = tid; t < n; t += 128) {
+        const float x = e[(int64_t)b * L + t];
+        ws[t] = x;
+        mx = fmaxf(mx, x);
+    }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = fmaxf(red[0], red[1]);
     float sm = 0.f;
-    for (int t = tid; t < L; t += 256) {
-        const float p = expf(es[t] - mx);
-        es[t] = p;
+    for (int t = tid; t < n; t += 128) {
+        const float p = expf(ws[t] - mx);
+        ws[t] = p;
         sm += p;
     }
     for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sm;
+    if ((tid & 63) == 0) red[2 + (tid >> 6)] = sm;
     __syncthreads();
-    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-    for (int t = tid; t < L; t += 256) {
-        const float w = es[t] * inv;
-        es[t] = w;
-        aw[(int64_t)b * L + t] = w;
-        aw_cum[(int64_t)b * L + t] += w;
-        align_out[((int64_t)b * Tcap + step) * L + t] = w;
+    const float inv = 1.0f / (red[2] + red[3]);
+    for (int t = tid; t < n; t += 128) ws[t] *= inv;
+    __syncthreads();
+    if (blockIdx.y == 0) {
+        for (int t = tid; t < L; t += 128) {
+            const float w = t < n ? ws[t] : 0.f;
+            aw[(int64_t)b * L + t] = w;
+            aw_cum[(int64_t)b * L + t] += w;
+            align_out[((int64_t)b * Tcap + step) * L + t] = w;
+        }
     }
-    __syncthreads();
-    for (int m = tid; m < M; m += 256) {
+    const int m = blockIdx.y * 128 + tid;
+    if (m < M) {
+        const float* mr = memory + (int64_t)b * L * M + m;
         float a = 0.f;
-        for (int t = 0; t < n; ++t) a = fmaf(es[t], memory[((int64_t)b * L + t) * M + m], a);
+        for (int t = 0; t < n; ++t) a = fmaf(ws[t], mr[(int64_t)t * M], a);
         ctx[(int64_t)b * M + m] = a;
     }
 }
 
-// mel projection (rows 0..79) + gate (row 80) from [dec_h | ctx]; stop bookkeeping as torchaudio's
-// _Decoder.infer: lengths[~finished] += 1, then finished |= sigmoid(gate) > threshold.
+// mel projection (rows 0..79) + gate (row 80) from [dec_h | ctx], one block per row; stop bookkeeping as
+// torchaudio's _Decoder.infer: lengths[~finished] += 1, then finished |= sigmoid(gate) > threshold.
 __global__ __launch_bounds__(256) void taco_proj_kernel(const float* __restrict__ dec_h, int D,
                                                         const float* __restrict__ ctx, int M,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        int n_mels, float thr, int step, int Tcap,
+                                                        int n_mels, float thr, int step, int Tcap, int B,
                                                         float* __restrict__ mel_out, float* __restrict__ dec_in,
                                                         int32_t* __restrict__ mel_lens, int32_t* __restrict__ finished) {
-    __shared__ float gate_s;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int K = D + M;
-    for (int r = wid; r <= n_mels; r += 4) {
-        const float* wr = w + (int64_t)r * K;
-        float a = 0.f;
-        for (int k = lane; k < K; k += 64) {
-            const float xv = k < D ? dec_h[(int64_t)b * D + k] : ctx[(int64_t)b * M + (k - D)];
-            a = fmaf(wr[k], xv, a);
-        }
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) {
-            a += bias[r];
+    __shared__ float red[1][TACO_BC], part[4][1][TACO_BC];
+    const int r = blockIdx.x, K = D + M;
+    for (int b0 = 0; b0 < B; b0 += TACO_BC) {
+        float acc[1][TACO_BC];
+#pragma unroll
+        for (int bb = 0; bb < TACO_BC; ++bb) acc[0][bb] = 0.f;
+        block_dots_acc<1>(w + (int64_t)r * K, 0, D, dec_h, D, b0, B, acc);
+        block_dots_acc<1>(w + (int64_t)r * K + D, 0, M, ctx, M, b0, B, acc);
+        block_dots_reduce<1>(acc, red, part);
+        if (threadIdx.x < TACO_BC && b0 + threadIdx.x < B) {
+            const int b = b0 + threadIdx.x;
+            const float a = red[0][threadIdx.x] + bias[r];
             if (r < n_mels) {
                 mel_out[((int64_t)b * n_mels + r) * Tcap + step] = a;
                 dec_in[(int64_t)b * n_mels + r] = a;
             } else {
-                gate_s = a;
+                if (!finished[b]) mel_lens[b] += 1;
+                if (sigmoidf_(a) > thr) finished[b] = 1;
             }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!finished[b]) mel_lens[b] += 1;
-        if (sigmoidf_(gate_s) > thr) finished[b] = 1;
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------ host
 
 struct TWs {
-    float *x0, *x1, *xproj, *memory, *pm, *pre, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
+    float *x0, *x1, *xproj, *memory, *pm, *pre, *pq, *energy, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
     float *post0, *post1;
     int32_t* finished;
 };
@@ -508,6 +545,8 @@ static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
     w.memory = a.take<float>((int64_t)B * L * M);
     w.pm = a.take<float>((int64_t)B * L * 128);
     w.pre = a.take<float>((int64_t)B * c.prenet_dim);
+    w.pq = a.take<float>((int64_t)B * 128);
+    w.energy = a.take<float>((int64_t)B * L);
     for (int i = 0; i < 2; ++i) w.att_h[i] = a.take<float>((int64_t)B * c.attention_rnn_dim);
     w.att_c = a.take<float>((int64_t)B * c.attention_rnn_dim);
     for (int i = 0; i < 2; ++i) w.dec_h[i] = a.take<float>((int64_t)B * c.decoder_rnn_dim);
@@ -599,15 +638,18 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         const int pi = step & 1, po = pi ^ 1;
         hipLaunchKernelGGL(taco_prenet_kernel, dim3(B), dim3(256), 0, s, w.dec_in, W + h->pre0T, W + h->pre1T, c.n_mels,
                            (long long)dropout_seed, step, w.pre);
-        hipLaunchKernelGGL(taco_lstm_kernel, dim3((A + 3) / 4), dim3(256), 0, s, w.pre, P, w.ctx, M, w.att_h[pi], w.att_c,
+        hipLaunchKernelGGL(taco_lstm_kernel, dim3(A), dim3(256), 0, s, w.pre, P, w.ctx, M, w.att_h[pi], w.att_c,
                            W + h->att_wih, W + h->att_whh, W + h->att_b, w.att_h[po], B, A);
-        hipLaunchKernelGGL(taco_attention_kernel, dim3(B), dim3(256), 0, s, w.att_h[po], A, W + h->wqT, w.pm,
-                           W + h->loc_conv, c.attention_location_kernel_size, W + h->loc_denseT, W + h->v, w.memory, M,
-                           lengths, L, w.aw, w.aw_cum, w.ctx, alignments, Tcap, step);
-        hipLaunchKernelGGL(taco_lstm_kernel, dim3((D + 3) / 4), dim3(256), 0, s, w.att_h[po], A, w.ctx, M, w.dec_h[pi],
-                           w.dec_c, W + h->dec_wih, W + h->dec_whh, W + h->dec_b, w.dec_h[po], B, D);
-        hipLaunchKernelGGL(taco_proj_kernel, dim3(B), dim3(256), 0, s, w.dec_h[po], D, w.ctx, M, W + h->proj_w,
-                           W + h->proj_b, c.n_mels, c.gate_threshold, step, Tcap, mel_raw, w.dec_in, mel_lens, w.finished);
+        hipLaunchKernelGGL(taco_query_kernel, dim3(128 / 4), dim3(256), 0, s, w.att_h[po], A, W + h->wq, w.pq, B);
+        hipLaunchKernelGGL(taco_energy_kernel, dim3((L + 3) / 4, B), dim3(256), 0, s, w.pq, w.pm, W + h->loc_conv,
+                           c.attention_location_kernel_size, W + h->loc_denseT, W + h->v, w.aw, w.aw_cum, L, w.energy);
+        hipLaunchKernelGGL(taco_context_kernel, dim3(B, (M + 127) / 128), dim3(128), 0, s, w.energy, w.memory, M, lengths,
+                           L, w.aw, w.aw_cum, w.ctx, alignments, Tcap, step);
+        hipLaunchKernelGGL(taco_lstm_kernel, dim3(D), dim3(256), 0, s, w.att_h[po], A, w.ctx, M, w.dec_h[pi], w.dec_c,
+                           W + h->dec_wih, W + h->dec_whh, W + h->dec_b, w.dec_h[po], B, D);
+        hipLaunchKernelGGL(taco_proj_kernel, dim3(c.n_mels + 1), dim3(256), 0, s, w.dec_h[po], D, w.ctx, M, W + h->proj_w,
+                           W + h->proj_b, c.n_mels, c.gate_threshold, step, Tcap, B, mel_raw, w.dec_in, mel_lens,
+                           w.finished);
         TTS_CHECK_HIP(hipGetLastError());
         steps = step + 1;
         if ((steps % 8) == 0 || steps == max_step) {          // the reference breaks as soon as all are finished
