@@ -230,3 +230,26 @@ def test_dropin_tacotron2wave_tts(dev, taco_ckpt):
     assert len(model.tts(LINES, batch_size=1, denoise=0)) == len(LINES)
     with pytest.raises(Exception):
         Tacotron2Wave(taco_ckpt[0], taco_ckpt[1], taco_ckpt[2], n_symbol=len(text.symbols)).tts(LINES[0])  # on the CPU
+
+
+def test_inference_cli_both_models(dev, taco_ckpt, tmp_path, synth_weights):
+    """inference.py twin (reference inference.py:20-64): --list file -> wavs/static<i>.wav at 22 050 Hz."""
+    import inference
+    import text
+    from scipy.io import wavfile
+    from ttsamd.config import NET_CONFIG
+    lst = tmp_path / 'lines.txt'
+    lst.write_text('\n'.join(LINES[:3]) + '\n', encoding='utf-8')
+    fp = {k: torch.from_numpy(v.copy()) for k, v in synth_weights['fastpitch'].items()}
+    torch.save({'model': fp, 'config': dict(NET_CONFIG), 'symbols': list(text.symbols)}, tmp_path / 'fp.pth')
+    for model, ckpt in (('fastpitch', str(tmp_path / 'fp.pth')), ('tacotron2', taco_ckpt[0])):
+        out = tmp_path / model
+        inference.main(['--list', str(lst), '--model', model, '--checkpoint', ckpt, '--vocoder_sd', taco_ckpt[1],
+                        '--vocoder_config', taco_ckpt[2], '--out_dir', str(out), '--batch_size', '2',
+                        '--denoise', '0.005'])
+        for i in range(3):
+            sr, data = wavfile.read(out / 'wavs' / f'static{i}.wav')
+            assert sr == 22050 and data.dtype == np.int16 and data.size > 0 and data.size % 256 == 0
+        assert len((out / 'index.tsv').read_text(encoding='utf-8').splitlines()) == 3
+    with pytest.raises(SystemExit):
+        inference.main(['--cpu'])
