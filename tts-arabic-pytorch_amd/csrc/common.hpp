@@ -84,7 +84,14 @@ struct ConvParams {
     int32_t mode;        // 0: y=v   1: y=y+v   2: y=(y+v)/div
     float div;
     int32_t batch;
+    // split-K for problems that cannot fill the chip (batch 1, encoder-side S = 64): when splitk_ws is set and
+    // the tile grid has < 192 blocks, the Cin range is cut into `ksplit` slices (extra grid.y factor) that write
+    // raw partial sums to splitk_ws[ks][b][Cout][Nout]; a second kernel sums them and applies the epilogue.
+    float* splitk_ws;         // >= splitk_floats floats of scratch, or nullptr (never split)
+    int64_t splitk_floats;
+    int32_t ksplit;           // set by the launcher
 };
+constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)
 
 // Launches the kernel; returns 0 or a negative code.
 int32_t launch_conv(const ConvParams& p, hipStream_t stream);

@@ -32,6 +32,8 @@
 // (SURVEY.md §3.4-5), tiles past lens_out[b] exit early.
 #include <cstring>
 
+#include <algorithm>
+
 #include "conv_mfma_common.hpp"
 
 namespace ttsamd {
@@ -68,8 +70,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     const int wm = wid / WN, wn = wid % WN;
     const int b = blockIdx.z;
     const int n_co_tiles = p.CoutP / CO_BLK;
-    const int phase = blockIdx.y / n_co_tiles;
-    const int co_blk0 = (blockIdx.y % n_co_tiles) * CO_BLK;
+    const int tiles_y = n_co_tiles * p.n_phase;
+    const int ks = blockIdx.y / tiles_y, by = blockIdx.y % tiles_y;   // ks = split-K slice (0 when ksplit == 1)
+    const int phase = by / n_co_tiles;
+    const int co_blk0 = (by % n_co_tiles) * CO_BLK;
     const int q0 = blockIdx.x * NT_BLK;
 
     int n_out = p.Nout;
@@ -85,13 +89,16 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     const int lo = (dil < 0 ? (K - 1) * dil : 0) - pad;  // first input position relative to q0
     const int W = NT_BLK + span;                          // staged columns actually used (<= WS)
 
-    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
-    // packed weights: [phase][octet][tap][kk][CoutP][4]
-    const float4* __restrict__ wp4 =
-        reinterpret_cast<const float4*>(p.w) + (int64_t)phase * (p.Cin / 8) * K * 2 * p.CoutP + co_blk0;
-    const float in_slope = p.in_slope;
-    const int n_chunks = p.Cin / KC;
     const int x_cs = p.x_cs, CoutP = p.CoutP;
+    const int chunks_all = p.Cin / KC;
+    const int c_beg = (int)((int64_t)ks * chunks_all / p.ksplit), c_end = (int)((int64_t)(ks + 1) * chunks_all / p.ksplit);
+    const int n_chunks = c_end - c_beg;
+    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs + (int64_t)c_beg * KC * x_cs;
+    // packed weights: [phase][octet][tap][kk][CoutP][4]
+    const float4* __restrict__ wp4 = reinterpret_cast<const float4*>(p.w) +
+                                     (int64_t)phase * (p.Cin / 8) * K * 2 * p.CoutP + co_blk0 +
+                                     (int64_t)c_beg * G::NOCT * K * 2 * CoutP;
+    const float in_slope = p.in_slope;
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -265,6 +272,21 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     // (bias, residual, previous y) are issued first and only then consumed.
     if (!wave_active) return;
     const int co_w0 = co_blk0 + wm * MT * 32;
+    if (p.ksplit > 1) {   // raw partial sums; bias / activation / residual happen in splitk_reduce_kernel
+        float* __restrict__ pb = p.splitk_ws + ((int64_t)ks * p.batch + b) * p.Cout * p.Nout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int q = q0 + qw0 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (q < n_out && co < p.Cout) pb[(int64_t)co * p.Nout + q] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     float* __restrict__ yb = p.y + (int64_t)b * p.y_bs + phase;
     const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs + phase : nullptr;
     const float* __restrict__ bias = p.bias;
@@ -310,6 +332,27 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     }
 }
 
+// Second half of a split-K conv: y = epilogue(sum_ks partial[ks]) with exactly the epilogue of the main kernel.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+    const int b = blockIdx.z, co = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    int n_out = p.Nout;
+    if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
+    if (q >= n_out) return;
+    const int64_t per = (int64_t)p.batch * p.Cout * p.Nout;
+    const float* __restrict__ pp = p.splitk_ws + ((int64_t)b * p.Cout + co) * p.Nout + q;
+    float v = 0.f;
+    for (int ks = 0; ks < p.ksplit; ++ks) v += pp[ks * per];
+    v += p.bias ? p.bias[co] : 0.f;
+    if (p.relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    v = v * (p.scale ? p.scale[co] : 1.f) + (p.res ? p.res[(int64_t)b * p.r_bs + (int64_t)co * p.r_cs + q] : 0.f);
+    if (p.relu_out == 1) v = fmaxf(v, 0.f);
+    else if (p.relu_out == 3) v = tanhf(v);
+    float* yp = p.y + (int64_t)b * p.y_bs + (int64_t)co * p.y_cs + q;
+    if (p.mode == 1) v = *yp + v;
+    else if (p.mode == 2) v = (*yp + v) / p.div;
+    *yp = v;
+}
+
 template <int K, int MT, int NTL, int WM, int WN>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
@@ -323,8 +366,23 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
-    hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN>), grid, dim3(256), lds, stream, p);
+    ConvParams q = p;
+    q.ksplit = 1;
+    const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
+    const int n_chunks = p.Cin / G::KC;
+    if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < 192 && n_chunks >= 8) {
+        int64_t ks = std::min<int64_t>((512 + nblk - 1) / nblk, n_chunks / 4);
+        ks = std::min<int64_t>(ks, p.splitk_floats / per);
+        if (ks >= 2) q.ksplit = (int)ks;
+    }
+    grid.y *= q.ksplit;
+    hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN>), grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
+    if (q.ksplit > 1) {
+        dim3 rg((p.Nout + 255) / 256, p.Cout, p.batch);
+        hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, stream, q);
+        TTS_CHECK_HIP(hipGetLastError());
+    }
     return 0;
 }
 

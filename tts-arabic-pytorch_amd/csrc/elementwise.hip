@@ -135,11 +135,69 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     }
 }
 
+// Single-read variant for C <= 512: block = 32 positions x 8 channel groups, the thread's <= 64 values stay
+// in registers between the mean, variance and normalise steps (1 read + 1 write of the tensor, 128 B
+// segments per wave-load); 4x more blocks than the kernel above, which matters at batch 1.
+constexpr int LN_TP = 32, LN_G = 8, LN_MAXV = 64;
+__global__ __launch_bounds__(256) void layernorm_cf_reg_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const int64_t* __restrict__ lens, int apply_mask,
+                                                               int C, int S, float eps) {
+    __shared__ float red[LN_G][LN_TP];
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & (LN_TP - 1), g = threadIdx.x / LN_TP;
+    const int t = blockIdx.x * LN_TP + tl;
+    const bool ok = t < S;
+    const float* xb = x + (int64_t)b * C * S + (ok ? t : 0);
+    float v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = g + LN_G * i;
+        v[i] = (c < C) ? xb[(int64_t)c * S] : 0.f;
+        sum += v[i];
+    }
+    red[g][tl] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_G; ++k) tot += red[k][tl];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const float d = (g + LN_G * i < C) ? v[i] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+    }
+    red[g][tl] = sq;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_G; ++k) tot += red[k][tl];
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+    if (!ok) return;
+    float m = 1.f;
+    if (apply_mask && lens && t >= (int)lens[b]) m = 0.f;
+    float* yb = y + (int64_t)b * C * S + t;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = g + LN_G * i;
+        if (c < C) yb[(int64_t)c * S] = ((v[i] - mean) * rstd * gamma[c] + beta[c]) * m;
+    }
+}
+
 int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const float* beta, const int64_t* lens,
                             int32_t apply_mask, int32_t B, int32_t C, int32_t S, hipStream_t s, float eps) {
     if (S <= 0 || B <= 0) return 0;
-    dim3 grid((S + 63) / 64, B);
-    hipLaunchKernelGGL(layernorm_cf_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
+    if (C <= LN_G * LN_MAXV) {
+        dim3 grid((S + LN_TP - 1) / LN_TP, B);
+        hipLaunchKernelGGL(layernorm_cf_reg_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
+    } else {
+        dim3 grid((S + 63) / 64, B);
+        hipLaunchKernelGGL(layernorm_cf_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
+    }
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -220,7 +220,14 @@ void fastpitch_destroy(FastPitch* h) {
 // ------------------------------------------------------------------------------------
 
 struct FftWs {
-    float *q, *a, *y, *hid;
+    float *q, *a, *y, *hid, *splitk;
+};
+
+// split-K scratch of the call in flight on this thread (carved from the caller's workspace by encode / decode)
+static thread_local float* t_splitk_ws = nullptr;
+struct SplitKScope {
+    explicit SplitKScope(float* p) { t_splitk_ws = p; }
+    ~SplitKScope() { t_splitk_ws = nullptr; }
 };
 
 static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, float* y, const float* res, int B, int S,
@@ -237,6 +244,7 @@ static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, floa
     p.Cin = c.cin; p.Cout = c.cout; p.CoutP = cout_padded(c.cout); p.K = c.k;
     p.dil = 1; p.pad = c.k / 2;
     p.n_phase = 1; p.in_slope = 1.0f; p.relu_out = relu; p.mode = 0; p.div = 1.f; p.batch = B;
+    p.splitk_ws = t_splitk_ws; p.splitk_floats = t_splitk_ws ? kSplitKFloats : 0;
     prof_begin(s, 2.0 * c.cout * c.cin * c.k);
     const int32_t rc = launch_conv(p, s);
     prof_end(s);
@@ -294,6 +302,7 @@ static void carve_enc(const FastPitch* h, Arena& a, int B, int L, EncWs& w) {
     w.p1 = a.take<float>((int64_t)B * filt * L);
     w.log_dur = a.take<float>((int64_t)B * L);
     w.lens = a.take<int64_t>(B);
+    w.f.splitk = a.take<float>(kSplitKFloats);
 }
 
 int64_t fastpitch_encode_workspace_bytes(const FastPitch* h, int32_t B, int32_t L) {
@@ -323,6 +332,7 @@ int32_t fastpitch_encode(const FastPitch* h, const int64_t* ids, int32_t B, int3
         return TTSAMD_ENOMEM;
     }
     const int d = c.d_model;
+    SplitKScope splitk(w.f.splitk);
     float* x = enc_cond;
     const float* spk = (c.n_speakers > 1 && h->spk_emb >= 0) ? h->dev + h->spk_emb + (int64_t)speaker * d : nullptr;
     TTS_TRY(launch_embed(ids, h->dev + h->word_emb, h->dev + h->pos_enc, h->pos_cap, spk, c.padding_idx, B, L, d, x,
@@ -351,6 +361,7 @@ static void carve_dec(const FastPitch* h, Arena& a, int B, int T, FftWs& w) {
     w.a = a.take<float>((int64_t)B * c.out_fft_n_heads * c.out_fft_d_head * T);
     w.y = a.take<float>((int64_t)B * c.d_model * T);
     w.hid = a.take<float>((int64_t)B * c.out_fft_filter * T);
+    w.splitk = a.take<float>(kSplitKFloats);
 }
 
 int64_t fastpitch_decode_workspace_bytes(const FastPitch* h, int32_t B, int32_t T) {
@@ -373,6 +384,7 @@ int32_t fastpitch_decode(const FastPitch* h, float* x, const int64_t* dec_lens, 
         return TTSAMD_ENOMEM;
     }
     const ttsamd_fastpitch_cfg& c = h->cfg;
+    SplitKScope splitk(w.splitk);
     // decoder input = len_regulated + pos_emb*mask (transformer.py:215-219, embed_input=False)
     TTS_TRY(launch_add_pos(x, h->dev + h->pos_dec, h->pos_cap, dec_lens, B, c.d_model, T, s));
     TTS_TRY(run_fft(h, h->dec, c.out_fft_d_head, x, dec_lens, B, T, w, s));
