@@ -30,6 +30,7 @@
 //    the LDS write; bias / residual / ReLU / ResBlock sum and /3 are fused in the epilogue.
 // Ragged batches: positions >= lens_in[b] read as zero at the INPUT of every layer
 // (SURVEY.md §3.4-5), tiles past lens_out[b] exit early.
+#include <cstdlib>
 #include <cstring>
 
 #include <algorithm>
@@ -393,7 +394,7 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
     auto blocks = [&](int co_blk, int nt_blk) -> int64_t {
         return (int64_t)((p.Nout + nt_blk - 1) / nt_blk) * (p.CoutP / co_blk) * p.n_phase * p.batch;
     };
-    const int64_t want = 768;
+    static const int64_t want = [] { const char* e = getenv("TTSAMD_WANT_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)768; }();
     const bool tiny = p.Nout <= 96;
 #ifdef TTS_FORCE_CFG   /* tile autotuning with tools/conv_bench.hip */
     switch (TTS_FORCE_CFG) {

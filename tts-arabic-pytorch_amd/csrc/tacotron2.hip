@@ -33,7 +33,7 @@ struct Taco2 {
     std::vector<TConv> enc_convs, post_convs;
     TConv enc_xproj;
     int64_t enc_whhT[2];
-    int64_t pre0T, pre1T;
+    int64_t pre0, pre1;
     int64_t att_wih, att_whh, att_b, dec_wih, dec_whh, dec_b;
     int64_t wq, wmT, v, loc_conv, loc_denseT;
     int64_t proj_w, proj_b;
@@ -125,7 +125,7 @@ int32_t tacotron2_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_t
     const int E = cfg->encoder_embedding_dim, S = cfg->num_speakers > 1 ? cfg->speaker_embedding_dim : 0;
     const int M = E + S, P = cfg->prenet_dim, A = cfg->attention_rnn_dim, D = cfg->decoder_rnn_dim;
     const int Hd = cfg->attention_hidden_dim, NF = cfg->attention_location_n_filter, KS = cfg->attention_location_kernel_size;
-    TTS_REQUIRE(cfg->symbol_embedding_dim == E && E % 16 == 0 && (E / 2) == 256 && A % 4 == 0 && D % 4 == 0 && Hd == 128 &&
+    TTS_REQUIRE(cfg->symbol_embedding_dim == E && E % 16 == 0 && (E / 2) == 256 && A == 1024 && D % 4 == 0 && D <= 1024 && Hd == 128 &&
                 NF == 32 && KS <= 63 && P == 256 && cfg->n_mels == 80,
                 "tacotron2_create: only the shipped geometry is built (512/256/1024/1024/128/32/80)");
     TensorMap tm;
@@ -159,8 +159,8 @@ int32_t tacotron2_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_t
         h->enc_whhT[0] = b.transposed("encoder.lstm.weight_hh_l0", 4 * Hh, Hh);
         h->enc_whhT[1] = b.transposed("encoder.lstm.weight_hh_l0_reverse", 4 * Hh, Hh);
     }
-    h->pre0T = b.transposed("decoder.prenet.layers.0.weight", P, cfg->n_mels);
-    h->pre1T = b.transposed("decoder.prenet.layers.1.weight", P, P);
+    h->pre0 = b.raw("decoder.prenet.layers.0.weight", (int64_t)P * cfg->n_mels);
+    h->pre1 = b.raw("decoder.prenet.layers.1.weight", (int64_t)P * P);
     h->att_wih = b.raw("decoder.attention_rnn.weight_ih", (int64_t)4 * A * (P + M));
     h->att_whh = b.raw("decoder.attention_rnn.weight_hh", (int64_t)4 * A * A);
     h->att_b = b.bias_sum("decoder.attention_rnn.bias_ih", "decoder.attention_rnn.bias_hh", 4 * A);
@@ -291,25 +291,44 @@ __device__ __forceinline__ float taco_keep(unsigned seed, unsigned layer, unsign
     return (x & 1u) ? 2.0f : 0.0f;
 }
 
-// prenet: 2 x [Linear(no bias) + ReLU + dropout(p=0.5, always on upstream)]; one block per utterance
-__global__ __launch_bounds__(256) void taco_prenet_kernel(const float* __restrict__ dec_in, const float* __restrict__ w0T,
-                                                          const float* __restrict__ w1T, int n_mels, long long seed,
-                                                          int step, float* __restrict__ out) {
+// prenet: 2 x [Linear(no bias) + ReLU + dropout(p=0.5, always on upstream)]; grid (utterance, 8): every block
+// redoes layer 1 (80 KB of weights, 4 threads per unit) and owns 32 units of layer 2 — one CU streams only
+// ~25-50 GB/s from the MALL, so the 336 KB of prenet weights must not go through a single block per utterance
+__global__ __launch_bounds__(1024) void taco_prenet_kernel(const float* __restrict__ dec_in, const float* __restrict__ w0,
+                                                           const float* __restrict__ w1, int n_mels, long long seed,
+                                                           int step, float* __restrict__ out) {
     __shared__ float xin[128], h0[256];
-    const int b = blockIdx.x, j = threadIdx.x;
-    if (j < n_mels) xin[j] = dec_in[(int64_t)b * n_mels + j];
+    const int b = blockIdx.x, tid = threadIdx.x, j = tid >> 2, sub = tid & 3;
+    if (tid < n_mels) xin[tid] = dec_in[(int64_t)b * n_mels + tid];
     __syncthreads();
-    float a = 0.f;
-    for (int k = 0; k < n_mels; ++k) a = fmaf(w0T[(int64_t)k * 256 + j], xin[k], a);
-    a = fmaxf(a, 0.f);
-    if (seed >= 0) a *= taco_keep((unsigned)seed, 0u, (unsigned)step, (unsigned)b, (unsigned)j);
-    h0[j] = a;
+    {
+        const int kq = n_mels / 4;                   // 80 -> 20 inputs per thread
+        const float* wr = w0 + (int64_t)j * n_mels + sub * kq;
+        float a = 0.f;
+        for (int k = 0; k < kq; k += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+            const int kk = sub * kq + k;
+            a = fmaf(wv.x, xin[kk], fmaf(wv.y, xin[kk + 1], fmaf(wv.z, xin[kk + 2], fmaf(wv.w, xin[kk + 3], a))));
+        }
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a = fmaxf(a, 0.f);
+        if (seed >= 0) a *= taco_keep((unsigned)seed, 0u, (unsigned)step, (unsigned)b, (unsigned)j);
+        if (sub == 0) h0[j] = a;
+    }
     __syncthreads();
-    float c = 0.f;
-    for (int k = 0; k < 256; ++k) c = fmaf(w1T[(int64_t)k * 256 + j], h0[k], c);
-    c = fmaxf(c, 0.f);
-    if (seed >= 0) c *= taco_keep((unsigned)seed, 1u, (unsigned)step, (unsigned)b, (unsigned)j);
-    out[(int64_t)b * 256 + j] = c;
+    {   // layer 2: this block's 32 of the 256 units, 32 lanes per unit (8 inputs each)
+        const int jj = blockIdx.y * 32 + (tid >> 5), l32 = tid & 31;
+        const float* wr = w1 + (int64_t)jj * 256 + l32 * 8;
+        const float4 wa = *reinterpret_cast<const float4*>(wr), wb = *reinterpret_cast<const float4*>(wr + 4);
+        const int kk = l32 * 8;
+        float a = fmaf(wa.x, h0[kk], fmaf(wa.y, h0[kk + 1], fmaf(wa.z, h0[kk + 2], wa.w * h0[kk + 3])));
+        a = fmaf(wb.x, h0[kk + 4], fmaf(wb.y, h0[kk + 5], fmaf(wb.z, h0[kk + 6], fmaf(wb.w, h0[kk + 7], a))));
+        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        a = fmaxf(a, 0.f);
+        if (seed >= 0) a *= taco_keep((unsigned)seed, 1u, (unsigned)step, (unsigned)b, (unsigned)jj);
+        if (l32 == 0) out[(int64_t)b * 256 + jj] = a;
+    }
 }
 
 // ---- block-level GEMV pieces of the decoder step ------------------------------------------------
@@ -357,55 +376,114 @@ __device__ __forceinline__ void block_dots_reduce(float (&acc)[NR][TACO_BC], flo
     __syncthreads();
 }
 
-// LSTMCell: block = hidden unit u (its 4 gate rows); x = [x1 (n1) | x2 (n2)], gates = W_ih x + W_hh h + bias
-// (= b_ih + b_hh); c updated in place, h ping-pong.  n1, n2, H multiples of 4.
-__global__ __launch_bounds__(256) void taco_lstm_kernel(const float* __restrict__ x1, int n1,
-                                                        const float* __restrict__ x2, int n2,
-                                                        const float* __restrict__ h_in, float* __restrict__ c,
-                                                        const float* __restrict__ wih, const float* __restrict__ whh,
-                                                        const float* __restrict__ bias, float* __restrict__ h_out,
-                                                        int B, int H) {
-    __shared__ float red[4][TACO_BC], part[4][4][TACO_BC];
-    const int u = blockIdx.x;
-    const int K1 = n1 + n2;
+// LSTMCell as a column-parallel weight-streaming GEMV (tools/gemv_bench.hip: 24.5 us for the attention +
+// decoder pair at B=8 vs 38.5 for a row-per-block layout; a bare read of the same 75.5 MB takes 11.5 us).
+// thread = one float4 column group of [x1 | x2 | h] with its 8 batch columns of x in registers (loaded once);
+// block = 2 hidden units = 8 gate rows, one float4 weight load per row and thread (a wave reads 1 KB of a
+// row).  The thread's 64 (row, batch) partials are summed over the wave with a transposing butterfly
+// (63 shuffles, lane l ends with partial l), over the waves through LDS; c updated in place, h ping-pong.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void taco_lstm_kernel(const float* __restrict__ x1, int n1,
+                                                            const float* __restrict__ x2, int n2,
+                                                            const float* __restrict__ h_in, float* __restrict__ c,
+                                                            const float* __restrict__ wih, const float* __restrict__ whh,
+                                                            const float* __restrict__ bias, float* __restrict__ h_out,
+                                                            int B, int H) {
+    __shared__ float part[NW][64], gates[64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int K1 = n1 + n2, K4 = (K1 + H) / 4;
+    const bool act = tid < K4;
+    const int k = 4 * min(tid, K4 - 1);
+    const int u0 = blockIdx.x * 2;
+    float4 w[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {          // row r = (unit r >> 2, gate r & 3)
+        const int64_t row = (int64_t)(r & 3) * H + (u0 + (r >> 2));
+        w[r] = *reinterpret_cast<const float4*>(k < K1 ? wih + row * K1 + k : whh + row * H + (k - K1));
+    }
     for (int b0 = 0; b0 < B; b0 += TACO_BC) {
-        float acc[4][TACO_BC];
+        float v[64];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int bb = 0; bb < TACO_BC; ++bb) {
+            const int b = min(b0 + bb, B - 1);
+            const float* src = k < n1 ? x1 + (int64_t)b * n1 + k
+                             : k < K1 ? x2 + (int64_t)b * n2 + (k - n1) : h_in + (int64_t)b * H + (k - K1);
+            float4 xv = *reinterpret_cast<const float4*>(src);
+            if (!act) xv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int bb = 0; bb < TACO_BC; ++bb) acc[g][bb] = 0.f;
-        block_dots_acc<4>(wih + (int64_t)u * K1, (int64_t)H * K1, n1, x1, n1, b0, B, acc);
-        block_dots_acc<4>(wih + (int64_t)u * K1 + n1, (int64_t)H * K1, n2, x2, n2, b0, B, acc);
-        block_dots_acc<4>(whh + (int64_t)u * H, (int64_t)H * H, H, h_in, H, b0, B, acc);
-        block_dots_reduce<4>(acc, red, part);
-        if (threadIdx.x < TACO_BC && b0 + threadIdx.x < B) {
-            const int bb = threadIdx.x, b = b0 + bb;
-            const float gi = red[0][bb] + bias[u], gf = red[1][bb] + bias[H + u];
-            const float gg = red[2][bb] + bias[2 * H + u], go = red[3][bb] + bias[3 * H + u];
-            const float cn = sigmoidf_(gf) * c[(int64_t)b * H + u] + sigmoidf_(gi) * tanhf(gg);
-            c[(int64_t)b * H + u] = cn;
-            h_out[(int64_t)b * H + u] = sigmoidf_(go) * tanhf(cn);
+            for (int r = 0; r < 8; ++r)
+                v[r * 8 + bb] = fmaf(w[r].x, xv.x, fmaf(w[r].y, xv.y, fmaf(w[r].z, xv.z, w[r].w * xv.w)));
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int m = 32 >> s, half = 32 >> s;
+            const bool upper = (lane & m) != 0;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const float send = upper ? v[j] : v[j + half];
+                const float keep = upper ? v[j + half] : v[j];
+                v[j] = keep + __shfl_xor(send, m);
+            }
+        }
+        part[wid][lane] = v[0];
+        __syncthreads();
+        if (tid < 64) {
+            float g = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) g += part[q][tid];
+            gates[tid] = g;                 // [unit (2)][gate (4)][batch (8)]
+        }
+        __syncthreads();
+        if (tid < 2 * TACO_BC) {
+            const int uu = tid / TACO_BC, bb = tid % TACO_BC, b = b0 + bb, u = u0 + uu;
+            if (b < B) {
+                const float* gp = gates + uu * 32 + bb;
+                const float gi = gp[0] + bias[u], gf = gp[8] + bias[H + u];
+                const float gg = gp[16] + bias[2 * H + u], go = gp[24] + bias[3 * H + u];
+                const float cn = sigmoidf_(gf) * c[(int64_t)b * H + u] + sigmoidf_(gi) * tanhf(gg);
+                c[(int64_t)b * H + u] = cn;
+                h_out[(int64_t)b * H + u] = sigmoidf_(go) * tanhf(cn);
+            }
         }
         __syncthreads();
     }
 }
 
-// processed query pq[b][r] = sum_k wq[r][k] att_h[b][k]   (query_layer, no bias); 4 rows per block
+// processed query pq[b][r] = sum_k wq[r][k] att_h[b][k]   (query_layer, no bias), column-parallel like the
+// LSTM kernel: thread = float4 column group (A/4 = 256 threads), block = 8 of the 128 rows
 __global__ __launch_bounds__(256) void taco_query_kernel(const float* __restrict__ att_h, int A,
                                                          const float* __restrict__ wq, float* __restrict__ pq, int B) {
-    __shared__ float red[4][TACO_BC], part[4][4][TACO_BC];
-    const int r0 = blockIdx.x * 4;
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r0 = blockIdx.x * 8, k = 4 * tid;
+    float4 w[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r] = *reinterpret_cast<const float4*>(wq + (int64_t)(r0 + r) * A + k);
     for (int b0 = 0; b0 < B; b0 += TACO_BC) {
-        float acc[4][TACO_BC];
+        float v[64];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int bb = 0; bb < TACO_BC; ++bb) {
+            const float4 xv = *reinterpret_cast<const float4*>(att_h + (int64_t)min(b0 + bb, B - 1) * A + k);
 #pragma unroll
-            for (int bb = 0; bb < TACO_BC; ++bb) acc[g][bb] = 0.f;
-        block_dots_acc<4>(wq + (int64_t)r0 * A, A, A, att_h, A, b0, B, acc);
-        block_dots_reduce<4>(acc, red, part);
-        if (threadIdx.x < 4 * TACO_BC) {
-            const int r = threadIdx.x / TACO_BC, bb = threadIdx.x % TACO_BC;
-            if (b0 + bb < B) pq[(int64_t)(b0 + bb) * 128 + r0 + r] = red[r][bb];
+            for (int r = 0; r < 8; ++r)
+                v[r * 8 + bb] = fmaf(w[r].x, xv.x, fmaf(w[r].y, xv.y, fmaf(w[r].z, xv.z, w[r].w * xv.w)));
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int m = 32 >> s, half = 32 >> s;
+            const bool upper = (lane & m) != 0;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const float send = upper ? v[j] : v[j + half];
+                const float keep = upper ? v[j + half] : v[j];
+                v[j] = keep + __shfl_xor(send, m);
+            }
+        }
+        part[wid][lane] = v[0];
+        __syncthreads();
+        if (tid < 64) {
+            const int r = tid >> 3, bb = tid & 7;
+            if (b0 + bb < B) pq[(int64_t)(b0 + bb) * 128 + r0 + r] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
         }
         __syncthreads();
     }
@@ -585,6 +663,25 @@ static int32_t tconv(const Taco2* h, const TConv& c, const float* x, int64_t x_b
     return rc;
 }
 
+static int32_t launch_lstm(const float* x1, int n1, const float* x2, int n2, const float* h_in, float* c,
+                           const float* wih, const float* whh, const float* bias, float* h_out, int B, int H,
+                           hipStream_t s) {
+    const int K4 = (n1 + n2 + H) / 4, NW = (K4 + 63) / 64;
+    TTS_REQUIRE(n1 % 4 == 0 && n2 % 4 == 0 && H % 4 == 0 && H % 2 == 0 && NW <= 16,
+                "tacotron2: LSTM geometry %d+%d+%d not supported", n1, n2, H);
+#define TTS_LSTM_CASE(N)                                                                                         \
+    if (NW <= N) {                                                                                               \
+        hipLaunchKernelGGL(taco_lstm_kernel<N>, dim3(H / 2), dim3(N * 64), 0, s, x1, n1, x2, n2, h_in, c, wih, whh, \
+                           bias, h_out, B, H);                                                                   \
+        return 0;                                                                                                \
+    }
+    TTS_LSTM_CASE(8)
+    TTS_LSTM_CASE(11)
+    TTS_LSTM_CASE(16)
+#undef TTS_LSTM_CASE
+    return 0;
+}
+
 int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* lengths, const int64_t* speaker_ids,
                         int32_t B, int32_t L, int32_t max_step, int64_t dropout_seed, float* mel_post,
                         int32_t* mel_lens, float* alignments, float* mel_raw, int32_t* n_steps_out, void* ws,
@@ -636,17 +733,17 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     int steps = 0;
     for (int step = 0; step < max_step; ++step) {
         const int pi = step & 1, po = pi ^ 1;
-        hipLaunchKernelGGL(taco_prenet_kernel, dim3(B), dim3(256), 0, s, w.dec_in, W + h->pre0T, W + h->pre1T, c.n_mels,
+        hipLaunchKernelGGL(taco_prenet_kernel, dim3(B, 8), dim3(1024), 0, s, w.dec_in, W + h->pre0, W + h->pre1, c.n_mels,
                            (long long)dropout_seed, step, w.pre);
-        hipLaunchKernelGGL(taco_lstm_kernel, dim3(A), dim3(256), 0, s, w.pre, P, w.ctx, M, w.att_h[pi], w.att_c,
-                           W + h->att_wih, W + h->att_whh, W + h->att_b, w.att_h[po], B, A);
-        hipLaunchKernelGGL(taco_query_kernel, dim3(128 / 4), dim3(256), 0, s, w.att_h[po], A, W + h->wq, w.pq, B);
+        TTS_TRY(launch_lstm(w.pre, P, w.ctx, M, w.att_h[pi], w.att_c, W + h->att_wih, W + h->att_whh, W + h->att_b,
+                            w.att_h[po], B, A, s));
+        hipLaunchKernelGGL(taco_query_kernel, dim3(128 / 8), dim3(256), 0, s, w.att_h[po], A, W + h->wq, w.pq, B);
         hipLaunchKernelGGL(taco_energy_kernel, dim3((L + 3) / 4, B), dim3(256), 0, s, w.pq, w.pm, W + h->loc_conv,
                            c.attention_location_kernel_size, W + h->loc_denseT, W + h->v, w.aw, w.aw_cum, L, w.energy);
         hipLaunchKernelGGL(taco_context_kernel, dim3(B, (M + 127) / 128), dim3(128), 0, s, w.energy, w.memory, M, lengths,
                            L, w.aw, w.aw_cum, w.ctx, alignments, Tcap, step);
-        hipLaunchKernelGGL(taco_lstm_kernel, dim3(D), dim3(256), 0, s, w.att_h[po], A, w.ctx, M, w.dec_h[pi], w.dec_c,
-                           W + h->dec_wih, W + h->dec_whh, W + h->dec_b, w.dec_h[po], B, D);
+        TTS_TRY(launch_lstm(w.att_h[po], A, w.ctx, M, w.dec_h[pi], w.dec_c, W + h->dec_wih, W + h->dec_whh, W + h->dec_b,
+                            w.dec_h[po], B, D, s));
         hipLaunchKernelGGL(taco_proj_kernel, dim3(c.n_mels + 1), dim3(256), 0, s, w.dec_h[po], D, w.ctx, M, W + h->proj_w,
                            W + h->proj_b, c.n_mels, c.gate_threshold, step, Tcap, B, mel_raw, w.dec_in, mel_lens,
                            w.finished);
