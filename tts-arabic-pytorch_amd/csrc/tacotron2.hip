@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,13 @@ struct Taco2 {
     int64_t wq, wmT, v, loc_conv, loc_denseT;
     int64_t proj_w, proj_b;
     int mem_dim = 0;
+    // host side of the stop test (one infer call at a time per handle: guarded by mu)
+    mutable std::mutex mu;
+    mutable int32_t* pinned = nullptr;      // [TACO_RING][pinned_cap] finished flags copied back asynchronously
+    mutable int pinned_cap = 0;
+    mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    mutable hipEvent_t ev_in = nullptr;
+    mutable hipStream_t loop_stream = nullptr;   // capture is not allowed on the legacy default stream torch hands us
 };
 
 using TensorMap = std::map<std::string, const ttsamd_tensor*>;
@@ -215,6 +223,11 @@ int32_t tacotron2_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_t
 
 void tacotron2_destroy(Taco2* h) {
     if (!h) return;
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->loop_stream) (void)hipStreamDestroy(h->loop_stream);
     if (h->dev) (void)hipFree(h->dev);
     if (h->dev16) (void)hipFree(h->dev16);
     delete h;
@@ -296,9 +309,11 @@ __device__ __forceinline__ float taco_keep(unsigned seed, unsigned layer, unsign
 // ~25-50 GB/s from the MALL, so the 336 KB of prenet weights must not go through a single block per utterance
 __global__ __launch_bounds__(1024) void taco_prenet_kernel(const float* __restrict__ dec_in, const float* __restrict__ w0,
                                                            const float* __restrict__ w1, int n_mels, long long seed,
-                                                           int step, float* __restrict__ out) {
+                                                           const int* __restrict__ step_base, int step_off,
+                                                           float* __restrict__ out) {
     __shared__ float xin[128], h0[256];
     const int b = blockIdx.x, tid = threadIdx.x, j = tid >> 2, sub = tid & 3;
+    const int step = *step_base + step_off;
     if (tid < n_mels) xin[tid] = dec_in[(int64_t)b * n_mels + tid];
     __syncthreads();
     {
@@ -531,9 +546,10 @@ __global__ __launch_bounds__(128) void taco_context_kernel(const float* __restri
                                                            int M, const int64_t* __restrict__ lens, int L,
                                                            float* __restrict__ aw, float* __restrict__ aw_cum,
                                                            float* __restrict__ ctx, float* __restrict__ align_out,
-                                                           int Tcap, int step) {
+                                                           int Tcap, const int* __restrict__ step_base, int step_off) {
     __shared__ float ws[TACO_LMAX], red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int step = *step_base + step_off;
     const int n = min((int)lens[b], L);
     float mx = -INFINITY;
     for (int t = tid; t < n; t += 128) {
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(128) void taco_context_kernel(const float* __restri
             const float w = t < n ? ws[t] : 0.f;
             aw[(int64_t)b * L + t] = w;
             aw_cum[(int64_t)b * L + t] += w;
-            align_out[((int64_t)b * Tcap + step) * L + t] = w;
+            if (step < Tcap) align_out[((int64_t)b * Tcap + step) * L + t] = w;
         }
     }
     const int m = blockIdx.y * 128 + tid;
@@ -579,11 +595,14 @@ __global__ __launch_bounds__(128) void taco_context_kernel(const float* __restri
 __global__ __launch_bounds__(256) void taco_proj_kernel(const float* __restrict__ dec_h, int D,
                                                         const float* __restrict__ ctx, int M,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        int n_mels, float thr, int step, int Tcap, int B,
+                                                        int n_mels, float thr, const int* __restrict__ step_base,
+                                                        int step_off, int Tcap, int B,
                                                         float* __restrict__ mel_out, float* __restrict__ dec_in,
                                                         int32_t* __restrict__ mel_lens, int32_t* __restrict__ finished) {
     __shared__ float red[1][TACO_BC], part[4][1][TACO_BC];
     const int r = blockIdx.x, K = D + M;
+    const int step = *step_base + step_off;
+    if (step >= Tcap) return;            // steps past max_step inside the last 8-step graph are no-ops
     for (int b0 = 0; b0 < B; b0 += TACO_BC) {
         float acc[1][TACO_BC];
 #pragma unroll
@@ -606,12 +625,14 @@ __global__ __launch_bounds__(256) void taco_proj_kernel(const float* __restrict_
     }
 }
 
+__global__ void taco_advance_kernel(int* step_base, int n) { *step_base += n; }
+
 // ------------------------------------------------------------------------------------ host
 
 struct TWs {
     float *x0, *x1, *xproj, *memory, *pm, *pre, *pq, *energy, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
     float *post0, *post1;
-    int32_t* finished;
+    int32_t *finished, *step;
 };
 
 static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
@@ -636,6 +657,7 @@ static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
     w.post0 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
     w.post1 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
     w.finished = a.take<int32_t>(B);
+    w.step = a.take<int32_t>(1);
 }
 
 int64_t tacotron2_workspace_bytes(const Taco2* h, int32_t B, int32_t L, int32_t Tcap) {
@@ -729,33 +751,82 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     TTS_CHECK_HIP(hipMemsetAsync(w.dec_in, 0, (size_t)B * c.n_mels * sizeof(float), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.finished, 0, (size_t)B * sizeof(int32_t), s));
     TTS_CHECK_HIP(hipMemsetAsync(mel_lens, 0, (size_t)B * sizeof(int32_t), s));
-    std::vector<int32_t> fin(B);
-    int steps = 0;
-    for (int step = 0; step < max_step; ++step) {
-        const int pi = step & 1, po = pi ^ 1;
+    TTS_CHECK_HIP(hipMemsetAsync(w.step, 0, sizeof(int32_t), s));
+    // The loop is launch-bound when issued kernel by kernel (7 dependent launches of 4-14 us per step), so
+    // 8 steps are captured once into a hipGraph (the step index lives in device memory and is advanced by the
+    // graph's last node) and replayed.  The stop flags come back through pinned memory two replays late, so
+    // the host never drains the queue; frames computed past the stop are sliced off (the reference breaks
+    // as soon as every utterance has finished, tacotron2_ms.py:327 -> torchaudio _Decoder.infer).
+    constexpr int GSTEPS = 8, RING = 4;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->pinned_cap < B) {
+        if (h->pinned) TTS_CHECK_HIP(hipHostFree(h->pinned));
+        h->pinned = nullptr;
+        TTS_CHECK_HIP(hipHostMalloc((void**)&h->pinned, (size_t)RING * B * sizeof(int32_t), hipHostMallocDefault));
+        h->pinned_cap = B;
+    }
+    for (auto& e : h->ev)
+        if (!e) TTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!h->ev_in) TTS_CHECK_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    if (!h->loop_stream) TTS_CHECK_HIP(hipStreamCreateWithFlags(&h->loop_stream, hipStreamNonBlocking));
+    hipStream_t caller = s;
+    TTS_CHECK_HIP(hipEventRecord(h->ev_in, caller));          // encoder + state resets were queued on the caller's stream
+    s = h->loop_stream;
+    TTS_CHECK_HIP(hipStreamWaitEvent(s, h->ev_in, 0));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    TTS_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    int32_t cap_rc = 0;
+    for (int i = 0; i < GSTEPS && cap_rc == 0; ++i) {
+        const int pi = i & 1, po = pi ^ 1;
         hipLaunchKernelGGL(taco_prenet_kernel, dim3(B, 8), dim3(1024), 0, s, w.dec_in, W + h->pre0, W + h->pre1, c.n_mels,
-                           (long long)dropout_seed, step, w.pre);
-        TTS_TRY(launch_lstm(w.pre, P, w.ctx, M, w.att_h[pi], w.att_c, W + h->att_wih, W + h->att_whh, W + h->att_b,
-                            w.att_h[po], B, A, s));
+                           (long long)dropout_seed, w.step, i, w.pre);
+        cap_rc = launch_lstm(w.pre, P, w.ctx, M, w.att_h[pi], w.att_c, W + h->att_wih, W + h->att_whh, W + h->att_b,
+                             w.att_h[po], B, A, s);
         hipLaunchKernelGGL(taco_query_kernel, dim3(128 / 8), dim3(256), 0, s, w.att_h[po], A, W + h->wq, w.pq, B);
         hipLaunchKernelGGL(taco_energy_kernel, dim3((L + 3) / 4, B), dim3(256), 0, s, w.pq, w.pm, W + h->loc_conv,
                            c.attention_location_kernel_size, W + h->loc_denseT, W + h->v, w.aw, w.aw_cum, L, w.energy);
         hipLaunchKernelGGL(taco_context_kernel, dim3(B, (M + 127) / 128), dim3(128), 0, s, w.energy, w.memory, M, lengths,
-                           L, w.aw, w.aw_cum, w.ctx, alignments, Tcap, step);
-        TTS_TRY(launch_lstm(w.att_h[po], A, w.ctx, M, w.dec_h[pi], w.dec_c, W + h->dec_wih, W + h->dec_whh, W + h->dec_b,
-                            w.dec_h[po], B, D, s));
+                           L, w.aw, w.aw_cum, w.ctx, alignments, Tcap, w.step, i);
+        if (cap_rc == 0)
+            cap_rc = launch_lstm(w.att_h[po], A, w.ctx, M, w.dec_h[pi], w.dec_c, W + h->dec_wih, W + h->dec_whh,
+                                 W + h->dec_b, w.dec_h[po], B, D, s);
         hipLaunchKernelGGL(taco_proj_kernel, dim3(c.n_mels + 1), dim3(256), 0, s, w.dec_h[po], D, w.ctx, M, W + h->proj_w,
-                           W + h->proj_b, c.n_mels, c.gate_threshold, step, Tcap, B, mel_raw, w.dec_in, mel_lens,
+                           W + h->proj_b, c.n_mels, c.gate_threshold, w.step, i, Tcap, B, mel_raw, w.dec_in, mel_lens,
                            w.finished);
-        TTS_CHECK_HIP(hipGetLastError());
-        steps = step + 1;
-        if ((steps % 8) == 0 || steps == max_step) {          // the reference breaks as soon as all are finished
-            TTS_CHECK_HIP(hipMemcpyAsync(fin.data(), w.finished, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            TTS_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(taco_advance_kernel, dim3(1), dim3(1), 0, s, w.step, GSTEPS);
+    hipError_t cap_err = hipStreamEndCapture(s, &graph);
+    if (cap_err == hipSuccess && cap_rc == 0) cap_err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (cap_rc != 0) return cap_rc;
+    if (cap_err != hipSuccess) {
+        set_error("tacotron2_infer: capturing the decoder step graph failed: %s", hipGetErrorString(cap_err));
+        return TTSAMD_EHIP;
+    }
+    int steps = 0;
+    hipError_t run_err = hipSuccess;
+    for (int g = 0; steps < max_step && run_err == hipSuccess; ++g) {
+        run_err = hipGraphLaunch(exec, s);
+        steps = std::min(steps + GSTEPS, (int)max_step);
+        const int slot = g % RING;
+        if (run_err == hipSuccess)
+            run_err = hipMemcpyAsync(h->pinned + (size_t)slot * B, w.finished, B * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (run_err == hipSuccess) run_err = hipEventRecord(h->ev[slot], s);
+        if (g >= 2 && run_err == hipSuccess) {               // flags as of replay g-2: keeps two replays queued
+            const int old = (g - 2) % RING;
+            run_err = hipEventSynchronize(h->ev[old]);
             bool all = true;
-            for (int b = 0; b < B; ++b) all = all && fin[b];
+            for (int b = 0; b < B; ++b) all = all && h->pinned[(size_t)old * B + b];
             if (all) break;
         }
+    }
+    if (run_err == hipSuccess) run_err = hipStreamSynchronize(s);   // host-blocking: the caller's stream may go on
+    (void)hipGraphExecDestroy(exec);
+    s = caller;
+    if (run_err != hipSuccess) {
+        set_error("tacotron2_infer: decoder loop failed: %s", hipGetErrorString(run_err));
+        return TTSAMD_EHIP;
     }
     // number of frames the reference would have produced: it stops at the step the last utterance finishes
     std::vector<int32_t> lens_h(B);
