@@ -89,6 +89,19 @@ typedef struct ttsamd_tacotron2_cfg {
     float gate_threshold;                   /* 0.5 */
 } ttsamd_tacotron2_cfg;
 
+/* models/diacritizers/shakkelha/network.py:10-27, shakkala/network.py:9-24 as one tagger geometry */
+typedef struct ttsamd_tagger_cfg {
+    int32_t n_vocab;          /* embedding rows (91 / 149) */
+    int32_t emb_dim;          /* 25 / 288 */
+    int32_t n_lstm;           /* bidirectional LSTM layers (2 / 3) */
+    int32_t lstm_hidden[4];   /* per direction (256,256 / 288,144,96) */
+    int32_t hard_sigmoid;     /* 1: gates i,f,o = clamp(0.2x+0.5,0,1) (shakkala/lstm_hsm.py:352-379) */
+    int32_t bn_after_lstm0;   /* 1: eval BatchNorm1d between lstm0 and lstm1 (shakkala/network.py:35) */
+    float bn_eps;
+    int32_t n_dense;          /* Linear layers after the LSTMs, ReLU on all but the last (3 / 1) */
+    int32_t dense_dim[4];     /* 512,512,19 / 28; the last one is the number of classes */
+} ttsamd_tagger_cfg;
+
 const char* ttsamd_last_error(void);
 int32_t ttsamd_version(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
@@ -207,6 +220,19 @@ int32_t ttsamd_tacotron2_infer(void* handle, const int64_t* tokens, const int64_
                                int64_t dropout_seed, float* mel_post, int32_t* mel_lens, float* alignments,
                                float* mel_raw, int32_t* n_steps, void* workspace, int64_t workspace_bytes,
                                void* stream);
+
+/* ---- diacritizer taggers: replaces Shakkelha.forward / Shakkala.forward
+ *      (models/diacritizers/shakkelha/network.py:29-42, shakkala/network.py:31-43).  Weight names are
+ *      canonical: emb.weight, lstm<i>.{weight,bias}_{ih,hh}_l0[_reverse], bn0.{weight,bias,running_mean,
+ *      running_var}, dense<i>.{weight,bias} (the Python classes rename emb0 / emb_input). ------------------ */
+int32_t ttsamd_tagger_create(const ttsamd_tensor* weights, int32_t n_weights, const ttsamd_tagger_cfg* cfg,
+                             void** handle);
+int32_t ttsamd_tagger_destroy(void* handle);
+int64_t ttsamd_tagger_workspace_bytes(void* handle, int32_t batch, int32_t n_chars);
+/* ids int64 [B][n_chars] (device) -> probs [B][n_chars][n_classes] (device), softmax over the classes.
+ * Sequences run over the full n_chars in both directions (no packing), as the reference modules do. */
+int32_t ttsamd_tagger_forward(void* handle, const int64_t* ids, int32_t batch, int32_t n_chars, float* probs,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- kernel-level entry used by the parity tests and the roofline bench ------------- */
 

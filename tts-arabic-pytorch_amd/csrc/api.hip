@@ -69,6 +69,11 @@ void tacotron2_destroy(Taco2*);
 int64_t tacotron2_workspace_bytes(const Taco2*, int32_t, int32_t, int32_t);
 int32_t tacotron2_infer(const Taco2*, const int64_t*, const int64_t*, const int64_t*, int32_t, int32_t, int32_t, int64_t,
                         float*, int32_t*, float*, float*, int32_t*, void*, int64_t, hipStream_t);
+struct Tagger;
+int32_t tagger_create(const ttsamd_tensor*, int32_t, const ttsamd_tagger_cfg*, Tagger**);
+void tagger_destroy(Tagger*);
+int64_t tagger_workspace_bytes(const Tagger*, int32_t, int32_t);
+int32_t tagger_forward(const Tagger*, const int64_t*, int32_t, int32_t, float*, void*, int64_t, hipStream_t);
 int32_t denoiser_create(Denoiser**);
 void denoiser_destroy(Denoiser*);
 int64_t denoiser_workspace_bytes(int32_t, int32_t);
@@ -269,6 +274,26 @@ int32_t ttsamd_tacotron2_infer(void* handle, const int64_t* tokens, const int64_
                                int64_t workspace_bytes, void* stream) {
     return tacotron2_infer((Taco2*)handle, tokens, lengths, speaker_ids, batch, n_tokens, max_step, dropout_seed, mel_post,
                            mel_lens, alignments, mel_raw, n_steps, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int32_t ttsamd_tagger_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_tagger_cfg* cfg, void** handle) {
+    TTS_REQUIRE(handle, "tagger_create: null handle");
+    Tagger* h = nullptr;
+    const int32_t rc = tagger_create(weights, n, cfg, &h);
+    if (rc == 0) *handle = h;
+    return rc;
+}
+int32_t ttsamd_tagger_destroy(void* handle) {
+    tagger_destroy((Tagger*)handle);
+    return 0;
+}
+int64_t ttsamd_tagger_workspace_bytes(void* handle, int32_t batch, int32_t n_chars) {
+    if (!handle || batch < 1 || n_chars < 1) return 0;
+    return tagger_workspace_bytes((Tagger*)handle, batch, n_chars);
+}
+int32_t ttsamd_tagger_forward(void* handle, const int64_t* ids, int32_t batch, int32_t n_chars, float* probs,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    return tagger_forward((Tagger*)handle, ids, batch, n_chars, probs, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {

@@ -7,7 +7,7 @@ defaults and return conventions, with the arithmetic routed to the HIP engines.
 
 Differences, all host-side: the vocoder runs ONCE on the ragged batch instead of in a
 per-utterance loop (:340-345) — results are identical because every layer pads at the true
-utterance edge — and `vowelizer=` raises (diacritizers are outside the hot path).
+utterance edge — `vowelizer=` runs the Shakkelha / Shakkala taggers of models/diacritizers on the HIP tagger engine.
 """
 from typing import List, Optional, Union
 
@@ -19,6 +19,7 @@ import text
 from ttsamd.engine import FastPitchEngine
 from ttsamd.lib import TtsAmdError
 from utils import get_basic_config
+from models.diacritizers import load_vowelizer
 from vocoder import load_hifigan
 from vocoder.hifigan.denoiser import Denoiser
 from vocoder.hifigan.models import _HipModule
@@ -52,9 +53,10 @@ class FastPitch(_HipModule):
         self._sd = {k: v.detach().cpu().float().numpy() for k, v in state_dicts['model'].items()
                     if torch.is_tensor(v) and v.is_floating_point() and not k.startswith('attention.')}
         self.config = get_basic_config()
+        self.vowelizers = {}
         if vowelizer is not None:
-            raise NotImplementedError('vowelizer= (Shakkala/Shakkelha diacritizers) is not part of the MI355X hot path')
-        self.default_vowelizer = None
+            self.vowelizers[vowelizer] = load_vowelizer(vowelizer, self.config)
+        self.default_vowelizer = vowelizer
         self.phon_to_id = None
         if 'symbols' in state_dicts:
             self.phon_to_id = {phon: i for i, phon in enumerate(state_dicts['symbols'])}
@@ -100,9 +102,16 @@ class FastPitch(_HipModule):
 
     # ---- text -> mel (reference :77-253) -----------------------------------------------
     def _vowelize(self, utterance: str, vowelizer=None):
-        if vowelizer is not None:
-            raise NotImplementedError('vowelizer= is not part of the MI355X hot path')
-        return utterance
+        """Optional diacritization pre-step (reference :77-87): Buckwalter -> Arabic -> tagger.predict."""
+        vowelizer = self.default_vowelizer if vowelizer is None else vowelizer
+        if vowelizer is None:
+            return utterance
+        if vowelizer not in self.vowelizers:
+            self.vowelizers[vowelizer] = load_vowelizer(vowelizer, self.config)
+        tagger = self.vowelizers[vowelizer]
+        if tagger.device != self.device:          # the dict is not a registered submodule, .to() does not reach it
+            tagger.to(self.device)
+        return tagger.predict(text.buckwalter_to_arabic(utterance))
 
     def _tokenize(self, utterance: str, vowelizer=None):
         utterance = self._vowelize(utterance, vowelizer)

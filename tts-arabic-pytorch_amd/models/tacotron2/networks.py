@@ -7,7 +7,7 @@ return conventions, with the arithmetic routed to the HIP engines.
 
 Differences, host-side only: `tts_batch` vocodes the (truncated / resized, hence ragged) mels in ONE
 ragged HiFi-GAN call instead of a per-mel loop (:340-346) — identical results, every layer pads at the
-true utterance edge — and `vowelizer=` raises (diacritizers are outside the hot path).
+true utterance edge — `vowelizer=` runs the Shakkelha / Shakkala taggers of models/diacritizers on the HIP tagger engine.
 """
 from typing import List, Optional, Union
 
@@ -17,6 +17,7 @@ import torch.nn as nn
 import text
 from text.symbols import EOS_TOKENS, SEPARATOR_TOKEN
 from utils import get_basic_config
+from models.diacritizers import load_vowelizer
 from vocoder import load_hifigan
 from vocoder.hifigan.denoiser import Denoiser
 
@@ -70,18 +71,26 @@ class Tacotron2(Tacotron2MS):
             state_dicts = torch.load(checkpoint, map_location='cpu')
             self.load_state_dict(state_dicts['model'])
         self.config = get_basic_config()
+        self.vowelizers = {}
         if vowelizer is not None:
-            raise NotImplementedError('vowelizer= (Shakkala/Shakkelha diacritizers) is not part of the MI355X hot path')
-        self.default_vowelizer = None
+            self.vowelizers[vowelizer] = load_vowelizer(vowelizer, self.config)
+        self.default_vowelizer = vowelizer
         self.phon_to_id = None
         if state_dicts is not None and 'symbols' in state_dicts:
             self.phon_to_id = {phon: i for i, phon in enumerate(state_dicts['symbols'])}
         self.eval()
 
     def _vowelize(self, utterance: str, vowelizer=None):
-        if vowelizer is not None:
-            raise NotImplementedError('vowelizer= is not part of the MI355X hot path')
-        return utterance
+        """Optional diacritization pre-step (reference :77-87): Buckwalter -> Arabic -> tagger.predict."""
+        vowelizer = self.default_vowelizer if vowelizer is None else vowelizer
+        if vowelizer is None:
+            return utterance
+        if vowelizer not in self.vowelizers:
+            self.vowelizers[vowelizer] = load_vowelizer(vowelizer, self.config)
+        tagger = self.vowelizers[vowelizer]
+        if tagger.device != self.device:          # the dict is not a registered submodule, .to() does not reach it
+            tagger.to(self.device)
+        return tagger.predict(text.buckwalter_to_arabic(utterance))
 
     def _tokenize(self, utterance: str, vowelizer=None):
         utterance = self._vowelize(utterance, vowelizer)

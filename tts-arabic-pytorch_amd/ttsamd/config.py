@@ -57,3 +57,13 @@ TACOTRON2_CONFIG = {
 
 SAMPLE_RATE = 22050
 HOP = 256
+
+# models/diacritizers/shakkelha/network.py:10-27 and shakkala/network.py:9-24 as tagger geometries
+SHAKKELHA_CONFIG = {
+    'n_vocab': 91, 'emb_dim': 25, 'lstm_hidden': [256, 256], 'hard_sigmoid': 0, 'bn_after_lstm0': 0, 'bn_eps': 1e-5,
+    'dense_dim': [512, 512, 19],
+}
+SHAKKALA_CONFIG = {
+    'n_vocab': 149, 'emb_dim': 288, 'lstm_hidden': [288, 144, 96], 'hard_sigmoid': 1, 'bn_after_lstm0': 1,
+    'bn_eps': 1e-3, 'dense_dim': [28],
+}

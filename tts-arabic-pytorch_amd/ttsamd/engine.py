@@ -346,6 +346,51 @@ class Tacotron2Engine:
         return mel_post[:, :, :T], mel_lens, align[:, :T]
 
 
+class TaggerEngine:
+    """Handle over ttsamd_tagger_* (replaces Shakkelha.forward / Shakkala.forward of models/diacritizers)."""
+
+    RENAME = {'emb0.weight': 'emb.weight', 'emb_input.weight': 'emb.weight'}
+
+    def __init__(self, state_dict, config, device='cuda'):
+        self.lib = _require_gpu()
+        self.device = torch.device(device if device != 'cuda' else 'cuda:0')
+        c = dict(config)
+        cfg = L.TaggerCfg()
+        cfg.n_vocab, cfg.emb_dim = c['n_vocab'], c['emb_dim']
+        cfg.n_lstm, cfg.n_dense = len(c['lstm_hidden']), len(c['dense_dim'])
+        for i, v in enumerate(c['lstm_hidden']):
+            cfg.lstm_hidden[i] = v
+        for i, v in enumerate(c['dense_dim']):
+            cfg.dense_dim[i] = v
+        cfg.hard_sigmoid, cfg.bn_after_lstm0, cfg.bn_eps = c['hard_sigmoid'], c['bn_after_lstm0'], c['bn_eps']
+        self.n_classes = c['dense_dim'][-1]
+        arr, keep = L.make_tensors({self.RENAME.get(k, k): v for k, v in state_dict.items()})
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ttsamd_tagger_create(arr, len(arr), C.byref(cfg), C.byref(handle)), 'tagger_create')
+        self.handle = handle
+        self.ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, 'handle', None):
+            self.lib.ttsamd_tagger_destroy(self.handle)
+            self.handle = None
+
+    def forward(self, ids):
+        """ids int64 [B, T] -> probs [B, T, n_classes] on the device"""
+        ids = torch.as_tensor(ids).to(device=self.device, dtype=torch.int64).contiguous()
+        B, T = ids.shape
+        probs = torch.empty(B, T, self.n_classes, dtype=torch.float32, device=self.device)
+        if T == 0:
+            return probs
+        with torch.cuda.device(self.device):
+            nb = self.lib.ttsamd_tagger_workspace_bytes(self.handle, B, T)
+            ws = self.ws.get(nb, self.device)
+            L.check(self.lib.ttsamd_tagger_forward(self.handle, _ptr(ids), B, T, _ptr(probs), _ptr(ws), nb, _stream()),
+                    'tagger_forward')
+        return probs
+
+
 def conv1d(x, w, bias=None, lens=None, dilation=1, in_slope=1.0, relu_out=False):
     """Kernel-level entry (parity tests / roofline bench): y = conv1d(lrelu(x), w) + b, 'same' padding."""
     lib = _require_gpu()

@@ -42,6 +42,12 @@ class Tacotron2Cfg(C.Structure):
         'postnet_embedding_dim')] + [('gate_threshold', C.c_float)]
 
 
+class TaggerCfg(C.Structure):
+    _fields_ = [('n_vocab', C.c_int32), ('emb_dim', C.c_int32), ('n_lstm', C.c_int32), ('lstm_hidden', C.c_int32 * 4),
+                ('hard_sigmoid', C.c_int32), ('bn_after_lstm0', C.c_int32), ('bn_eps', C.c_float),
+                ('n_dense', C.c_int32), ('dense_dim', C.c_int32 * 4)]
+
+
 # every symbol include/ttsamd.h declares: name -> (restype, argtypes)
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -75,6 +81,10 @@ SYMBOLS = {
     'ttsamd_tacotron2_workspace_bytes': (_I64, [_P, _I32, _I32, _I32]),
     'ttsamd_tacotron2_infer': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P, _P,
                                       C.POINTER(_I32), _P, _I64, _P]),
+    'ttsamd_tagger_create': (_I32, [C.POINTER(Tensor), _I32, C.POINTER(TaggerCfg), C.POINTER(_P)]),
+    'ttsamd_tagger_destroy': (_I32, [_P]),
+    'ttsamd_tagger_workspace_bytes': (_I64, [_P, _I32, _I32]),
+    'ttsamd_tagger_forward': (_I32, [_P, _P, _I32, _I32, _P, _P, _I64, _P]),
     'ttsamd_conv1d_packed_floats': (_I64, [_I32, _I32, _I32]),
     'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     'ttsamd_set_precision': (_I32, [_I32]),

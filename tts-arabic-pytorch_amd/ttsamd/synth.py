@@ -13,7 +13,7 @@ import zlib
 
 import numpy as np
 
-from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG, TACOTRON2_CONFIG
+from .config import NET_CONFIG, HIFIGAN_CONFIG, VOCOS_22K_CONFIG, TACOTRON2_CONFIG, SHAKKELHA_CONFIG, SHAKKALA_CONFIG
 
 
 def _rng(seed, name):
@@ -179,8 +179,8 @@ def _bn(sd, seed, name, n):
     sd[name + '.running_var'] = (1.0 + 0.2 * _rng(seed, name + '.rv').random(n)).astype(np.float32)
 
 
-def _lstm(sd, seed, name, n_in, n_h, suffixes=('',)):
-    k = 1.0 / np.sqrt(n_h)
+def _lstm(sd, seed, name, n_in, n_h, suffixes=('',), gain=1.0):
+    k = gain / np.sqrt(n_h)
     for sfx in suffixes:
         sd[f'{name}.weight_ih{sfx}'] = ((_rng(seed, f'{name}.wih{sfx}').random((4 * n_h, n_in)) * 2 - 1) * k).astype(np.float32)
         sd[f'{name}.weight_hh{sfx}'] = ((_rng(seed, f'{name}.whh{sfx}').random((4 * n_h, n_h)) * 2 - 1) * k).astype(np.float32)
@@ -230,6 +230,44 @@ def tacotron2_state_dict(config=None, seed=0, gate_bias=-2.0):
         sd[f'postnet.convolutions.{i}.0.weight'] = _normal(seed, f'taco.post{i}.w', (cout, cin, pk), 1.0 / np.sqrt(cin * pk))
         sd[f'postnet.convolutions.{i}.0.bias'] = _normal(seed, f'taco.post{i}.b', (cout,), 0.1)
         _bn(sd, seed, f'postnet.convolutions.{i}.1', cout)
+    return sd
+
+
+def _dense(sd, seed, name, n_in, n_out, gain=1.4):
+    sd[name + '.weight'] = _normal(seed, name + '.w', (n_out, n_in), gain / np.sqrt(n_in))
+    sd[name + '.bias'] = _normal(seed, name + '.b', (n_out,), 0.1)
+
+
+TAGGER_LSTM_GAIN, TAGGER_OUT_GAIN = 4.0, 8.0   # make the synthetic taggers input-sensitive (varied classes)
+
+
+def shakkelha_state_dict(seed=0):
+    """Shakkelha.state_dict() (models/diacritizers/shakkelha/network.py:14-24): emb0, lstm0, lstm1 (nn.LSTM,
+    bidirectional), dense0-2.  LSTM weights are scaled up a little so the synthetic tagger is not constant."""
+    c, sd = SHAKKELHA_CONFIG, {}
+    sd['emb0.weight'] = _normal(seed, 'shakkelha.emb', (c['n_vocab'], c['emb_dim']), 1.0)
+    n_in = c['emb_dim']
+    for i, h in enumerate(c['lstm_hidden']):
+        _lstm(sd, seed, f'lstm{i}', n_in, h, ('_l0', '_l0_reverse'), gain=TAGGER_LSTM_GAIN)
+        n_in = 2 * h
+    for i, d in enumerate(c['dense_dim']):
+        _dense(sd, seed, f'dense{i}', n_in, d, 1.4 if i < len(c['dense_dim']) - 1 else TAGGER_OUT_GAIN)
+        n_in = d
+    return sd
+
+
+def shakkala_state_dict(seed=0):
+    """Shakkala.state_dict() (models/diacritizers/shakkala/network.py:13-22): emb_input, lstm0-2
+    (LSTMHardSigmoid, bidirectional), bn0 (BatchNorm1d eps 1e-3), dense0."""
+    c, sd = SHAKKALA_CONFIG, {}
+    sd['emb_input.weight'] = _normal(seed, 'shakkala.emb', (c['n_vocab'], c['emb_dim']), 1.0)
+    n_in = c['emb_dim']
+    for i, h in enumerate(c['lstm_hidden']):
+        _lstm(sd, seed, f'lstm{i}', n_in, h, ('_l0', '_l0_reverse'), gain=TAGGER_LSTM_GAIN)
+        n_in = 2 * h
+    _bn(sd, seed, 'bn0', 2 * c['lstm_hidden'][0])
+    sd['bn0.num_batches_tracked'] = np.zeros((), np.int64)
+    _dense(sd, seed, 'dense0', n_in, c['dense_dim'][0], TAGGER_OUT_GAIN)
     return sd
 
 
