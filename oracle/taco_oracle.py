@@ -84,6 +84,8 @@ def tacotron2_infer(w, cfg, tokens, speaker_ids=None, lengths=None, max_step=Non
         memory = torch.cat((enc, spk), dim=2)
     else:
         memory = enc
+    if trace is not None:
+        trace['conv_out'], trace['enc'] = x.clone(), enc.clone()           # test aid: encoder blocks vs torch.nn modules
     # ---- decoder.infer
     A, D = cfg['attention_rnn_dim'], cfg['decoder_rnn_dim']
     Mdim = memory.shape[2]

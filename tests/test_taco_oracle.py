@@ -47,3 +47,30 @@ def test_oracle_gate_stops_and_counts_like_the_reference_loop():
     a = T.tacotron2_infer(sd, cfg, tok, None, lens, max_step=3, seed=5)[0]
     b = T.tacotron2_infer(sd, cfg, tok, None, lens, max_step=3, seed=5)[0]
     assert torch.equal(a, b)
+
+
+def test_oracle_blocks_equal_the_torch_modules_torchaudio_builds_on():
+    """torchaudio's _Encoder is nn.LSTM(bidirectional) on a packed sequence, its decoder cells are nn.LSTMCell:
+    the oracle's hand-written recurrences must equal those torch modules on the same weights (op-level pin;
+    the wiring between the blocks stays a restatement)."""
+    import taco_oracle as T
+    cfg, sd, tok, lens = _setup(B=2, L=9)
+    tr = {}
+    T.tacotron2_infer(sd, cfg, tok, torch.tensor([0, 5]), lens, max_step=1, seed=-1, trace=tr)
+    lstm = torch.nn.LSTM(512, 256, 1, batch_first=True, bidirectional=True)
+    lstm.load_state_dict({k[len('encoder.lstm.'):]: torch.from_numpy(v) for k, v in sd.items()
+                          if k.startswith('encoder.lstm.')})
+    packed = torch.nn.utils.rnn.pack_padded_sequence(tr['conv_out'], lens, batch_first=True)
+    with torch.no_grad():
+        out, _ = torch.nn.utils.rnn.pad_packed_sequence(lstm(packed)[0], batch_first=True)
+    assert float((out - tr['enc']).abs().max()) < 2e-6
+    cell = torch.nn.LSTMCell(896, 1024)
+    cell.load_state_dict({k[len('decoder.attention_rnn.'):]: torch.from_numpy(v) for k, v in sd.items()
+                          if k.startswith('decoder.attention_rnn.')})
+    g = torch.Generator().manual_seed(0)
+    x, h, c = torch.randn(2, 896, generator=g), torch.randn(2, 1024, generator=g), torch.randn(2, 1024, generator=g)
+    W = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    with torch.no_grad():
+        h1, c1 = cell(x, (h, c))
+    h2, c2 = T._lstm_cell(x, h, c, W, 'decoder.attention_rnn')
+    assert float((h1 - h2).abs().max()) < 2e-6 and float((c1 - c2).abs().max()) < 2e-6
