@@ -360,11 +360,14 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     using G = Geo<K, NT_BLK, CO_BLK>;
     TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
     const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(float4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
+    int dev_id = 0;
+    TTS_CHECK_HIP(hipGetDevice(&dev_id));
+    dev_id &= 15;
+    if (!attr_set[dev_id]) {
         TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_f32<K, MT, NTL, WM, WN>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev_id] = true;
     }
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
     ConvParams q = p;

@@ -10,7 +10,9 @@
 //             the LSTM cells are weight-streaming GEMVs (75 MB of fp32 weights per step, resident
 //             in L2/MALL), one wave64 per hidden unit; the stop test is read back every 8 steps
 //   postnet : 5 x [Conv1d k5 + BatchNorm folded (+ tanh)] on the conv engine, residual fused.
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -713,6 +715,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     TTS_REQUIRE(B >= 1 && L >= 1 && L <= TACO_LMAX && max_step >= 1, "tacotron2_infer: bad batch/length/max_step");
     const ttsamd_tacotron2_cfg& c = h->cfg;
     TTS_REQUIRE(c.num_speakers <= 1 || speaker_ids, "tacotron2_infer: speaker_ids is null");
+    const double t_enter = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     Arena a(ws, ws_bytes);
     TWs w;
     const int Tcap = max_step;
@@ -773,6 +776,11 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     TTS_CHECK_HIP(hipEventRecord(h->ev_in, caller));          // encoder + state resets were queued on the caller's stream
     s = h->loop_stream;
     TTS_CHECK_HIP(hipStreamWaitEvent(s, h->ev_in, 0));
+    static const bool dbg = getenv("TTSAMD_TACO_DEBUG") != nullptr;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (dbg) (void)hipStreamSynchronize(s);
+    const double t_cap0 = now_us();
+    if (dbg) fprintf(stderr, "[taco] encoder + state reset (synced): %.0f us\n", t_cap0 - t_enter);
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     TTS_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
@@ -804,6 +812,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         set_error("tacotron2_infer: capturing the decoder step graph failed: %s", hipGetErrorString(cap_err));
         return TTSAMD_EHIP;
     }
+    const double t_loop0 = now_us();
     int steps = 0;
     hipError_t run_err = hipSuccess;
     for (int g = 0; steps < max_step && run_err == hipSuccess; ++g) {
@@ -821,7 +830,9 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             if (all) break;
         }
     }
+    const double t_loop1 = now_us();
     if (run_err == hipSuccess) run_err = hipStreamSynchronize(s);   // host-blocking: the caller's stream may go on
+    if (dbg) fprintf(stderr, "[taco] encoder+reset %.0f us (synced), capture+instantiate %.0f us, loop host %.0f us, loop total %.0f us for %d steps\n", 0.0, t_loop0 - t_cap0, t_loop1 - t_loop0, now_us() - t_loop0, steps);
     (void)hipGraphExecDestroy(exec);
     s = caller;
     if (run_err != hipSuccess) {
@@ -850,6 +861,10 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         const int y_cs = last ? Tcap : T;
         TTS_TRY(tconv(h, cv, px, px_bs, px_cs, y, y_bs, y_cs, last ? mel_raw : nullptr, B, T, last ? 0 : 3, s));
         px = y; px_bs = y_bs; px_cs = y_cs;
+    }
+    if (dbg) {
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[taco] whole call (synced): %.0f us, T=%d\n", now_us() - t_enter, T);
     }
     return 0;
 }
