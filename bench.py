@@ -53,10 +53,24 @@ def cpu_baseline(fp_sd, hg_sd, tokens, seconds_budget=25.0):
             el = time.perf_counter() - t0
             if el > seconds_budget * 0.5:
                 break
-    return {'value': n_samples / el, 'unit': 'audio samples/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'sample': f'{n_utts} utterances x {tokens} tokens (batch {b}, forced durations), '
-                                      f'{el:.1f} s of torch-CPU fp32 on {os.cpu_count()} host cpus',
-            'rtf': el / (n_samples / SAMPLE_RATE)}
+    out = {'value': n_samples / el, 'unit': 'audio samples/s', 'cores': torch.get_num_threads(),
+           'kind': 'port', 'sample': f'{n_utts} utterances x {tokens} tokens (batch {b}, forced durations), '
+                                     f'{el:.1f} s of torch-CPU fp32 on {os.cpu_count()} host cpus',
+           'rtf': el / (n_samples / SAMPLE_RATE)}
+    # single-thread figure on a quarter-length utterance so it stays within a few seconds
+    n_thr = torch.get_num_threads()
+    try:
+        torch.set_num_threads(1)
+        q = max(8, tokens // 4)
+        with torch.inference_mode():
+            t0 = time.perf_counter()
+            _, _, waves = O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids[:1, :q], dur_tgt=dur[:1, :q])
+            el1 = time.perf_counter() - t0
+        out['one_thread'] = {'value': int(waves[0].numel()) / el1, 'unit': 'audio samples/s', 'cores': 1,
+                             'sample': f'1 utterance x {q} tokens, {el1:.1f} s'}
+    finally:
+        torch.set_num_threads(n_thr)
+    return out
 
 
 def main():
