@@ -269,10 +269,97 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #undef TTS_FETCH_PART
 #undef TTS_LRELU
 
-    // epilogue: bias, residual, activation, accumulate modes.  Per half tile all loads
-    // (bias, residual, previous y) are issued first and only then consumed.
-    if (!wave_active) return;
+    // ---- epilogue: bias, residual, activation, accumulate modes ------------------------------------------
     const int co_w0 = co_blk0 + wm * MT * 32;
+#ifndef TTS_NO_VEC_EPILOGUE
+    // Row-major float4 path: the accumulator tile (32 x 32 per MFMA, one column per lane) goes through the
+    // now dead LDS ring so that every wave reads, combines and stores whole 1 KB row segments (16 B per lane)
+    // instead of 4 B per lane in 128 B pieces: 4x fewer memory instructions for the residual read and the
+    // store, which are the un-overlapped ~0.2 ms of every launch.  Needs 16-byte aligned rows.
+    {
+        const bool vec_ok = p.ksplit == 1 && p.y_ts == 1 && p.n_phase == 1 && (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 &&
+                            ((uintptr_t)p.y & 15) == 0 &&
+                            (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0));
+        if (vec_ok) {
+            constexpr int LDS_F = NSTAGE * G::BUF4 * 4;                         // floats of LDS this block owns
+            constexpr int NPASS = (CO_BLK * NT_BLK + LDS_F - 1) / LDS_F;        // the tile goes through in NPASS row slabs
+            constexpr int ROWS_P = (CO_BLK + NPASS - 1) / NPASS;
+            constexpr int LPR = NT_BLK / 4;                                     // lanes per row (one float4 each)
+            static_assert(ROWS_P * NT_BLK <= LDS_F && 64 % LPR == 0 || LPR % 64 == 0, "epilogue slab");
+            float* ep = reinterpret_cast<float*>(smem4);
+            float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+            const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+            const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
+            const float div = p.div;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                __syncthreads();                                                // ring stages / previous slab are dead
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                            if (row >= ps * ROWS_P && row < (ps + 1) * ROWS_P)
+                                ep[(row - ps * ROWS_P) * NT_BLK + qw0 + j * 32 + l31] = acc[i][j][r];
+                        }
+                __syncthreads();
+                constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                     // rows per wave instruction
+                constexpr int CPL = LPR >= 64 ? LPR / 64 : 1;                     // float4 columns groups per lane
+                for (int r0 = wid * RPI; r0 < ROWS_P; r0 += 4 * RPI) {
+                    const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
+                    const int co = co_blk0 + ps * ROWS_P + rl;
+                    if (rl >= ROWS_P || co >= Cout) continue;
+                    const float bsv = p.bias ? p.bias[co] : 0.f, scv = p.scale ? p.scale[co] : 1.f;
+#pragma unroll
+                    for (int cg = 0; cg < CPL; ++cg) {
+                        const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
+                        const int q = q0 + col;
+                        if (q >= n_out) continue;
+                        const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
+                        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                        float* yp = yb + (int64_t)co * p.y_cs + q;
+                        const float* rp = rb ? rb + (int64_t)co * p.r_cs + q : nullptr;
+                        const bool full = q + 3 < n_out;
+                        float rr4[4] = {0.f, 0.f, 0.f, 0.f}, pp4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (full) {
+                            if (rp) { const float4 t = *reinterpret_cast<const float4*>(rp); rr4[0] = t.x; rr4[1] = t.y; rr4[2] = t.z; rr4[3] = t.w; }
+                            if (mode != 0) { const float4 t = *reinterpret_cast<const float4*>(yp); pp4[0] = t.x; pp4[1] = t.y; pp4[2] = t.z; pp4[3] = t.w; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (q + e < n_out) {
+                                    if (rp) rr4[e] = rp[e];
+                                    if (mode != 0) pp4[e] = yp[e];
+                                }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = v[e] + bsv;
+                            if (relu_out == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                            x = x * scv + rr4[e];
+                            if (relu_out == 1) x = fmaxf(x, 0.f);
+                            else if (relu_out == 3) x = tanhf(x);
+                            if (mode == 1) x = pp4[e] + x;
+                            else if (mode == 2) x = (pp4[e] + x) / div;
+                            v[e] = x;
+                        }
+                        if (full) {
+                            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (q + e < n_out) yp[e] = v[e];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+#endif
+    if (!wave_active) return;
     if (p.ksplit > 1) {   // raw partial sums; bias / activation / residual happen in splitk_reduce_kernel
         float* __restrict__ pb = p.splitk_ws + ((int64_t)ks * p.batch + b) * p.Cout * p.Nout;
 #pragma unroll
