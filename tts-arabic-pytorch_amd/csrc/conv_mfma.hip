@@ -461,8 +461,8 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     q.ksplit = 1;
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
     const int n_chunks = p.Cin / G::KC;
-    if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < 192 && n_chunks >= 8) {
-        int64_t ks = std::min<int64_t>((512 + nblk - 1) / nblk, n_chunks / 4);
+    if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < 320 && n_chunks >= 8) {
+        int64_t ks = std::min<int64_t>((640 + nblk - 1) / nblk, n_chunks / 4);
         ks = std::min<int64_t>(ks, p.splitk_floats / per);
         if (ks >= 2) q.ksplit = (int)ks;
     }

@@ -217,6 +217,7 @@ void hifigan_destroy(HifiGan* h) {
 int64_t hifigan_workspace_bytes(const HifiGan* h, int32_t B, int32_t T) {
     Arena a(nullptr, 0);
     for (int i = 0; i < 4; ++i) a.take<float>((int64_t)B * h->max_cl * T);
+    a.take<float>(kSplitKFloats);
     return a.off;
 }
 
@@ -226,6 +227,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     Arena a(ws, ws_bytes);
     float* buf[4];
     for (int i = 0; i < 4; ++i) buf[i] = a.take<float>((int64_t)B * h->max_cl * T);
+    float* splitk = a.take<float>(kSplitKFloats);
     if (!ws || !a.ok) {
         set_error("hifigan_forward: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
         return TTSAMD_ENOMEM;
@@ -238,6 +240,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     p.batch = B;
     p.lens_in = lens; p.lens_out = lens;
     p.n_phase = 1; p.div = 1.f;
+    p.splitk_ws = splitk; p.splitk_floats = kSplitKFloats;     // batch 1: stage-1 launches have < 256 tiles
     auto conv = [&](const ConvW& cw, const float* x, int C_in_stride_L, float* y, const float* res, int L, int mul,
                     int dil, float slope, int mode, float div) -> int32_t {
         p.x = x; p.x_bs = (int64_t)cw.cin * L; p.x_cs = L;
