@@ -37,6 +37,13 @@ int main(int argc, char** argv) {
         if (s.cin >= s.cout) { p.res = x; p.r_bs = p.x_bs; p.r_cs = s.L; }   // residual read like c2
         p.len_in_mul = p.len_out_mul = 1; p.Lin = p.Nout = s.L; p.Cin = s.cin; p.Cout = s.cout; p.CoutP = cp; p.K = s.k;
         p.dil = s.dil; p.pad = (s.k * s.dil - s.dil) / 2; p.n_phase = 1; p.in_slope = 0.1f; p.div = 1.f; p.batch = s.B;
+#ifdef TTS_TIMING
+        unsigned long long* tbuf = nullptr;
+        const size_t tblocks = (size_t)((s.L + 31) / 32) * (cp / 32) * s.B;       // upper bound on blocks
+        hipMalloc(&tbuf, tblocks * 8 * sizeof(unsigned long long));
+        hipMemset(tbuf, 0, tblocks * 8 * sizeof(unsigned long long));
+        p.timing = tbuf;
+#endif
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int i = 0; i < 2; ++i) launch_conv(p, 0);
         hipEventRecord(e0, 0);
@@ -47,6 +54,23 @@ int main(int argc, char** argv) {
         double fl = 2.0 * s.cout * s.cin * s.k * (double)s.B * s.L;
         printf("B%d cin%d cout%d k%d d%d L%d: %.3f ms %.1f TF\n", s.B, s.cin, s.cout, s.k, s.dil, s.L, ms, fl / ms / 1e9);
         fflush(stdout);
+#ifdef TTS_TIMING
+        {
+            hipMemset(tbuf, 0, tblocks * 8 * sizeof(unsigned long long));
+            launch_conv(p, 0); hipDeviceSynchronize();
+            std::vector<unsigned long long> ht(tblocks * 8);
+            hipMemcpy(ht.data(), tbuf, ht.size() * 8, hipMemcpyDeviceToHost);
+            char fn[256]; snprintf(fn, sizeof fn, "gpurun_out/timing_c%d_k%d.csv", s.cin, s.k);
+            FILE* f = fopen(fn, "w");
+            if (f) {
+                fprintf(f, "block,start,pro,main,end,hwid,xcc\n");
+                for (size_t i = 0; i < tblocks; ++i)
+                    if (ht[i * 8]) fprintf(f, "%zu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, ht[i * 8], ht[i * 8 + 1], ht[i * 8 + 2], ht[i * 8 + 3], ht[i * 8 + 4], ht[i * 8 + 5]);
+                fclose(f);
+            }
+            hipFree(tbuf);
+        }
+#endif
         hipFree(x); hipFree(y); hipFree(w); hipFree(b);
     }
     return 0;

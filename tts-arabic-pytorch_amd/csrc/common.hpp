@@ -90,6 +90,7 @@ struct ConvParams {
     float* splitk_ws;         // >= splitk_floats floats of scratch, or nullptr (never split)
     int64_t splitk_floats;
     int32_t ksplit;           // set by the launcher
+    unsigned long long* timing;   // tools/conv_bench -DTTS_TIMING only: [blocks][8] clock samples (nullptr otherwise)
 };
 constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)
 

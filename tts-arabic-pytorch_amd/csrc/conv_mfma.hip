@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     int n_out = p.Nout;
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
     if (q0 >= n_out) return;
+#ifdef TTS_TIMING   /* tools/conv_bench: block timeline (start, prologue done, main loop done, end) per block */
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long t_pro = 0, t_main = 0;
+#endif
     int in_len = p.Lin;
     if (p.lens_in) in_len = min(in_len, (int)p.lens_in[b] * p.len_in_mul);
 
@@ -202,6 +206,9 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #pragma unroll
     for (int P = 0; P < NF; ++P) TTS_FETCH_PART(0, 0, 0, P)
 
+#ifdef TTS_TIMING
+    t_pro = wall_clock64();
+#endif
     int stage = 0;  // c % NSTAGE
     for (int c = 0; c < n_chunks; ++c) {
         // chunk to stage during this chunk (clamped: at the tail the last chunk is re-staged
@@ -269,6 +276,9 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #undef TTS_FETCH_PART
 #undef TTS_LRELU
 
+#ifdef TTS_TIMING
+    t_main = wall_clock64();
+#endif
     // ---- epilogue: bias, residual, activation, accumulate modes ------------------------------------------
     const int co_w0 = co_blk0 + wm * MT * 32;
 #ifndef TTS_NO_VEC_EPILOGUE
@@ -355,6 +365,16 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                     }
                 }
             }
+#ifdef TTS_TIMING
+            if (p.timing && threadIdx.x == 0) {
+                const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                unsigned hwid, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                unsigned long long* tp = p.timing + (size_t)lin * 8;
+                tp[0] = t_start; tp[1] = t_pro; tp[2] = t_main; tp[3] = wall_clock64(); tp[4] = hwid; tp[5] = xcc;
+            }
+#endif
             return;
         }
     }
