@@ -20,6 +20,15 @@ int main(int argc, char** argv) {
                                   {32, 64, 64, 3, 1, 57344}, {32, 64, 64, 7, 3, 57344}, {32, 64, 64, 11, 5, 57344},
                                   {32, 32, 32, 3, 1, 114688}, {32, 32, 32, 7, 3, 114688}, {32, 32, 32, 11, 5, 114688},
                                   {32, 384, 1536, 3, 1, 496}, {32, 1536, 384, 3, 1, 496}};
+    if (const char* cs = getenv("CUSTOM")) {   // CUSTOM="B,C,k,dil,L;B,C,k,dil,L;..."
+        shapes.clear();
+        int B, C, k, d, L, n = 0;
+        while (sscanf(cs, "%d,%d,%d,%d,%d%n", &B, &C, &k, &d, &L, &n) == 5) {
+            shapes.push_back({B, C, C, k, d, L});
+            cs += n;
+            if (*cs == ';') ++cs;
+        }
+    }
     for (auto s : shapes) {
         const int cp = cout_padded(s.cout);
         float *x, *w, *y, *b;
