@@ -10,7 +10,7 @@ class Denoiser(_HipModule):
     def __init__(self, hifigan, filter_length=1024, n_overlap=4, win_length=1024, mode='zeros', **infer_kw):
         super().__init__()
         assert filter_length == 1024 and n_overlap == 4 and win_length == 1024, 'only the shipped 1024/256 STFT is built'
-        assert mode == 'zeros', "only mode='zeros' is built (denoiser.py:50)"
+        self._mel_init = {'zeros': torch.zeros, 'normal': torch.randn}[mode]     # denoiser.py:50-51
         self._hifigan = [hifigan]            # not a sub-module: the vocoder is owned by the caller
         self._bias = {}
         dev = hifigan.device if hasattr(hifigan, 'device') else torch.device('cpu')
@@ -26,7 +26,7 @@ class Denoiser(_HipModule):
             moved = voc.device != dev
             if moved:
                 voc.to(dev)
-            bias_audio = voc(torch.zeros(1, 80, 88, device=dev))          # denoiser.py:50-54
+            bias_audio = voc(self._mel_init((1, 80, 88), device=dev))         # denoiser.py:50-54
             self._bias[key] = eng.bias_spec(bias_audio.reshape(-1))
         return self._bias[key]
 
