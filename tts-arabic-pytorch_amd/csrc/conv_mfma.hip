@@ -317,11 +317,24 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                 __syncthreads();
                 constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                     // rows per wave instruction
                 constexpr int CPL = LPR >= 64 ? LPR / 64 : 1;                     // float4 columns groups per lane
-                for (int r0 = wid * RPI; r0 < ROWS_P; r0 += 4 * RPI) {
+                constexpr int NR = (ROWS_P + 4 * RPI - 1) / (4 * RPI);            // row iterations per wave
+                // bias / scale of this wave's rows first: inside the loop each of them is a vmcnt(0) wait, and on
+                // this ISA such a wait also covers the previous row's store
+                float rbias[NR], rscale[NR];
+#pragma unroll
+                for (int it = 0; it < NR; ++it) {
+                    const int rl_ = wid * RPI + it * 4 * RPI + (LPR >= 64 ? 0 : lane / LPR);
+                    const int co_ = min(co_blk0 + ps * ROWS_P + rl_, Cout - 1);
+                    rbias[it] = p.bias ? p.bias[co_] : 0.f;
+                    rscale[it] = p.scale ? p.scale[co_] : 1.f;
+                }
+#pragma unroll
+                for (int it = 0; it < NR; ++it) {
+                    const int r0 = wid * RPI + it * 4 * RPI;
                     const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
                     const int co = co_blk0 + ps * ROWS_P + rl;
                     if (rl >= ROWS_P || co >= Cout) continue;
-                    const float bsv = p.bias ? p.bias[co] : 0.f, scv = p.scale ? p.scale[co] : 1.f;
+                    const float bsv = rbias[it], scv = rscale[it];
 #pragma unroll
                     for (int cg = 0; cg < CPL; ++cg) {
                         const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
