@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
     const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + tl;
     const int64_t* idb = ids + (int64_t)b * L;
-    if (blockIdx.x == 0 && g == 0) {
+    if (blockIdx.x == 0 && blockIdx.z == 0 && g == 0) {
         int cnt = 0;
         for (int i = tl; i < L; i += 64) cnt += (idb[i] != pad_idx) ? 1 : 0;
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
     const float m = (id != pad_idx) ? 1.f : 0.f;
     const float* er = word_emb + id * C;
     float* xb = x + (int64_t)b * C * L;
-    for (int c = g; c < C; c += 4) {
+    for (int c = g + 4 * blockIdx.z; c < C; c += 4 * gridDim.z) {
         float v = er[c] + pos[(int64_t)c * pos_stride + t] * m;
         if (spk) v += spk[c];
         xb[(int64_t)c * L + t] = v;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 
 int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos_table, int32_t pos_stride,
                      const float* spk, int32_t pad_idx, int32_t B, int32_t L, int32_t C, float* x, int64_t* lens, hipStream_t s) {
-    dim3 grid((L + 63) / 64, B);
+    dim3 grid((L + 63) / 64, B, 8);     // z: channel slices (the kernel is latency-bound at one block per utterance)
     hipLaunchKernelGGL(embed_kernel, grid, dim3(256), 0, s, ids, word_emb, pos_table, pos_stride, spk, pad_idx, L,
                        C, x, lens);
     TTS_CHECK_HIP(hipGetLastError());
@@ -244,66 +244,90 @@ int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos
 
 // ------------------------------------------------------------------------------------
 // Single-head attention, flash-style (online softmax), fp32 VALU: 0.1 % of the path's FLOPs.
-// Block = 64 queries of one utterance; key/value tiles of 64 streamed through LDS.
-// Thread (ti = tid/16, tj = tid%16) owns score rows i0=4*ti.. and score cols / out dims 4*tj..
+// Block = QT = 16*RA queries of one utterance; key/value tiles of 64 streamed through LDS, the next
+// tile's 32 values per thread are already in flight (registers) while the current one is consumed.
+// Thread (ti = tid/16, tj = tid%16) owns score rows i0=RA*ti.. and score cols / out dims 4*tj..
+// RA = 4 (64 queries per block) when that already fills the chip, RA = 1 (16 queries) otherwise:
+// the arithmetic per (query, key) is the same in both, so the result does not depend on RA.
 // ------------------------------------------------------------------------------------
 constexpr int ATT_D = 64;
+template <int RA>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
                                                         const int64_t* __restrict__ lens, int S, float scale,
                                                         float* __restrict__ out) {
-    __shared__ float Qs[ATT_D][64 + 4];
+    constexpr int QT = 16 * RA;
+    __shared__ float Qs[ATT_D][QT + 4];
     __shared__ float Ks[ATT_D][64 + 4];
     __shared__ float Vs[ATT_D][64 + 1];
-    __shared__ float Ps[64][64 + 4];
+    __shared__ float Ps[QT][64 + 4];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int ti = tid >> 4, tj = tid & 15;
-    const int i0 = ti * 4, j0 = tj * 4;
-    const int qbase = blockIdx.x * 64;
+    const int i0 = ti * RA, j0 = tj * 4;
+    const int qbase = blockIdx.x * QT;
     int len = S;
     if (lens) len = min(S, (int)lens[b]);
     const float* qb = qkv + (int64_t)b * 3 * ATT_D * S;
     const float* kb = qb + (int64_t)ATT_D * S;
     const float* vb = kb + (int64_t)ATT_D * S;
 
-    for (int e = tid; e < ATT_D * 64; e += 256) {
-        const int d = e >> 6, i = e & 63;
+    for (int e = tid; e < ATT_D * QT; e += 256) {
+        const int d = e / QT, i = e % QT;
         Qs[d][i] = (qbase + i < S) ? qb[(int64_t)d * S + qbase + i] : 0.f;
     }
-    float m_run[4], l_run[4], o[4][4];
+    float m_run[RA], l_run[RA], o[RA][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < RA; ++a) {
         m_run[a] = -INFINITY;
         l_run[a] = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[a][c] = 0.f;
     }
+    // element e = tid + 256*r of a [64 d][64 j] tile: d = 4*r + tid/64, j = tid%64
+    const int lj = tid & 63, ld = tid >> 6;
+    float kreg[16], vreg[16];
+    auto fetch = [&](int kt) {
+        const bool ok = kt + lj < len;
+        const int64_t off = (int64_t)ld * S + kt + lj;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            kreg[r] = ok ? kb[off + (int64_t)(4 * r) * S] : 0.f;
+            vreg[r] = ok ? vb[off + (int64_t)(4 * r) * S] : 0.f;
+        }
+    };
+    if (len > 0) fetch(0);
     for (int kt = 0; kt < len; kt += 64) {
         __syncthreads();
-        for (int e = tid; e < ATT_D * 64; e += 256) {
-            const int d = e >> 6, j = e & 63;
-            const bool ok = kt + j < len;
-            Ks[d][j] = ok ? kb[(int64_t)d * S + kt + j] : 0.f;
-            Vs[d][j] = ok ? vb[(int64_t)d * S + kt + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            Ks[4 * r + ld][lj] = kreg[r];
+            Vs[4 * r + ld][lj] = vreg[r];
         }
         __syncthreads();
-        float sc[4][4];
+        if (kt + 64 < len) fetch(kt + 64);
+        float sc[RA][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < RA; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) sc[a][c] = 0.f;
         for (int d = 0; d < ATT_D; ++d) {
-            const float4 qv = *reinterpret_cast<const float4*>(&Qs[d][i0]);
+            float qa[RA];
+            if constexpr (RA == 4) {
+                const float4 qv = *reinterpret_cast<const float4*>(&Qs[d][i0]);
+                qa[0] = qv.x; qa[1] = qv.y; qa[2] = qv.z; qa[3] = qv.w;
+            } else {
+#pragma unroll
+                for (int a = 0; a < RA; ++a) qa[a] = Qs[d][i0 + a];
+            }
             const float4 kv = *reinterpret_cast<const float4*>(&Ks[d][j0]);
-            const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
             const float ka[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RA; ++a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) sc[a][c] = fmaf(qa[a], ka[c], sc[a][c]);
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < RA; ++a) {
             float mx = -INFINITY;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -330,20 +354,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         __syncthreads();
         // O[i0+a][d0+c] += sum_j P[i0+a][j] * V[d0+c][j], d0 = j0
         for (int j = 0; j < 64; ++j) {
-            float pa[4], va[4];
+            float pa[RA], va[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) pa[a] = Ps[i0 + a][j];
+            for (int a = 0; a < RA; ++a) pa[a] = Ps[i0 + a][j];
 #pragma unroll
             for (int c = 0; c < 4; ++c) va[c] = Vs[j0 + c][j];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RA; ++a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[a][c] = fmaf(pa[a], va[c], o[a][c]);
         }
     }
     float* ob = out + (int64_t)b * ATT_D * S;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < RA; ++a) {
         const int i = qbase + i0 + a;
         if (i >= S) continue;
         const float inv = 1.0f / l_run[a];
@@ -356,8 +380,13 @@ int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32
                          float* out, hipStream_t s) {
     TTS_REQUIRE(D == ATT_D, "attention: d_head=%d, only %d is built", D, ATT_D);
     if (S <= 0 || B <= 0) return 0;
-    dim3 grid((S + 63) / 64, B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
+    if ((int64_t)((S + 63) / 64) * B >= 1024) {
+        dim3 grid((S + 63) / 64, B);
+        hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
+    } else {
+        dim3 grid((S + 15) / 16, B);
+        hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
+    }
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -365,17 +394,25 @@ int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32
 // ------------------------------------------------------------------------------------
 // Predictor head (model.py:132) + duration transform (model.py:368) / pitch_trf (networks.py:38-42)
 // ------------------------------------------------------------------------------------
+// Block = 16 positions x 16 channel groups (group g sums c = g, g+16, ...), LDS reduction in group order.
 __global__ __launch_bounds__(256) void pred_fc_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias,
                                                       const int64_t* __restrict__ lens, int C, int S,
                                                       float* __restrict__ out, float* __restrict__ out2,
                                                       float max_dur, float mul, float add) {
+    __shared__ float part[16][17];
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= S) return;
-    const float* xb = x + (int64_t)b * C * S;
+    const int tl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + tl;
+    const float* xb = x + (int64_t)b * C * S + (t < S ? t : 0);
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = fmaf(w[c], xb[(int64_t)c * S + t], acc);
+    for (int c = g; c < C; c += 16) acc = fmaf(w[c], xb[(int64_t)c * S], acc);
+    part[g][tl] = acc;
+    __syncthreads();
+    if (g != 0 || t >= S) return;
+    acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += part[k][tl];
     acc += bias[0];
     if (lens && t >= (int)lens[b]) acc = 0.f;   // "* enc_out_mask"
     if (out2) out2[(int64_t)b * S + t] = fminf(fmaxf(expf(acc) - 1.0f, 0.f), max_dur);
@@ -385,7 +422,7 @@ __global__ __launch_bounds__(256) void pred_fc_kernel(const float* __restrict__ 
 int32_t launch_pred_fc(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t B,
                        int32_t C, int32_t S, float* out, float* out2, float max_dur, float mul, float add,
                        hipStream_t s) {
-    dim3 grid((S + 255) / 256, B);
+    dim3 grid((S + 15) / 16, B);
     hipLaunchKernelGGL(pred_fc_kernel, grid, dim3(256), 0, s, x, w, bias, lens, C, S, out, out2, max_dur, mul,
                        add);
     TTS_CHECK_HIP(hipGetLastError());
@@ -486,10 +523,10 @@ __global__ __launch_bounds__(256) void regulate_gather_kernel(const float* __res
         }
         j = lo;
     }
-    if (idx) idx[(int64_t)b * T + t] = j;
+    if (idx && blockIdx.z == 0) idx[(int64_t)b * T + t] = j;
     const float* eb = enc + (int64_t)b * C * L;
     float* ob = out + (int64_t)b * C * T;
-    for (int c = 0; c < C; ++c) {
+    for (int c = blockIdx.z; c < C; c += gridDim.z) {
         float v = 0.f;
         if (j >= 0) {
             v = eb[(int64_t)c * L + j];
@@ -503,7 +540,7 @@ int32_t launch_regulate_gather(const float* enc, const int64_t* reps, const floa
                                int32_t B, int32_t L, int32_t C, int32_t T, float* out, int32_t* idx, hipStream_t s) {
     TTS_REQUIRE(L <= REG_MAX_L, "length_regulate: n_tokens=%d exceeds %d", L, REG_MAX_L);
     if (T <= 0 || B <= 0) return 0;
-    dim3 grid((T + 255) / 256, B);
+    dim3 grid((T + 255) / 256, B, 16);  // z: channel slices; every slice redoes the (cheap) scan and search
     hipLaunchKernelGGL(regulate_gather_kernel, grid, dim3(256), 0, s, enc, reps, pos_table, pos_stride, L, C,
                        T, out, idx);
     TTS_CHECK_HIP(hipGetLastError());
