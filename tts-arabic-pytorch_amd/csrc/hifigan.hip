@@ -4,7 +4,9 @@
 // (vocoder/hifigan/models.py:111-127) incl. ResBlock1.forward (:46-53).
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,7 +29,23 @@ struct HifiGan {
     std::vector<ConvW> c1, c2;  // [stage*n_kernels + j][m]
     int hop = 1;
     int64_t max_cl = 0;  // max over stages of C * (L / T)
+    // small batches: the three ResBlocks of a stage run on three streams (guarded by mu, created on first use)
+    mutable std::mutex mu;
+    mutable hipStream_t side[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
 };
+
+// The ResBlocks of one stage are independent until their sum.  When a launch cannot fill the chip for long
+// (batch 1..8: 1-3 rounds of blocks per launch, so up to a third of the chip idles in each launch's tail) they
+// are issued on three streams; only the last conv of each branch, which accumulates into the stage output, is
+// chained j = 0 -> 1 -> 2 by events, so the sum is formed in the reference's order (bit-identical results).
+// At batch 32 a launch has > 10 rounds and the branches stay on one stream (TTSAMD_HIFIGAN_STREAMS=0/1 forces).
+static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
+    if (h->cfg.n_kernels != 3) return false;
+    static const char* env = std::getenv("TTSAMD_HIFIGAN_STREAMS");
+    if (env) return env[0] == '1';
+    return (int64_t)B * T <= 4608;
+}
 
 using TensorMap = std::map<std::string, const ttsamd_tensor*>;
 
@@ -211,13 +229,17 @@ void hifigan_destroy(HifiGan* h) {
     if (!h) return;
     if (h->dev) (void)hipFree(h->dev);
     if (h->dev16) (void)hipFree(h->dev16);
+    for (hipStream_t st : h->side) if (st) (void)hipStreamDestroy(st);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_done) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
 int64_t hifigan_workspace_bytes(const HifiGan* h, int32_t B, int32_t T) {
     Arena a(nullptr, 0);
-    for (int i = 0; i < 4; ++i) a.take<float>((int64_t)B * h->max_cl * T);
-    a.take<float>(kSplitKFloats);
+    const int nb = use_branch_streams(h, B, T) ? 3 : 1;
+    for (int i = 0; i < 2 + 2 * nb; ++i) a.take<float>((int64_t)B * h->max_cl * T);
+    for (int i = 0; i < nb; ++i) a.take<float>(kSplitKFloats);
     return a.off;
 }
 
@@ -225,23 +247,42 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                         void* ws, int64_t ws_bytes, hipStream_t s) {
     TTS_REQUIRE(h && mel && wave && B >= 1 && T >= 1, "hifigan_forward: bad argument");
     Arena a(ws, ws_bytes);
-    float* buf[4];
-    for (int i = 0; i < 4; ++i) buf[i] = a.take<float>((int64_t)B * h->max_cl * T);
-    float* splitk = a.take<float>(kSplitKFloats);
+    const bool multi = use_branch_streams(h, B, T);
+    const int nb = multi ? 3 : 1;
+    float* cur = a.take<float>((int64_t)B * h->max_cl * T);
+    float* ups_out = a.take<float>((int64_t)B * h->max_cl * T);
+    float *Tbs[3], *Rs[3], *splitks[3];
+    for (int i = 0; i < nb; ++i) {
+        Tbs[i] = a.take<float>((int64_t)B * h->max_cl * T);
+        Rs[i] = a.take<float>((int64_t)B * h->max_cl * T);
+    }
+    for (int i = 0; i < nb; ++i) splitks[i] = a.take<float>(kSplitKFloats);
+    for (int i = nb; i < 3; ++i) { Tbs[i] = Tbs[0]; Rs[i] = Rs[0]; splitks[i] = splitks[0]; }
     if (!ws || !a.ok) {
         set_error("hifigan_forward: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
         return TTSAMD_ENOMEM;
     }
     const ttsamd_hifigan_cfg& cfg = h->cfg;
-    float *cur = buf[0], *ups_out = buf[1], *R = buf[2], *Tb = buf[3];
+    std::unique_lock<std::mutex> lk(h->mu, std::defer_lock);
+    hipStream_t bs[3] = {s, s, s};
+    if (multi) {
+        lk.lock();
+        if (!h->ev_fork) {
+            for (auto& st : h->side) TTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            TTS_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            for (auto& e : h->ev_done) TTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        bs[1] = h->side[0];
+        bs[2] = h->side[1];
+    }
 
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.batch = B;
     p.lens_in = lens; p.lens_out = lens;
     p.n_phase = 1; p.div = 1.f;
-    p.splitk_ws = splitk; p.splitk_floats = kSplitKFloats;     // batch 1: stage-1 launches have < 256 tiles
-    auto conv = [&](const ConvW& cw, const float* x, int C_in_stride_L, float* y, const float* res, int L, int mul,
+    p.splitk_ws = splitks[0]; p.splitk_floats = kSplitKFloats;     // batch 1: stage-1 launches have < 256 tiles
+    auto conv = [&](const ConvW& cw, const float* x, hipStream_t st, float* y, const float* res, int L, int mul,
                     int dil, float slope, int mode, float div) -> int32_t {
         p.x = x; p.x_bs = (int64_t)cw.cin * L; p.x_cs = L;
         p.w = h->dev + cw.w_off; p.bias = h->dev + cw.b_off;
@@ -253,15 +294,14 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         p.dil = dil; p.pad = (cw.k * dil - dil) / 2;
         p.n_phase = 1; p.phase_p = 0;
         p.in_slope = slope; p.relu_out = 0; p.mode = mode; p.div = div;
-        (void)C_in_stride_L;
-        prof_begin(s, 2.0 * cw.cout * cw.cin * cw.k * mul);
-        const int32_t rc = launch_conv(p, s);
-        prof_end(s);
+        prof_begin(st, 2.0 * cw.cout * cw.cin * cw.k * mul);
+        const int32_t rc = launch_conv(p, st);
+        prof_end(st);
         return rc;
     };
 
     // conv_pre (models.py:112)
-    TTS_TRY(conv(h->conv_pre, mel, 0, cur, nullptr, T, 1, 1, 1.0f, 0, 1.f));
+    TTS_TRY(conv(h->conv_pre, mel, s, cur, nullptr, T, 1, 1, 1.0f, 0, 1.f));
     int L = T, mul = 1;
     for (int i = 0; i < cfg.n_ups; ++i) {
         const int u = cfg.upsample_rates[i], kt = cfg.upsample_kernel_sizes[i];
@@ -282,22 +322,32 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         TTS_TRY(rc);
         L *= u; mul *= u;
         // 3 ResBlock1 on the same input, averaged (models.py:116-122, 46-53)
+        if (multi) TTS_CHECK_HIP(hipEventRecord(h->ev_fork, s));
         for (int j = 0; j < cfg.n_kernels; ++j) {
+            hipStream_t st = bs[j % 3];
+            float *Tb = Tbs[j % 3], *R = Rs[j % 3];
+            p.splitk_ws = splitks[j % 3];
+            if (multi && j > 0) TTS_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
             const float* src = ups_out;
             for (int m = 0; m < cfg.n_dilations; ++m) {
                 const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
                 const int d = cfg.resblock_dilations[j][m];
-                TTS_TRY(conv(h->c1[li], src, 0, Tb, nullptr, L, mul, d, 0.1f, 0, 1.f));
+                TTS_TRY(conv(h->c1[li], src, st, Tb, nullptr, L, mul, d, 0.1f, 0, 1.f));
                 if (m + 1 < cfg.n_dilations) {
-                    TTS_TRY(conv(h->c2[li], Tb, 0, R, src, L, mul, 1, 0.1f, 0, 1.f));
+                    TTS_TRY(conv(h->c2[li], Tb, st, R, src, L, mul, 1, 0.1f, 0, 1.f));
                     src = R;
                 } else {
                     const int mode = (j == 0) ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2);
                     const int md = cfg.n_kernels == 1 ? 0 : mode;
-                    TTS_TRY(conv(h->c2[li], Tb, 0, cur, src, L, mul, 1, 0.1f, md, (float)cfg.n_kernels));
+                    // the accumulation into `cur` follows branch j-1's
+                    if (multi && j > 0) TTS_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
+                    TTS_TRY(conv(h->c2[li], Tb, st, cur, src, L, mul, 1, 0.1f, md, (float)cfg.n_kernels));
+                    if (multi) TTS_CHECK_HIP(hipEventRecord(h->ev_done[j], st));
                 }
             }
         }
+        p.splitk_ws = splitks[0];
+        if (multi) TTS_CHECK_HIP(hipStreamWaitEvent(s, h->ev_done[cfg.n_kernels - 1], 0));
     }
     // leaky_relu (default slope 0.01) + conv_post + tanh (models.py:123-125)
     TTS_TRY(launch_conv_post(cur, (int64_t)h->conv_post.cin * L, L, h->dev + h->conv_post.w_off,
