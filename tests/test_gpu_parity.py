@@ -436,3 +436,52 @@ def test_c_abi_error_codes(dev, hifigan_engine):
     arr, keep = L.make_tensors({})
     assert lib.ttsamd_hifigan_create(arr, 0, C.byref(cfg), C.byref(h)) == -1      # missing tensors
     assert b'conv_pre' in lib.ttsamd_last_error()
+
+
+def test_full_size_bench_workload_properties(dev, synth_weights, fastpitch_engine, hifigan_engine):
+    """BASELINE config 2 at its full size (32 utterances x 64 tokens, the bench.py workload; single-stream
+    vocoder, large tiles).  The oracle needs ~1 s per utterance, so it checks two utterances; the rest is
+    covered by size-independent properties: run-to-run determinism, frame counts = sum of the durations,
+    silence past each utterance's end, |wave| <= 1, and batch independence (the same utterance synthesised
+    alone goes through the small-batch path: split-K, three streams, other tiles)."""
+    import tts_oracle as O
+    from ttsamd import synth
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    B, Lt = 32, 64
+    ids = torch.from_numpy(synth.synth_ids(B, Lt)).to(dev)
+    dur = torch.from_numpy(synth.synth_durations(B, Lt)).to(dev)
+    mel, dec_lens, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
+    wave = hifigan_engine.forward(mel, dec_lens)
+    mel2, dec_lens2, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
+    wave2 = hifigan_engine.forward(mel2, dec_lens2)
+    assert torch.equal(mel, mel2) and torch.equal(wave, wave2)                  # deterministic
+    dl = dec_lens.cpu().numpy()
+    assert np.array_equal(dl, np.floor(dur.cpu().numpy() + 0.5).astype(np.int64).sum(1))
+    assert wave.shape == (B, 256 * int(dl.max())) and bool(torch.isfinite(wave).all())
+    assert float(wave.abs().max()) <= 1.0
+    w = wave.cpu()
+    for b in range(B):
+        assert float(w[b, 256 * int(dl[b]):].abs().max()) == 0.0 if dl[b] < dl.max() else True
+    # batch independence of the vocoder: an utterance's mel vocoded alone (small-batch path) gives the same wave
+    for b in (0, 13, 31):
+        n = int(dl[b])
+        w1 = hifigan_engine.forward(mel[b:b + 1, :, :n].contiguous(), dec_lens[b:b + 1])
+        assert maxabs(w1[0], wave[b, :256 * n]) < WAVE_TOL
+    # FastPitch follows the reference's padded-batch semantics (SURVEY §3.4-1: the conv-FF hidden layer is not
+    # masked, so an utterance's last frames see relu(bias) from the first pad frame when a longer utterance
+    # shares the batch, and zero padding when it is the longest).  Only the longest utterance is therefore
+    # batch-independent; the oracle sub-batch below contains it for the same reason.
+    bmax = int(np.argmax(dl))
+    m1, l1, *_ = fastpitch_engine.infer(ids[bmax:bmax + 1], dur_tgt=dur[bmax:bmax + 1])
+    assert int(l1[0]) == int(dl[bmax]) and maxabs(m1[0], mel[bmax]) < 1e-4
+    fw, hw = O.to_torch(synth_weights['fastpitch']), O.fold_weight_norm(synth_weights['hifigan'])
+    sel = [5 if bmax != 5 else 6, bmax]
+    assert dl[sel[0]] < dl[bmax]
+    with torch.inference_mode():
+        mel_ref, lens_ref, waves_ref = O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids[sel].cpu().numpy(),
+                                                   dur_tgt=dur[sel].cpu().numpy())
+    for r, b in enumerate(sel):
+        n = int(dl[b])
+        assert int(lens_ref[r]) == n
+        assert maxabs(mel[b, :, :n], np.asarray(mel_ref[r])[:, :n]) < MEL_TOL
+        assert maxabs(w[b, :256 * n], waves_ref[r]) < WAVE_TOL
