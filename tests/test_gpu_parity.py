@@ -485,3 +485,19 @@ def test_full_size_bench_workload_properties(dev, synth_weights, fastpitch_engin
         assert int(lens_ref[r]) == n
         assert maxabs(mel[b, :, :n], np.asarray(mel_ref[r])[:, :n]) < MEL_TOL
         assert maxabs(w[b, :256 * n], waves_ref[r]) < WAVE_TOL
+
+
+def test_hifigan_branch_streams_bit_identical(dev, hifigan_engine, monkeypatch):
+    """Small batches run the three ResBlocks of a stage on three streams (csrc/hifigan.hip); the accumulation
+    into the stage output is event-chained in the reference's order, so the waves must equal the one-stream
+    result bit for bit, call after call (a missing dependency would show up as run-to-run differences)."""
+    rng = np.random.default_rng(11)
+    lens = torch.tensor([37, 12, 30]).to(dev)
+    mel = torch.from_numpy((rng.standard_normal((3, 80, 37)) * 1.5 - 4.0).astype(np.float32)).to(dev)
+    monkeypatch.setenv('TTSAMD_HIFIGAN_STREAMS', '0')
+    ref = hifigan_engine.forward(mel, lens).clone()
+    monkeypatch.setenv('TTSAMD_HIFIGAN_STREAMS', '1')
+    for _ in range(20):
+        assert torch.equal(hifigan_engine.forward(mel, lens), ref)
+    monkeypatch.delenv('TTSAMD_HIFIGAN_STREAMS')
+    assert torch.equal(hifigan_engine.forward(mel, lens), ref)

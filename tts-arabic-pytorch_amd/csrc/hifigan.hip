@@ -42,7 +42,7 @@ struct HifiGan {
 // At batch 32 a launch has > 10 rounds and the branches stay on one stream (TTSAMD_HIFIGAN_STREAMS=0/1 forces).
 static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
     if (h->cfg.n_kernels != 3) return false;
-    static const char* env = std::getenv("TTSAMD_HIFIGAN_STREAMS");
+    const char* env = std::getenv("TTSAMD_HIFIGAN_STREAMS");   // read per call: the tests flip it
     if (env) return env[0] == '1';
     return (int64_t)B * T <= 4608;
 }
