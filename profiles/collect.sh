@@ -21,4 +21,5 @@ python3 profiles/pmc_summarize.py $O/pmc_mfma > $O/pmc_mfma_by_kernel.txt
 python3 profiles/pmc_summarize.py $O/pmc_fetch > $O/pmc_fetch_by_kernel.txt
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma
+bash profiles/collect_small.sh $R > /dev/null 2>&1
 tail -c 600 $O/final_bench_line.json
