@@ -527,6 +527,8 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
         case 3: if (p.CoutP % 64 == 0) return launch_cfg<K, 1, 1, 2, 2>(p, stream); break;
         case 4: return launch_cfg<K, 1, 2, 1, 4>(p, stream);
         case 5: return launch_cfg<K, 1, 1, 1, 4>(p, stream);
+        case 6: if (p.CoutP % 64 == 0) return launch_cfg<K, 1, 2, 2, 2>(p, stream); break;   // 64 co x 128 t
+        case 7: if (p.CoutP % 128 == 0) return launch_cfg<K, 2, 1, 2, 2>(p, stream); break;  // 128 co x 64 t, 2x1 tiles per wave
     }
 #endif
     if (p.CoutP % 128 == 0) {
