@@ -501,3 +501,34 @@ def test_hifigan_branch_streams_bit_identical(dev, hifigan_engine, monkeypatch):
         assert torch.equal(hifigan_engine.forward(mel, lens), ref)
     monkeypatch.delenv('TTSAMD_HIFIGAN_STREAMS')
     assert torch.equal(hifigan_engine.forward(mel, lens), ref)
+
+
+def test_dropin_app_utils_request_flow(dev, golden, checkpoints):
+    """utils/app_utils.py:62-81 (TTSManager.tts): per request model.to(device) -> ttmel -> vocoder ->
+    denoiser -> peak-normalise to 0.99 -> model.cpu().  The second request must reuse the device handle
+    (no weight re-upload) and give the same audio."""
+    from models.fastpitch import FastPitch
+    from vocoder import load_hifigan
+    from vocoder.hifigan.denoiser import Denoiser
+    from utils.audio import peak_normalise
+    e = golden('e2e_tts')
+    text = _lines(golden, e['line_idx'])[0]
+    model = FastPitch(checkpoints[0])
+    vocoder = load_hifigan(checkpoints[1], checkpoints[2])
+    denoiser = Denoiser(vocoder, mode='zeros')
+    vocoder.to(dev)
+    denoiser.to(dev)
+    outs, engines = [], []
+    for _ in range(2):
+        model.to(dev)
+        mel = model.ttmel(text, speed=1)
+        wave = vocoder(mel)
+        wave_den = denoiser(wave, 0.01)
+        wave_den = wave_den / wave_den.abs().max() * 0.99
+        outs.append(wave_den.cpu())
+        engines.append(model.engine())
+        model.cpu()
+    assert engines[0] is engines[1]
+    assert torch.equal(outs[0], outs[1])
+    assert abs(float(outs[0].abs().max()) - 0.99) < 1e-6
+    assert maxabs(peak_normalise(wave_den.cpu().reshape(-1)), outs[0].reshape(-1)) < 1e-6

@@ -11,8 +11,8 @@ LRELU_SLOPE = 0.1
 
 
 class _HipModule(nn.Module):
-    """Weights live in C-ABI handles, one per device, created lazily; `.to()/.cuda()/.cpu()`
-    behave as for any nn.Module (a 1-element anchor parameter tracks the device).  Running on
+    """Weights live in C-ABI handles, one per device, created lazily and kept; `.to()/.cuda()/.cpu()`
+    move a 1-element anchor parameter that tracks the device the next call runs on.  Running on
     a non-ROCm device raises: there is no CPU path."""
 
     def __init__(self):
@@ -25,11 +25,15 @@ class _HipModule(nn.Module):
         return self._anchor.device
 
     def _apply(self, fn, *a, **k):
-        out = super()._apply(fn, *a, **k)
-        dev = self._anchor.device
-        for key in [k_ for k_ in self._engines if k_ != str(dev)]:
-            del self._engines[key]            # frees the device copy of the weights
-        return out
+        # Device handles survive `.cpu()` / `.to(other)`: the reference's server moves each model to the GPU
+        # and back on every request (utils/app_utils.py:65,81) to share a small card; with 288 GB of HBM the
+        # packed weights (< 1 GB for every model of this repo together) simply stay resident, so the next
+        # `.to('cuda')` costs nothing.  `release_device_memory()` frees them explicitly.
+        return super()._apply(fn, *a, **k)
+
+    def release_device_memory(self):
+        """Destroy the C-ABI handles (device copies of the packed weights) of every device."""
+        self._engines.clear()
 
     def _engine(self, factory):
         dev = self._anchor.device
