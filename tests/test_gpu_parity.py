@@ -50,6 +50,46 @@ def test_conv1d_kernel(dev, cin, cout, k, dil, lin, B):
         assert float(y[i, :, n:].abs().max()) == 0.0 if n < lin else True
 
 
+def _conv_fuzz(dev, cases, tol, seed):
+    from ttsamd.engine import conv1d
+    rng = np.random.default_rng(seed)
+    for (cin, cout, k, dil, lin, B) in cases:
+        g = torch.Generator().manual_seed(cin + 7 * cout + 13 * k + lin)
+        x = torch.randn(B, cin, lin, generator=g)
+        w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+        b = torch.randn(cout, generator=g)
+        lens = torch.from_numpy(rng.integers(lin // 2, lin + 1, size=B)).long()
+        lens[0], lens[B - 1] = lin, 0
+        if B > 4:
+            lens[1], lens[2], lens[3] = 1, 255, 257
+        y = conv1d(x.to(dev), w.to(dev), b.to(dev), lens.to(dev), dilation=dil, in_slope=0.1).cpu()
+        for i in rng.choice(B, size=min(B, 6), replace=False).tolist() + [0, B - 1]:
+            n = int(lens[i])
+            if n:
+                ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x[i:i + 1, :, :n].double(), 0.1),
+                                                 w.double(), b.double(), dilation=dil, padding=(k * dil - dil) // 2)[0]
+                assert maxabs(y[i, :, :n], ref) < tol, (cin, cout, k, dil, lin, i, n)
+            assert float(y[i, :, n:].abs().max()) == 0.0 if n < lin else True, (cin, cout, k, dil, lin, i, n)
+
+
+def _large_tile_cases(seed, ks=(3, 7, 11)):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for c in (32, 64, 128, 256):
+        for k in ks:
+            big = int(rng.choice([2048, 4096 + 1, 6144 - 1]))
+            cases.append((c, c, k, int(rng.integers(1, 6)), big, 24 if c < 256 else 12))
+    return cases + [(384, 1536, 3, 1, 500, 16), (1536, 384, 3, 1, 497, 16), (80, 512, 7, 1, 513, 16), (512, 80, 5, 2, 300, 8)]
+
+
+def test_conv1d_kernel_large_tiles_fuzz(dev):
+    """The cases above are small, so the launcher always picks its smallest tiles.  Here batch x length is
+    large enough for every tile shape of the launcher (128x128, 64x256, 32x256, 128x64, 64x64, 32x128), with
+    random dilations, lengths straddling tile edges and ragged utterances (some empty), against torch on the
+    CPU in float64."""
+    _conv_fuzz(dev, _large_tile_cases(2024), 3e-5, 2024)
+
+
 def test_length_regulate_exact(dev, golden):
     import tts_oracle as O
     from ttsamd.engine import length_regulate
@@ -347,6 +387,12 @@ def test_conv1d_kernel_bf16_modes(dev, precision, mode, tol):
         ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x.double(), 0.1), w.double(), b.double(),
                                          dilation=dil, padding=(k * dil - dil) // 2)
         assert maxabs(y, ref) < tol, (mode, cin, cout, k)
+
+
+@pytest.mark.parametrize('mode,tol', [('bf16x3', 5e-5), ('bf16', 4e-2)])
+def test_conv1d_kernel_bf16_modes_large_tiles(dev, precision, mode, tol):
+    precision(mode)
+    _conv_fuzz(dev, _large_tile_cases(7, ks=(3, 11)), tol, 7)
 
 
 @pytest.mark.parametrize('mode,mel_tol,wave_tol', [('bf16x3', X3_MEL_TOL, X3_WAVE_TOL), ('bf16', BF16_MEL_TOL, BF16_WAVE_TOL)])
