@@ -532,6 +532,11 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
     }
 #endif
     if (p.CoutP % 128 == 0) {
+        // deep-K layers on short sequences (HiFi-GAN stage 1: C = 256, 8 positions per frame) have few, long blocks;
+        // a launch is then 2-4 rounds of blocks and its tail costs 15-19 %: finer tiles pay there
+        const bool few_long = p.Cin >= 256 && p.CoutP <= p.Cin && !tiny && blocks(128, 128) < 4 * want;
+        if (few_long && K == 3 && blocks(128, 64) >= want) return launch_cfg<K, 1, 2, 4, 1>(p, stream);  // 128 co x 64 t
+        if (few_long && K == 11 && blocks(64, 128) >= want) return launch_cfg<K, 1, 2, 2, 2>(p, stream); //  64 co x 128 t
         if (K < 11 && !tiny && blocks(128, 128) >= want) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
         if (K == 11 && !tiny && blocks(64, 256) >= want) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
         if (blocks(128, 64) >= want || (tiny && blocks(64, 64) < 2 * want)) return launch_cfg<K, 1, 2, 4, 1>(p, stream);   // 128 co x 64 t
