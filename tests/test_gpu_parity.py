@@ -578,3 +578,20 @@ def test_dropin_app_utils_request_flow(dev, golden, checkpoints):
     assert torch.equal(outs[0], outs[1])
     assert abs(float(outs[0].abs().max()) - 0.99) < 1e-6
     assert maxabs(peak_normalise(wave_den.cpu().reshape(-1)), outs[0].reshape(-1)) < 1e-6
+
+
+def test_bf16_packed_intermediate_bit_identical(dev, precision, hifigan_engine, monkeypatch):
+    """bf16 mode: the c1 -> c2 intermediate of every ResBlock crosses HBM as packed bf16 (leaky-relu and RNE
+    rounding done by the producer instead of the consumer's staging): same rounding point, same bits.
+    Covers the small tiles (B=3) and the large ones (B=24 x 200 frames, one-stream path)."""
+    precision('bf16')
+    rng = np.random.default_rng(5)
+    for B, T in ((3, 37), (24, 200)):
+        lens = torch.from_numpy(rng.integers(T // 2, T + 1, size=B)).to(dev)
+        lens[0] = T
+        mel = torch.from_numpy((rng.standard_normal((B, 80, T)) * 1.5 - 4.0).astype(np.float32)).to(dev)
+        monkeypatch.setenv('TTSAMD_BF16_PACKED_T', '0')
+        ref = hifigan_engine.forward(mel, lens).clone()
+        monkeypatch.setenv('TTSAMD_BF16_PACKED_T', '1')
+        out = hifigan_engine.forward(mel, lens)
+        assert torch.equal(out, ref), (B, T, float((out - ref).abs().max()))

@@ -90,6 +90,12 @@ struct ConvParams {
     float* splitk_ws;         // >= splitk_floats floats of scratch, or nullptr (never split)
     int64_t splitk_floats;
     int32_t ksplit;           // set by the launcher
+    // bf16 mode only (precision 1): activations that only feed the next conv can cross HBM as bf16 in the LDS entry
+    // order [B][C/8][2 (kk)][L][4 bf16] (entry (o,kk,t) = channels 8o+kk+{0,2,4,6} at position t), already
+    // leaky-relu'd with the consumer's slope and rounded RNE: the consumer's staging is then a plain 8-byte copy.
+    int32_t y_packed;         // write y in that layout (requires Cout % 8 == 0, y_ts == 1, mode 0, no phases)
+    float pack_slope;         // ... after applying leaky-relu with this slope
+    int32_t x_packed;         // read x in that layout (x_cs = positions per row; in_slope is ignored)
     unsigned long long* timing;   // tools/conv_bench -DTTS_TIMING only: [blocks][8] clock samples (nullptr otherwise)
 };
 constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)

@@ -556,6 +556,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.dil >= -DMAX && p.dil <= DMAX && p.dil != 0, "conv: dilation %d outside [-%d,%d]", p.dil, DMAX, DMAX);
     if (p.Nout <= 0) return 0;
     if (p.precision != 0) return launch_conv_bf16_any(p, stream);
+    TTS_REQUIRE(!p.x_packed && !p.y_packed, "conv: packed bf16 activations exist only in the bf16 mode");
     switch (p.K) {
         case 1: return launch_k<1>(p, stream);
         case 2: return launch_k<2>(p, stream);

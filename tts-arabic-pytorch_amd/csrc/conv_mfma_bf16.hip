@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     const int W = NT_BLK + span;                          // staged columns actually used (<= WS)
 
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+    const bool xpk = NPL == 1 && p.x_packed != 0;       // x is the packed bf16 layout (ConvParams::x_packed)
+    const uint2* __restrict__ xpb = reinterpret_cast<const uint2*>(p.x) + (int64_t)b * (p.Cin / 4) * p.x_cs;
     // packed bf16 weights: [plane][phase][octet][tap][kk][CoutP][4 bf16]
     const int64_t plane_stride = (int64_t)p.n_phase * (p.Cin / 8) * K * 2 * p.CoutP;     // in uint2
     const uint2* __restrict__ wp4 =
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
         const int pos = q0 + lo + col;
         st_in[i] = it < G::XI;
         st_ok[i] = st_in[i] && (col < W) && (pos >= 0) && (pos < in_len);
-        st_off[i] = ((ockk >> 1) * 8 + (ockk & 1)) * x_cs + min(max(pos, 0), max(in_len - 1, 0));
+        st_off[i] = (xpk ? ockk : ((ockk >> 1) * 8 + (ockk & 1))) * x_cs + min(max(pos, 0), max(in_len - 1, 0));
     }
 
     // One staging "job" = one memory instruction (+ its VALU).  Jobs are spread one by one
@@ -117,7 +119,12 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
 #define TTS_LOAD_JOB(J)                                                                              \
     {                                                                                                \
         if ((J) < 4 * NXI) {                                                                         \
-            sx[(J)] = xc[st_off[(J) / 4] + 2 * ((J) % 4) * x_cs];                                    \
+            if (!xpk) {                                                                              \
+                sx[(J)] = xc[st_off[(J) / 4] + 2 * ((J) % 4) * x_cs];                                \
+            } else if ((J) % 4 == 0) {                                                               \
+                const uint2 t2 = xcp[st_off[(J) / 4]];                                               \
+                sx[(J)] = __uint_as_float(t2.x); sx[(J) + 1] = __uint_as_float(t2.y);                \
+            }                                                                                        \
         } else {                                                                                     \
             const int i_ = ((J)-4 * NXI) % NW, pl_ = ((J)-4 * NXI) / NW;                             \
             const int e = min(tid + 256 * i_, G::W4 - 1);                                            \
@@ -130,7 +137,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     {                                                                                                \
         if ((J) < NXI) {                                                                             \
             const int i_ = (J);                                                                      \
-            if (st_in[i_]) {                                                                         \
+            if (st_in[i_] && xpk) {                                                                  \
+                (SB)[tid + 256 * i_] = st_ok[i_] ? make_uint2(__float_as_uint(sx[4 * i_]), __float_as_uint(sx[4 * i_ + 1])) \
+                                                 : make_uint2(0u, 0u);                               \
+            } else if (st_in[i_]) {                                                                  \
                 float v0 = sx[4 * i_], v1 = sx[4 * i_ + 1], v2 = sx[4 * i_ + 2], v3 = sx[4 * i_ + 3]; \
                 v0 = st_ok[i_] ? TTS_LRELU(v0) : 0.f; v1 = st_ok[i_] ? TTS_LRELU(v1) : 0.f;           \
                 v2 = st_ok[i_] ? TTS_LRELU(v2) : 0.f; v3 = st_ok[i_] ? TTS_LRELU(v3) : 0.f;           \
@@ -170,6 +180,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     // prologue: fill NSTAGE-1 stages (bulk), fetch the first operands
     for (int c0 = 0; c0 < NSTAGE - 1 && c0 < n_chunks; ++c0) {
         const float* __restrict__ xc = xb + (int64_t)c0 * KC * x_cs;
+        const uint2* __restrict__ xcp = xpb + (int64_t)c0 * (KC / 4) * x_cs;
         const uint2* __restrict__ wc = wp4 + (int64_t)c0 * G::NOCT * K * 2 * CoutP;
         uint2* sbp = smem4 + c0 * G::BUF4;
 #pragma unroll
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
         // into a dead stage, which keeps the loop body branch-free)
         const int cl = min(c + NSTAGE - 1, n_chunks - 1);
         const float* __restrict__ xc = xb + (int64_t)cl * KC * x_cs;
+        const uint2* __restrict__ xcp = xpb + (int64_t)cl * (KC / 4) * x_cs;
         const uint2* __restrict__ wc = wp4 + (int64_t)cl * G::NOCT * K * 2 * CoutP;
         const int stage_next = (stage + 1 == NSTAGE) ? 0 : stage + 1;           // chunk c+1
         const int stage_fill = (stage == 0) ? NSTAGE - 1 : stage - 1;           // chunk c+NSTAGE-1
@@ -269,6 +281,38 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
     const int y_cs = p.y_cs, y_ts = p.y_ts, r_cs = p.r_cs;
     const float div = p.div;
+    if (NPL == 1 && p.y_packed) {
+        // lane (kk, l31) of a 32x32 tile holds rows 8*oo + 4*kk + {0,1,2,3} of column l31: the bf16 pairs
+        // (rows +0,+2) and (+1,+3) are dword kk of the entries (octet oo, kk' = 0) and (octet oo, kk' = 1)
+        unsigned* __restrict__ yp = reinterpret_cast<unsigned*>(p.y) + (int64_t)b * (Cout / 2) * y_cs;
+        const float ps = p.pack_slope;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int q = q0 + qw0 + j * 32 + l31;
+#pragma unroll
+                for (int oo = 0; oo < 4; ++oo) {
+                    const int co0 = co_w0 + i * 32 + 8 * oo + 4 * kk;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int coc = min(co0 + e, Cout - 1);
+                        float t = acc[i][j][4 * oo + e] + (bias ? bias[coc] : 0.f);
+                        if (scale) t *= scale[coc];
+                        if (relu_out == 1) t = fmaxf(t, 0.f);
+                        v[e] = t > 0.f ? t : t * ps;
+                    }
+                    if (q < n_out && co0 < Cout) {
+                        const int64_t e0 = ((int64_t)((co0 >> 3) * 2) * y_cs + q) * 2 + kk;
+                        yp[e0] = bf16_rne(v[0]) | (bf16_rne(v[2]) << 16);
+                        yp[e0 + 2 * (int64_t)y_cs] = bf16_rne(v[1]) | (bf16_rne(v[3]) << 16);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -314,6 +358,9 @@ static int32_t launch_cfg_bf16(const ConvParams& p, hipStream_t stream) {
     using G = GeoB<K, NT_BLK, CO_BLK, NPL>;
     TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
     TTS_REQUIRE(p.w_bf16 != nullptr, "conv: bf16 weights were not packed for this layer");
+    TTS_REQUIRE(!(p.x_packed || p.y_packed) || (NPL == 1 && p.n_phase == 1 && p.y_ts == 1),
+                "conv: packed bf16 activations need the plain bf16 mode and a non-transposed conv");
+    TTS_REQUIRE(!p.y_packed || (p.Cout % 8 == 0 && p.mode == 0 && p.res == nullptr), "conv: y_packed needs Cout %% 8 == 0, mode 0, no residual");
     const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(uint2);
     static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
     int dev_id = 0;

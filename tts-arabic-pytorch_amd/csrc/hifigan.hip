@@ -282,6 +282,11 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     p.lens_in = lens; p.lens_out = lens;
     p.n_phase = 1; p.div = 1.f;
     p.splitk_ws = splitks[0]; p.splitk_floats = kSplitKFloats;     // batch 1: stage-1 launches have < 256 tiles
+    // plain bf16 mode: the c1 -> c2 intermediate of a ResBlock only feeds c2, so it crosses HBM as packed bf16
+    // (ConvParams::y_packed / x_packed; same rounding point as the fp32 buffer + round-on-load, bit-identical)
+    const char* pk_env = std::getenv("TTSAMD_BF16_PACKED_T");
+    const bool pack_t = default_precision() == 1 && !(pk_env && pk_env[0] == '0');
+    int pack_io = 0;   // bit 0: x is packed, bit 1: write y packed (set around the c1 / c2 launches below)
     auto conv = [&](const ConvW& cw, const float* x, hipStream_t st, float* y, const float* res, int L, int mul,
                     int dil, float slope, int mode, float div) -> int32_t {
         p.x = x; p.x_bs = (int64_t)cw.cin * L; p.x_cs = L;
@@ -294,6 +299,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         p.dil = dil; p.pad = (cw.k * dil - dil) / 2;
         p.n_phase = 1; p.phase_p = 0;
         p.in_slope = slope; p.relu_out = 0; p.mode = mode; p.div = div;
+        p.x_packed = (pack_io & 1) ? 1 : 0; p.y_packed = (pack_io & 2) ? 1 : 0; p.pack_slope = 0.1f;
         prof_begin(st, 2.0 * cw.cout * cw.cin * cw.k * mul);
         const int32_t rc = launch_conv(p, st);
         prof_end(st);
@@ -316,6 +322,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         p.Cin = uw.cin; p.Cout = uw.cout; p.CoutP = cout_padded(uw.cout); p.K = 2;
         p.dil = -1; p.pad = 0; p.n_phase = u; p.phase_p = (kt - u) / 2;
         p.in_slope = 0.1f; p.relu_out = 0; p.mode = 0; p.div = 1.f;
+        p.x_packed = 0; p.y_packed = 0;
         prof_begin(s, 2.0 * uw.cout * uw.cin * 2 * u * mul);
         int32_t rc = launch_conv(p, s);
         prof_end(s);
@@ -332,9 +339,12 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
             for (int m = 0; m < cfg.n_dilations; ++m) {
                 const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
                 const int d = cfg.resblock_dilations[j][m];
+                pack_io = pack_t ? 2 : 0;
                 TTS_TRY(conv(h->c1[li], src, st, Tb, nullptr, L, mul, d, 0.1f, 0, 1.f));
+                pack_io = pack_t ? 1 : 0;
                 if (m + 1 < cfg.n_dilations) {
                     TTS_TRY(conv(h->c2[li], Tb, st, R, src, L, mul, 1, 0.1f, 0, 1.f));
+                    pack_io = 0;
                     src = R;
                 } else {
                     const int mode = (j == 0) ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2);
@@ -342,6 +352,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     // the accumulation into `cur` follows branch j-1's
                     if (multi && j > 0) TTS_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
                     TTS_TRY(conv(h->c2[li], Tb, st, cur, src, L, mul, 1, 0.1f, md, (float)cfg.n_kernels));
+                    pack_io = 0;
                     if (multi) TTS_CHECK_HIP(hipEventRecord(h->ev_done[j], st));
                 }
             }
