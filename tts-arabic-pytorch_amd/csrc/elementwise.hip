@@ -1,5 +1,7 @@
 // HBM-/latency-bound kernels around the MFMA conv engine.  All activations are channel-first
 // [B][C][T] so that consecutive lanes touch consecutive time steps (coalesced, 64-wide waves).
+#include <cstdint>
+
 #include "kernels.hpp"
 
 namespace ttsamd {
@@ -22,24 +24,37 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const float b0 = bias ? bias[0] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+    // window = positions t0-4 .. t0+7 as three aligned float4 loads (t0 % 4 == 0); rows are 16-byte aligned when
+    // the row stride is a multiple of 4 (always: L = 256 * frames), otherwise element loads
+    const bool vec = (x_cs % 4 == 0) && (x_bs % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && t0 + 8 <= L;
     for (int c = 0; c < C; ++c) {
         const float* xr = xb + (int64_t)c * x_cs;
-        float win[10];
+        float win[12];
+        if (vec) {
+            const float4 m = *reinterpret_cast<const float4*>(xr + t0);
+            const float4 l = t0 >= 4 ? *reinterpret_cast<const float4*>(xr + t0 - 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 r = *reinterpret_cast<const float4*>(xr + t0 + 4);
+            win[0] = l.x; win[1] = l.y; win[2] = l.z; win[3] = l.w;
+            win[4] = m.x; win[5] = m.y; win[6] = m.z; win[7] = m.w;
+            win[8] = r.x; win[9] = r.y; win[10] = r.z; win[11] = r.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int pos = t0 - 3 + i;
-            float v = 0.f;
-            if (pos >= 0 && pos < n) {
-                v = xr[pos];
-                v = v > 0.f ? v : v * slope;
+            for (int i = 0; i < 12; ++i) {
+                const int pos = t0 - 4 + i;
+                win[i] = (pos >= 0 && pos < L) ? xr[pos] : 0.f;
             }
-            win[i] = v;
+        }
+#pragma unroll
+        for (int i = 1; i < 11; ++i) {
+            const int pos = t0 - 4 + i;
+            const float v = win[i];
+            win[i] = (pos >= 0 && pos < n) ? (v > 0.f ? v : v * slope) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const float wk = w[c * 7 + k];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk, win[i + k], acc[i]);
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk, win[i + k + 1], acc[i]);
         }
     }
     float* o = wave + (int64_t)b * wave_bs;
