@@ -60,7 +60,12 @@ struct Geo {
     static constexpr int NGRP = NOCT * K;                     // operand groups per chunk
 };
 
-template <int K, int MT, int NTL, int WM, int WN>
+// EPI selects the epilogue that is compiled in (the launcher decides on the host, launch_cfg): with all of them in one
+// kernel the code was 140 KB, of which the main loop is 2 KB -- more than the 64 KB instruction cache two CUs share.
+//   0: row-major float4 epilogue, bias / scale / residual / ReLU / accumulate modes   (every ResBlock and FFT conv)
+//   1: the same plus GELU and tanh                                                    (Vocos pwconv1, Tacotron2 postnet)
+//   2: per-lane epilogue for everything else: polyphase upsamplers, unaligned rows, split-K partial sums
+template <int K, int MT, int NTL, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     constexpr int CO_BLK = WM * MT * 32;
@@ -281,16 +286,9 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #endif
     // ---- epilogue: bias, residual, activation, accumulate modes ------------------------------------------
     const int co_w0 = co_blk0 + wm * MT * 32;
-#ifndef TTS_NO_VEC_EPILOGUE
-    // Row-major float4 path: the accumulator tile (32 x 32 per MFMA, one column per lane) goes through the
-    // now dead LDS ring so that every wave reads, combines and stores whole 1 KB row segments (16 B per lane)
-    // instead of 4 B per lane in 128 B pieces: 4x fewer memory instructions for the residual read and the
-    // store, which are the un-overlapped ~0.2 ms of every launch.  Needs 16-byte aligned rows.
-    {
-        const bool vec_ok = p.ksplit == 1 && p.y_ts == 1 && p.n_phase == 1 && (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 &&
-                            ((uintptr_t)p.y & 15) == 0 &&
-                            (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0));
-        if (vec_ok) {
+    if constexpr (EPI < 2) {
+        {
+
             constexpr int LDS_F = NSTAGE * G::BUF4 * 4;                         // floats of LDS this block owns
             constexpr int NPASS = (CO_BLK * NT_BLK + LDS_F - 1) / LDS_F;        // the tile goes through in NPASS row slabs
             constexpr int ROWS_P = (CO_BLK + NPASS - 1) / NPASS;
@@ -360,10 +358,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = v[e] + bsv;
-                            if (relu_out == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                            if constexpr (EPI == 1) { if (relu_out == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
                             x = x * scv + rr4[e];
                             if (relu_out == 1) x = fmaxf(x, 0.f);
-                            else if (relu_out == 3) x = tanhf(x);
+                            if constexpr (EPI == 1) { if (relu_out == 3) x = tanhf(x); }
                             if (mode == 1) x = pp4[e] + x;
                             else if (mode == 2) x = (pp4[e] + x) / div;
                             v[e] = x;
@@ -390,8 +388,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #endif
             return;
         }
-    }
-#endif
+    } else {
     if (!wave_active) return;
     if (p.ksplit > 1) {   // raw partial sums; bias / activation / residual happen in splitk_reduce_kernel
         float* __restrict__ pb = p.splitk_ws + ((int64_t)ks * p.batch + b) * p.Cout * p.Nout;
@@ -451,6 +448,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
             }
         }
     }
+    }   // EPI == 2
 }
 
 // Second half of a split-K conv: y = epilogue(sum_ks partial[ks]) with exactly the epilogue of the main kernel.
@@ -474,21 +472,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
     *yp = v;
 }
 
+template <int K, int MT, int NTL, int WM, int WN, int EPI>
+static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_t stream) {
+    static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
+    int dev_id = 0;
+    TTS_CHECK_HIP(hipGetDevice(&dev_id));
+    dev_id &= 15;
+    if (!attr_set[dev_id]) {
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_f32<K, MT, NTL, WM, WN, EPI>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev_id] = true;
+    }
+    hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN, EPI>), grid, dim3(256), lds, stream, q);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int K, int MT, int NTL, int WM, int WN>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
     using G = Geo<K, NT_BLK, CO_BLK>;
     TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
     const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(float4);
-    static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_f32<K, MT, NTL, WM, WN>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev_id] = true;
-    }
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
     ConvParams q = p;
     q.ksplit = 1;
@@ -500,8 +505,20 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         if (ks >= 2) q.ksplit = (int)ks;
     }
     grid.y *= q.ksplit;
-    hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN>), grid, dim3(256), lds, stream, q);
-    TTS_CHECK_HIP(hipGetLastError());
+    // epilogue kind (see the kernel): the float4 row epilogue needs 16-byte aligned rows of y (and of the residual)
+    const bool vec_ok = q.ksplit == 1 && p.y_ts == 1 && p.n_phase == 1 && (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 &&
+                        ((uintptr_t)p.y & 15) == 0 &&
+                        (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0));
+#ifdef TTS_NO_VEC_EPILOGUE
+    const int epi = 2;
+#else
+    const int epi = !vec_ok ? 2 : (p.relu_out >= 2 ? ((K == 1 || K == 5) ? 1 : 2) : 0);
+#endif
+    int32_t rc;
+    if (epi == 0) rc = launch_epi<K, MT, NTL, WM, WN, 0>(q, grid, lds, stream);
+    else if (epi == 1) rc = launch_epi<K, MT, NTL, WM, WN, (K == 1 || K == 5) ? 1 : 2>(q, grid, lds, stream);
+    else rc = launch_epi<K, MT, NTL, WM, WN, 2>(q, grid, lds, stream);
+    if (rc != 0) return rc;
     if (q.ksplit > 1) {
         dim3 rg((p.Nout + 255) / 256, p.Cout, p.batch);
         hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, stream, q);
