@@ -34,7 +34,9 @@ struct GeoB {
     static constexpr int NGRP = NOCT * K;
 };
 
-template <int K, int MT, int NTL, int WM, int WN, int NPL>
+// ACT: GELU / tanh compiled in (Vocos pwconv1, Tacotron2 postnet only): their inline expansions for 64 accumulators
+// per lane were most of the 70-100 KB of kernel code (64 KB instruction cache per CU pair)
+template <int K, int MT, int NTL, int WM, int WN, int NPL, bool ACT>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const ConvParams p) {
     // NPL = 1: plain bf16 operands; NPL = 2: split bf16 (hi + lo planes, 3 MFMAs per product)
     extern __shared__ __attribute__((aligned(16))) uint2 smem4[];
@@ -338,10 +340,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
                     const int r = h * 8 + r8;
                     const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                     float v = acc[i][j][r] + bv[r8];
-                    if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU()
+                    if constexpr (ACT) { if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }  // nn.GELU()
                     v = v * sv[r8] + rv[r8];
                     if (relu_out == 1) v = fmaxf(v, 0.f);
-                    else if (relu_out == 3) v = tanhf(v);
+                    if constexpr (ACT) { if (relu_out == 3) v = tanhf(v); }
                     if (mode == 1) v = pv[r8] + v;
                     else if (mode == 2) v = (pv[r8] + v) / div;
                     if (q_ok && co < Cout) yb[(int64_t)co * y_cs + (int64_t)q * y_ts] = v;
@@ -352,6 +354,22 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
 }
 
 
+template <int K, int MT, int NTL, int WM, int WN, int NPL, bool ACT>
+static int32_t launch_act_bf16(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
+    static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
+    int dev_id = 0;
+    TTS_CHECK_HIP(hipGetDevice(&dev_id));
+    dev_id &= 15;
+    if (!attr_set[dev_id]) {
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, ACT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev_id] = true;
+    }
+    hipLaunchKernelGGL((conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, ACT>), grid, dim3(256), lds, stream, p);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int K, int MT, int NTL, int WM, int WN, int NPL>
 static int32_t launch_cfg_bf16(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
@@ -361,20 +379,12 @@ static int32_t launch_cfg_bf16(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(!(p.x_packed || p.y_packed) || (NPL == 1 && p.n_phase == 1 && p.y_ts == 1),
                 "conv: packed bf16 activations need the plain bf16 mode and a non-transposed conv");
     TTS_REQUIRE(!p.y_packed || (p.Cout % 8 == 0 && p.mode == 0 && p.res == nullptr), "conv: y_packed needs Cout %% 8 == 0, mode 0, no residual");
+    constexpr bool HAS_ACT = K == 1 || K == 5;      // GELU: Vocos pwconv1 (k1); tanh: Tacotron2 postnet (k5)
+    TTS_REQUIRE(p.relu_out < 2 || HAS_ACT, "conv: GELU / tanh epilogues are built for kernel sizes 1 and 5 only (K=%d)", K);
     const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(uint2);
-    static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev_id] = true;
-    }
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
-    hipLaunchKernelGGL((conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL>), grid, dim3(256), lds, stream, p);
-    TTS_CHECK_HIP(hipGetLastError());
-    return 0;
+    if (HAS_ACT && p.relu_out >= 2) return launch_act_bf16<K, MT, NTL, WM, WN, NPL, HAS_ACT>(p, grid, lds, stream);
+    return launch_act_bf16<K, MT, NTL, WM, WN, NPL, false>(p, grid, lds, stream);
 }
 
 template <int K, int NPL>
