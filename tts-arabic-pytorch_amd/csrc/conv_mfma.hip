@@ -110,6 +110,16 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                                      (int64_t)c_beg * G::NOCT * K * 2 * CoutP;
     const float in_slope = p.in_slope;
 
+    // this block's bias / scale (one output channel per thread) for the row epilogue: loaded now, parked in LDS after the
+    // main loop, so that the rolled row loop reads them with lgkmcnt waits only (a vmcnt wait would also wait for the
+    // previous row's store on this ISA)
+    float ep_bias = 0.f, ep_scale = 1.f;
+    if (EPI < 2 && tid < CO_BLK) {
+        const int co_ = min(co_blk0 + tid, p.Cout - 1);
+        if (p.bias) ep_bias = p.bias[co_];
+        if (p.scale) ep_scale = p.scale[co_];
+    }
+
     f32x16 acc[MT][NTL];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -290,11 +300,13 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
         {
 
             constexpr int LDS_F = NSTAGE * G::BUF4 * 4;                         // floats of LDS this block owns
-            constexpr int NPASS = (CO_BLK * NT_BLK + LDS_F - 1) / LDS_F;        // the tile goes through in NPASS row slabs
+            constexpr int ROWS_FIT = (LDS_F - 2 * CO_BLK) / NT_BLK;             // whole rows next to the bias/scale vectors
+            constexpr int NPASS = (CO_BLK + ROWS_FIT - 1) / ROWS_FIT;           // the tile goes through in NPASS row slabs
             constexpr int ROWS_P = (CO_BLK + NPASS - 1) / NPASS;
             constexpr int LPR = NT_BLK / 4;                                     // lanes per row (one float4 each)
-            static_assert(ROWS_P * NT_BLK <= LDS_F && 64 % LPR == 0 || LPR % 64 == 0, "epilogue slab");
+            static_assert(ROWS_FIT >= 1 && (64 % LPR == 0 || LPR % 64 == 0), "epilogue slab");
             float* ep = reinterpret_cast<float*>(smem4);
+            float* epb = ep + LDS_F - 2 * CO_BLK;                               // [CO_BLK] bias, [CO_BLK] scale
             float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
             const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
             const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
@@ -302,6 +314,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 __syncthreads();                                                // ring stages / previous slab are dead
+                if (ps == 0 && tid < CO_BLK) { epb[tid] = ep_bias; epb[CO_BLK + tid] = ep_scale; }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -316,23 +329,13 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                 constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                     // rows per wave instruction
                 constexpr int CPL = LPR >= 64 ? LPR / 64 : 1;                     // float4 columns groups per lane
                 constexpr int NR = (ROWS_P + 4 * RPI - 1) / (4 * RPI);            // row iterations per wave
-                // bias / scale of this wave's rows first: inside the loop each of them is a vmcnt(0) wait, and on
-                // this ISA such a wait also covers the previous row's store
-                float rbias[NR], rscale[NR];
-#pragma unroll
-                for (int it = 0; it < NR; ++it) {
-                    const int rl_ = wid * RPI + it * 4 * RPI + (LPR >= 64 ? 0 : lane / LPR);
-                    const int co_ = min(co_blk0 + ps * ROWS_P + rl_, Cout - 1);
-                    rbias[it] = p.bias ? p.bias[co_] : 0.f;
-                    rscale[it] = p.scale ? p.scale[co_] : 1.f;
-                }
-#pragma unroll
+#pragma unroll 1
                 for (int it = 0; it < NR; ++it) {
                     const int r0 = wid * RPI + it * 4 * RPI;
                     const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
                     const int co = co_blk0 + ps * ROWS_P + rl;
                     if (rl >= ROWS_P || co >= Cout) continue;
-                    const float bsv = rbias[it], scv = rscale[it];
+                    const float bsv = epb[ps * ROWS_P + rl], scv = epb[CO_BLK + ps * ROWS_P + rl];
 #pragma unroll
                     for (int cg = 0; cg < CPL; ++cg) {
                         const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
