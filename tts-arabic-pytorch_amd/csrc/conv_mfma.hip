@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                     const int r0 = wid * RPI + it * 4 * RPI;
                     const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
                     const int co = co_blk0 + ps * ROWS_P + rl;
-                    if (rl >= ROWS_P || co >= Cout) continue;
+                    if (rl >= ROWS_P || ps * ROWS_P + rl >= CO_BLK || co >= Cout) continue;   // NPASS * ROWS_P may exceed the tile
                     const float bsv = epb[ps * ROWS_P + rl], scv = epb[CO_BLK + ps * ROWS_P + rl];
 #pragma unroll
                     for (int cg = 0; cg < CPL; ++cg) {

@@ -1,5 +1,7 @@
 // bf16 / split-bf16 MFMA variants of the implicit-GEMM conv engine.  See conv_mfma.hip for the
 // structure; this file is derived from it (same tiling, LDS ring, gap interleave).
+#include <cstdint>
+
 #include "conv_mfma_common.hpp"
 
 namespace ttsamd {
@@ -36,7 +38,9 @@ struct GeoB {
 
 // ACT: GELU / tanh compiled in (Vocos pwconv1, Tacotron2 postnet only): their inline expansions for 64 accumulators
 // per lane were most of the 70-100 KB of kernel code (64 KB instruction cache per CU pair)
-template <int K, int MT, int NTL, int WM, int WN, int NPL, bool ACT>
+// EPI 0: row-major float4 epilogue through the dead LDS ring (same as the fp32 kernel's); EPI 2: per-lane epilogue
+// (polyphase upsamplers, unaligned rows, packed bf16 output)
+template <int K, int MT, int NTL, int WM, int WN, int NPL, int EPI, bool ACT>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const ConvParams p) {
     // NPL = 1: plain bf16 operands; NPL = 2: split bf16 (hi + lo planes, 3 MFMAs per product)
     extern __shared__ __attribute__((aligned(16))) uint2 smem4[];
@@ -75,6 +79,13 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     const float in_slope = p.in_slope;
     const int n_chunks = p.Cin / KC;
     const int x_cs = p.x_cs, CoutP = p.CoutP;
+
+    float ep_bias = 0.f, ep_scale = 1.f;     // see conv_mfma.hip: parked in LDS for the rolled row epilogue
+    if (EPI == 0 && tid < CO_BLK) {
+        const int co_ = min(co_blk0 + tid, p.Cout - 1);
+        if (p.bias) ep_bias = p.bias[co_];
+        if (p.scale) ep_scale = p.scale[co_];
+    }
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -272,6 +283,92 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
 #undef TTS_FETCH_PART
 #undef TTS_LRELU
 
+    if constexpr (EPI == 0) {
+        {
+
+            constexpr int LDS_F = NSTAGE * G::BUF4 * 2;                         // floats of LDS this block owns
+            constexpr int ROWS_FIT = (LDS_F - 2 * CO_BLK) / NT_BLK;             // whole rows next to the bias/scale vectors
+            constexpr int NPASS = (CO_BLK + ROWS_FIT - 1) / ROWS_FIT;           // the tile goes through in NPASS row slabs
+            constexpr int ROWS_P = (CO_BLK + NPASS - 1) / NPASS;
+            constexpr int LPR = NT_BLK / 4;                                     // lanes per row (one float4 each)
+            static_assert(ROWS_FIT >= 1 && (64 % LPR == 0 || LPR % 64 == 0), "epilogue slab");
+            float* ep = reinterpret_cast<float*>(smem4);
+            float* epb = ep + LDS_F - 2 * CO_BLK;                               // [CO_BLK] bias, [CO_BLK] scale
+            float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+            const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+            const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
+            const float div = p.div;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                __syncthreads();                                                // ring stages / previous slab are dead
+                if (ps == 0 && tid < CO_BLK) { epb[tid] = ep_bias; epb[CO_BLK + tid] = ep_scale; }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                            if (row >= ps * ROWS_P && row < (ps + 1) * ROWS_P)
+                                ep[(row - ps * ROWS_P) * NT_BLK + qw0 + j * 32 + l31] = acc[i][j][r];
+                        }
+                __syncthreads();
+                constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                     // rows per wave instruction
+                constexpr int CPL = LPR >= 64 ? LPR / 64 : 1;                     // float4 columns groups per lane
+                constexpr int NR = (ROWS_P + 4 * RPI - 1) / (4 * RPI);            // row iterations per wave
+#pragma unroll 1
+                for (int it = 0; it < NR; ++it) {
+                    const int r0 = wid * RPI + it * 4 * RPI;
+                    const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
+                    const int co = co_blk0 + ps * ROWS_P + rl;
+                    if (rl >= ROWS_P || ps * ROWS_P + rl >= CO_BLK || co >= Cout) continue;   // NPASS * ROWS_P may exceed the tile
+                    const float bsv = epb[ps * ROWS_P + rl], scv = epb[CO_BLK + ps * ROWS_P + rl];
+#pragma unroll
+                    for (int cg = 0; cg < CPL; ++cg) {
+                        const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
+                        const int q = q0 + col;
+                        if (q >= n_out) continue;
+                        const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
+                        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                        float* yp = yb + (int64_t)co * p.y_cs + q;
+                        const float* rp = rb ? rb + (int64_t)co * p.r_cs + q : nullptr;
+                        const bool full = q + 3 < n_out;
+                        float rr4[4] = {0.f, 0.f, 0.f, 0.f}, pp4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (full) {
+                            if (rp) { const float4 t = *reinterpret_cast<const float4*>(rp); rr4[0] = t.x; rr4[1] = t.y; rr4[2] = t.z; rr4[3] = t.w; }
+                            if (mode != 0) { const float4 t = *reinterpret_cast<const float4*>(yp); pp4[0] = t.x; pp4[1] = t.y; pp4[2] = t.z; pp4[3] = t.w; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (q + e < n_out) {
+                                    if (rp) rr4[e] = rp[e];
+                                    if (mode != 0) pp4[e] = yp[e];
+                                }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = v[e] + bsv;
+                            if constexpr (ACT) { if (relu_out == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+                            x = x * scv + rr4[e];
+                            if (relu_out == 1) x = fmaxf(x, 0.f);
+                            if constexpr (ACT) { if (relu_out == 3) x = tanhf(x); }
+                            if (mode == 1) x = pp4[e] + x;
+                            else if (mode == 2) x = (pp4[e] + x) / div;
+                            v[e] = x;
+                        }
+                        if (full) {
+                            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (q + e < n_out) yp[e] = v[e];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    } else {
     // epilogue: bias, residual, activation, accumulate modes.  Per half tile all loads
     // (bias, residual, previous y) are issued first and only then consumed.
     if (!wave_active) return;
@@ -351,21 +448,22 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
             }
         }
     }
+    }   // EPI == 2
 }
 
 
-template <int K, int MT, int NTL, int WM, int WN, int NPL, bool ACT>
+template <int K, int MT, int NTL, int WM, int WN, int NPL, int EPI, bool ACT>
 static int32_t launch_act_bf16(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
     int dev_id = 0;
     TTS_CHECK_HIP(hipGetDevice(&dev_id));
     dev_id &= 15;
     if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, ACT>,
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, EPI, ACT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev_id] = true;
     }
-    hipLaunchKernelGGL((conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, ACT>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, EPI, ACT>), grid, dim3(256), lds, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -383,8 +481,16 @@ static int32_t launch_cfg_bf16(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.relu_out < 2 || HAS_ACT, "conv: GELU / tanh epilogues are built for kernel sizes 1 and 5 only (K=%d)", K);
     const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(uint2);
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
-    if (HAS_ACT && p.relu_out >= 2) return launch_act_bf16<K, MT, NTL, WM, WN, NPL, HAS_ACT>(p, grid, lds, stream);
-    return launch_act_bf16<K, MT, NTL, WM, WN, NPL, false>(p, grid, lds, stream);
+    const bool vec_ok = !p.y_packed && p.y_ts == 1 && p.n_phase == 1 && (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 &&
+                        ((uintptr_t)p.y & 15) == 0 &&
+                        (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0));
+    const bool act = HAS_ACT && p.relu_out >= 2;
+    if (vec_ok) {
+        if (act) return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 0, HAS_ACT>(p, grid, lds, stream);
+        return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 0, false>(p, grid, lds, stream);
+    }
+    if (act) return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 2, HAS_ACT>(p, grid, lds, stream);
+    return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 2, false>(p, grid, lds, stream);
 }
 
 template <int K, int NPL>
