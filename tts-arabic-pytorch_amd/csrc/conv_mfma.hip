@@ -440,10 +440,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                     const int r = h * 8 + r8;
                     const int co = co_w0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                     float v = acc[i][j][r] + bv[r8];
-                    if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU()
+                    if constexpr (K == 1 || K == 5) { if (relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }   // nn.GELU()
                     v = v * sv[r8] + rv[r8];
                     if (relu_out == 1) v = fmaxf(v, 0.f);
-                    else if (relu_out == 3) v = tanhf(v);
+                    if constexpr (K == 1 || K == 5) { if (relu_out == 3) v = tanhf(v); }
                     if (mode == 1) v = pv[r8] + v;
                     else if (mode == 2) v = (pv[r8] + v) / div;
                     if (q_ok && co < Cout) yb[(int64_t)co * y_cs + (int64_t)q * y_ts] = v;
@@ -515,7 +515,9 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
 #ifdef TTS_NO_VEC_EPILOGUE
     const int epi = 2;
 #else
-    const int epi = !vec_ok ? 2 : (p.relu_out >= 2 ? ((K == 1 || K == 5) ? 1 : 2) : 0);
+    // GELU (Vocos pwconv1, k = 1) and tanh (Tacotron2 postnet, k = 5) are compiled into those kernel sizes only
+    TTS_REQUIRE(p.relu_out < 2 || K == 1 || K == 5, "conv: GELU / tanh epilogues are built for kernel sizes 1 and 5 only (K=%d)", K);
+    const int epi = !vec_ok ? 2 : (p.relu_out >= 2 ? 1 : 0);
 #endif
     int32_t rc;
     if (epi == 0) rc = launch_epi<K, MT, NTL, WM, WN, 0>(q, grid, lds, stream);
