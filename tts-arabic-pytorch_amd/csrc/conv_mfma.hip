@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                 constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                     // rows per wave instruction
                 constexpr int CPL = LPR >= 64 ? LPR / 64 : 1;                     // float4 columns groups per lane
                 constexpr int NR = (ROWS_P + 4 * RPI - 1) / (4 * RPI);            // row iterations per wave
-#pragma unroll 1
+#pragma unroll 2
                 for (int it = 0; it < NR; ++it) {
                     const int r0 = wid * RPI + it * 4 * RPI;
                     const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
