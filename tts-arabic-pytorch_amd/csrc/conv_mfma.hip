@@ -160,24 +160,24 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     constexpr int NF = MT + NTL;               // ds_read_b128 per operand fetch
     constexpr int GL = (NGRP - 1) * NM;        // gaps carrying load jobs
     static_assert(NGRP >= 2 && NF <= NM, "operand group layout");
-#define TTS_LOAD_JOB(J)                                                                              \
+#define TTS_LOAD_JOB_(J, SX, SW, XC, WC)                                                                           \
     {                                                                                                \
         if ((J) < 4 * NXI) {                                                                         \
-            sx[(J)] = xc[st_off[(J) / 4] + 2 * ((J) % 4) * x_cs];                                    \
+            SX[(J)] = XC[st_off[(J) / 4] + 2 * ((J) % 4) * x_cs];                                    \
         } else {                                                                                     \
             const int i_ = (J)-4 * NXI;                                                              \
             const int e = min(tid + 256 * i_, G::W4 - 1);                                            \
-            const float4 t4 = wc[(int64_t)(e / CO_BLK) * CoutP + (e % CO_BLK)];                      \
-            sw[4 * i_] = t4.x; sw[4 * i_ + 1] = t4.y; sw[4 * i_ + 2] = t4.z; sw[4 * i_ + 3] = t4.w;  \
+            const float4 t4 = WC[(int64_t)(e / CO_BLK) * CoutP + (e % CO_BLK)];                      \
+            SW[4 * i_] = t4.x; SW[4 * i_ + 1] = t4.y; SW[4 * i_ + 2] = t4.z; SW[4 * i_ + 3] = t4.w;  \
         }                                                                                            \
     }
 #define TTS_LRELU(v) ((v) > 0.f ? (v) : (v)*in_slope)
-#define TTS_WRITE_JOB(J, SB)                                                                         \
+#define TTS_WRITE_JOB_(J, SB, SX, SW)                                                                         \
     {                                                                                                \
         if ((J) < NXI) {                                                                             \
             const int i_ = (J);                                                                      \
             if (st_in[i_]) {                                                                         \
-                const float v0 = sx[4 * i_], v1 = sx[4 * i_ + 1], v2 = sx[4 * i_ + 2], v3 = sx[4 * i_ + 3]; \
+                const float v0 = SX[4 * i_], v1 = SX[4 * i_ + 1], v2 = SX[4 * i_ + 2], v3 = SX[4 * i_ + 3]; \
                 (SB)[tid + 256 * i_] =                                                               \
                     st_ok[i_] ? make_float4(TTS_LRELU(v0), TTS_LRELU(v1), TTS_LRELU(v2), TTS_LRELU(v3)) \
                               : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
@@ -186,9 +186,11 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
             const int i_ = (J)-NXI;                                                                  \
             const int e = tid + 256 * i_;                                                            \
             if (e < G::W4)                                                                           \
-                (SB)[G::XI + e] = make_float4(sw[4 * i_], sw[4 * i_ + 1], sw[4 * i_ + 2], sw[4 * i_ + 3]); \
+                (SB)[G::XI + e] = make_float4(SW[4 * i_], SW[4 * i_ + 1], SW[4 * i_ + 2], SW[4 * i_ + 3]); \
         }                                                                                            \
     }
+#define TTS_LOAD_JOB(J) TTS_LOAD_JOB_(J, sx, sw, xc, wc)
+#define TTS_WRITE_JOB(J, SB) TTS_WRITE_JOB_(J, SB, sx, sw)
     // part PART (< NF) of the operand fetch of group GRP of stage STG into register slot SLOT
 #define TTS_FETCH_PART(SLOT, STG, GRP, PART)                                                         \
     {                                                                                                \
@@ -207,15 +209,33 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     const float4* sA = smem4 + G::XI + kk * CO_BLK + wm * MT * 32 + l31;
     float a[2][MT][4], bq[2][NTL][4];
 
-    // prologue: fill NSTAGE-1 stages (bulk), fetch the first operands
-    for (int c0 = 0; c0 < NSTAGE - 1 && c0 < n_chunks; ++c0) {
-        const float* __restrict__ xc = xb + (int64_t)c0 * KC * x_cs;
-        const float4* __restrict__ wc = wp4 + (int64_t)c0 * G::NOCT * K * 2 * CoutP;
-        float4* sbp = smem4 + c0 * G::BUF4;
+    // prologue: fill NSTAGE-1 stages (bulk), fetch the first operands.  With three stages the loads of both chunks
+    // are issued before the first LDS write (second register set, dead after the prologue): one memory round trip
+    // instead of two at the start of every block.
+    if (NSTAGE == 3 && n_chunks >= 2) {
+        float sxb[4 * NXI], swb[4 * NW + 1];
+        const float* __restrict__ xc0 = xb;
+        const float4* __restrict__ wc0 = wp4;
+        const float* __restrict__ xc1 = xb + (int64_t)KC * x_cs;
+        const float4* __restrict__ wc1 = wp4 + (int64_t)G::NOCT * K * 2 * CoutP;
 #pragma unroll
-        for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
+        for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB_(J, sx, sw, xc0, wc0)
 #pragma unroll
-        for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, sbp)
+        for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB_(J, sxb, swb, xc1, wc1)
+#pragma unroll
+        for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB_(J, smem4, sx, sw)
+#pragma unroll
+        for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB_(J, smem4 + G::BUF4, sxb, swb)
+    } else {
+        for (int c0 = 0; c0 < NSTAGE - 1 && c0 < n_chunks; ++c0) {
+            const float* __restrict__ xc = xb + (int64_t)c0 * KC * x_cs;
+            const float4* __restrict__ wc = wp4 + (int64_t)c0 * G::NOCT * K * 2 * CoutP;
+            float4* sbp = smem4 + c0 * G::BUF4;
+#pragma unroll
+            for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
+#pragma unroll
+            for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, sbp)
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -288,6 +308,8 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     }
 #undef TTS_LOAD_JOB
 #undef TTS_WRITE_JOB
+#undef TTS_LOAD_JOB_
+#undef TTS_WRITE_JOB_
 #undef TTS_FETCH_PART
 #undef TTS_LRELU
 
