@@ -55,7 +55,9 @@ struct Geo {
 #ifdef TTS_FORCE_NSTAGE
     static constexpr int NSTAGE = TTS_FORCE_NSTAGE;
 #else
-    static constexpr int NSTAGE = (3 * BUF4 * 16 <= 80 * 1024) ? 3 : 2;
+    // three stages when they fit in half of the LDS; the 32-channel tiles (HiFi-GAN stage 4: 4 chunks per block, all
+    // prologue and epilogue) do better with two stages and one more resident block (+2...5 %, tools/conv_bench)
+    static constexpr int NSTAGE = (CO_BLK > 32 && 3 * BUF4 * 16 <= 80 * 1024) ? 3 : 2;
 #endif
     static constexpr int NGRP = NOCT * K;                     // operand groups per chunk
 };
