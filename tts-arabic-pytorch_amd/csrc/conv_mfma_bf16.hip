@@ -32,7 +32,7 @@ struct GeoB {
     static constexpr int W4 = NOCT * K * 2 * CO_BLK;          // W entries (uint2) per plane per stage
     static constexpr int NW = (W4 + 255) / 256;
     static constexpr int BUF4 = NPL * (XI + W4);              // uint2 per stage
-    static constexpr int NSTAGE = (3 * BUF4 * 8 <= 80 * 1024) ? 3 : 2;
+    static constexpr int NSTAGE = (CO_BLK > 32 && 3 * BUF4 * 8 <= 80 * 1024) ? 3 : 2;   // see conv_mfma.hip
     static constexpr int NGRP = NOCT * K;
 };
 
