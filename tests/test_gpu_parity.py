@@ -583,7 +583,7 @@ def test_dropin_app_utils_request_flow(dev, golden, checkpoints):
 def test_bf16_packed_intermediate_bit_identical(dev, precision, hifigan_engine, monkeypatch):
     """bf16 mode: the c1 -> c2 intermediate of every ResBlock crosses HBM as packed bf16 (leaky-relu and RNE
     rounding done by the producer instead of the consumer's staging): same rounding point, same bits.
-    Covers the small tiles (B=3) and the large ones (B=24 x 200 frames, one-stream path)."""
+    Covers the small tiles (B=3) and the large ones (B=24 x 200 frames)."""
     precision('bf16')
     rng = np.random.default_rng(5)
     for B, T in ((3, 37), (24, 200)):

@@ -39,12 +39,14 @@ struct HifiGan {
 // (batch 1..8: 1-3 rounds of blocks per launch, so up to a third of the chip idles in each launch's tail) they
 // are issued on three streams; only the last conv of each branch, which accumulates into the stage output, is
 // chained j = 0 -> 1 -> 2 by events, so the sum is formed in the reference's order (bit-identical results).
-// At batch 32 a launch has > 10 rounds and the branches stay on one stream (TTSAMD_HIFIGAN_STREAMS=0/1 forces).
+// Measured gain: +6 % at batch 1, +7 % at 8, +4-5 % at 12-16, +3 % at 24, +2 % at 32.  From 14 000 frames per call on
+// (batch 32 x 448) the branches stay on one stream so that per-launch durations remain meaningful for profiling and
+// for bench.py's roofline line (TTSAMD_HIFIGAN_STREAMS=0/1 forces either schedule).
 static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
     if (h->cfg.n_kernels != 3) return false;
     const char* env = std::getenv("TTSAMD_HIFIGAN_STREAMS");   // read per call: the tests flip it
     if (env) return env[0] == '1';
-    return (int64_t)B * T <= 4608;
+    return (int64_t)B * T < 14000;
 }
 
 using TensorMap = std::map<std::string, const ttsamd_tensor*>;
