@@ -254,6 +254,42 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
 int32_t ttsamd_set_precision(int32_t precision);
 int32_t ttsamd_get_precision(void);
 
+/* ---- data-parallel sharding over the GPUs of one node: RCCL over xGMI.
+ *      No reference counterpart: the reference is single-device (inference.py:23-24); utterances are
+ *      independent, so the only exchanges are C1 (weights, once) and C2 (lengths + audio fan-in per call).
+ *      One communicator per process (= per GPU); librccl.so.1 is bound at run time by the first call.
+ *      Host binding (ctypes / cgo / JNI alike): rank 0 calls ttsamd_dp_unique_id and ships the 128 bytes
+ *      to the other ranks out of band (env, file, torch.distributed store); every rank then calls
+ *      ttsamd_dp_init after hipSetDevice(local_rank). ------------------------------------------------- */
+#define TTSAMD_DP_ID_BYTES 128
+#define TTSAMD_DP_HIFIGAN 0
+#define TTSAMD_DP_FASTPITCH 1
+int32_t ttsamd_dp_unique_id(void* id128 /* host, out */);
+int32_t ttsamd_dp_init(int32_t rank, int32_t world, const void* id128 /* host */, void** comm);
+int32_t ttsamd_dp_destroy(void* comm);
+int32_t ttsamd_dp_rank(void* comm);
+int32_t ttsamd_dp_world(void* comm);
+/* C1, generic: in-place broadcast of a device buffer from `root`. */
+int32_t ttsamd_dp_broadcast(void* comm, void* buf, int64_t nbytes, int32_t root, void* stream);
+/* C1, handle form: overwrites this rank's packed weight blobs (fp32 + bf16 planes) of a
+ * ttsamd_hifigan / ttsamd_fastpitch handle (kind = TTSAMD_DP_*) with the root's.  Non-root ranks create
+ * their handle from tensors of the same names and shapes (any values): only rank 0 reads the checkpoint
+ * (replaces one torch.load + remove_weight_norm per GPU; vocoder/__init__.py:15-18). */
+int32_t ttsamd_dp_broadcast_weights(void* comm, int32_t kind, void* handle, int32_t root, void* stream);
+/* C2a: recv[r*nbytes .. (r+1)*nbytes) = rank r's send[0 .. nbytes) on every rank (the lengths). */
+int32_t ttsamd_dp_allgather(void* comm, const void* send, void* recv, int64_t nbytes_per_rank, void* stream);
+/* C2b: packed[off(b) + t] = wave[b][t] for t < min(nsamples[b], n_max), off(b) = sum of the shorter-indexed
+ * utterances' sample counts: the valid samples of a padded ragged batch back to back (no padding crosses
+ * xGMI or PCIe).  wave [B][wave_stride], nsamples int64 [B] (device).  Needs no communicator. */
+int32_t ttsamd_dp_pack_audio(const float* wave, int64_t wave_stride, const int64_t* nsamples, int32_t batch,
+                             int64_t n_max, float* packed, void* stream);
+/* C2c: fan-in to `root`: rank r's packed[0 .. counts[r]) lands at recv[offsets[r] ..) on the root
+ * (grouped ncclSend / ncclRecv: world-1 independent point-to-point transfers, one per xGMI link).
+ * counts / offsets are HOST int64 [world] (floats), identical on every rank — the caller knows them from
+ * the all-gathered lengths; recv / offsets are ignored on the other ranks. */
+int32_t ttsamd_dp_gather_audio(void* comm, const float* packed, float* recv, const int64_t* counts,
+                               const int64_t* offsets, int32_t root, void* stream);
+
 /* Timing hooks for bench.py (roofline of the dominant kernel): when enabled, hifigan
  * forward brackets its ResBlock conv launches with HIP events on the launch stream. */
 int32_t ttsamd_profile_enable(int32_t on);

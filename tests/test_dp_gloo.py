@@ -1,10 +1,10 @@
-"""CPU, world_size 2 over gloo: the data-parallel plumbing of ttsamd.dp (shard bounds,
-weight broadcast C1, audio gather C2).  On the GPU box the same code runs over RCCL."""
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of ttsamd.dp (shard bounds, weight broadcast C1,
+length exchange + packed audio fan-in C2, sharded tts).  On the GPU box the same class runs over RCCL through
+libttsamd's ttsamd_dp_* entry points (tests/test_gpu_dp.py)."""
 import os
 import socket
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -14,6 +14,32 @@ def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         return s.getsockname()[1]
+
+
+class _Stub:
+    """Deterministic stand-in for FastPitch2Wave: text 'x'*n -> n samples whose values depend only on the
+    utterance (so any sharding must reproduce the 1-rank result bit for bit)."""
+    device = torch.device('cpu')
+
+    @staticmethod
+    def _wave(t):
+        g = torch.Generator().manual_seed(len(t))
+        return torch.randn(len(t), generator=g)
+
+    def tts(self, texts, batch_size=2, **kw):
+        return [self._wave(t) for t in texts]
+
+
+class _StubDevice(_Stub):
+    """Same, through the device-resident entry point the real FastPitch2Wave offers."""
+
+    def tts_batch_device(self, batch, **kw):
+        ws = [self._wave(t) for t in batch]
+        n = torch.tensor([w.numel() for w in ws], dtype=torch.int64)
+        wave = torch.zeros(len(ws), int(n.max()))
+        for i, w in enumerate(ws):
+            wave[i, :w.numel()] = w
+        return wave, n
 
 
 def _worker(rank, world, port, tmpdir):
@@ -26,42 +52,61 @@ def _worker(rank, world, port, tmpdir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         dev = torch.device('cpu')
+        dpx = dp.Dp(dev)
+        assert dpx.transport == 'torch' and not dpx.host_staged
         # C1: weights exist only on rank 0
         rng = np.random.default_rng(0)
         sd = {'a.weight': rng.standard_normal((3, 5, 2)).astype(np.float32),
               'b.bias': rng.standard_normal((7,)).astype(np.float32)} if rank == 0 else None
-        got = dp.broadcast_state_dict(sd, dev)
+        got = dpx.broadcast_state_dict(sd)
         ref = np.random.default_rng(0)
         assert np.array_equal(got['a.weight'], ref.standard_normal((3, 5, 2)).astype(np.float32))
         assert np.array_equal(got['b.bias'], ref.standard_normal((7,)).astype(np.float32))
+        shp = dpx.broadcast_shapes(sd)
+        assert {k: v.shape for k, v in shp.items()} == {'a.weight': (3, 5, 2), 'b.bias': (7,)}
         # sharding: 5 utterances over 2 ranks -> [0,3) and [3,5)
         lo, hi = dp.shard_bounds(5, world, rank)
         assert (lo, hi) == ((0, 3) if rank == 0 else (3, 5))
         # C2: ragged audio; utterance g has (g+1)*10 samples filled with g+1
         lens = torch.tensor([(g + 1) * 10 for g in range(lo, hi)], dtype=torch.int64)
-        wave = torch.zeros(hi - lo, int(lens.max()))
+        wave = torch.zeros(hi - lo, int(lens.max()) + 3)              # stride > longest utterance
         for i, g in enumerate(range(lo, hi)):
             wave[i, :lens[i]] = g + 1
+        all_lens = dpx.exchange_lens(lens, b_cap=4)
+        assert all_lens.shape == (2, 5)
+        assert all_lens[0].tolist() == [3, 10, 20, 30, 0] and all_lens[1].tolist() == [2, 40, 50, 0, 0]
+        for trial in range(3):                                        # persistent buffers: repeated calls
+            out = dpx.gather_audio(wave, lens, all_lens=all_lens if trial else None)
+            if rank == 0:
+                assert len(out) == 5
+                for g, w in enumerate(out):
+                    assert w.shape == ((g + 1) * 10,) and bool((w == g + 1).all())
+            else:
+                assert out is None
+        ptr = dpx._recv.buf.data_ptr() if rank == 0 else dpx._pack.buf.data_ptr()
+        dpx.gather_audio(wave, lens, all_lens=all_lens)
+        assert ptr == (dpx._recv.buf.data_ptr() if rank == 0 else dpx._pack.buf.data_ptr()), 'steady state must not reallocate'
+        # a rank with nothing to send
+        e_lens = lens if rank == 0 else torch.zeros(0, dtype=torch.int64)
+        e_wave = wave if rank == 0 else torch.zeros(0, 1)
+        out = dpx.gather_audio(e_wave, e_lens, b_cap=4)
+        if rank == 0:
+            assert [w.numel() for w in out] == [10, 20, 30]
+        # end-to-end sharded tts: rank-sharded result == 1-rank result, bit-identical per utterance
+        texts = ['x' * n for n in (5, 9, 3, 7, 1, 12, 2)]
+        for model in (_Stub(), _StubDevice()):
+            for bs in (2, 3, 8):
+                res = dp.tts_sharded(model, texts, batch_size=bs, dp=dpx)
+                if rank == 0:
+                    single = _Stub().tts(texts)
+                    assert [w.numel() for w in res] == [len(t) for t in texts]
+                    assert all(torch.equal(a, b) for a, b in zip(res, single))
+                else:
+                    assert res is None
+        # module-level helpers keep working
         out = dp.gather_audio(wave, lens)
-        if rank == 0:
-            assert len(out) == 5
-            for g, w in enumerate(out):
-                assert w.shape == ((g + 1) * 10,) and bool((w == g + 1).all())
-        else:
-            assert out is None
-        # end-to-end sharded tts with a stub model: utterance text 'x'*n -> wave of n samples valued n
-        class Stub:
-            device = torch.device('cpu')
-
-            def tts(self, texts, batch_size=2, **kw):
-                return [torch.full((len(t),), float(len(t))) for t in texts]
-        texts = ['x' * n for n in (5, 9, 3, 7, 1)]
-        res = dp.tts_sharded(Stub(), texts, batch_size=2)
-        if rank == 0:
-            assert [w.numel() for w in res] == [5, 9, 3, 7, 1]
-            assert all(bool((w == w.numel()).all()) for w in res)
-        else:
-            assert res is None
+        assert (out is None) == (rank != 0)
+        dp.reset_default()
         with open(os.path.join(tmpdir, f'ok{rank}'), 'w') as f:
             f.write('ok')
     finally:
@@ -82,3 +127,17 @@ def test_shard_bounds_cover():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_bench_self_launch_relays_failure():
+    """`python bench.py --gpus 2` typed as is starts its own ranks; without a GPU every rank fails and the
+    launcher must exit non-zero (never hang, never print a JSON line)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('a GPU is present: covered by tests/test_gpu_dp.py')
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, timeout=300)
+    assert p.returncode != 0 and b'{' not in p.stdout

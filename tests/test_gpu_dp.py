@@ -1,0 +1,151 @@
+"""GPU (pytest -m gpu): the data-parallel path with the REAL engines.
+
+* `test_dp_rccl_world1`: the C-ABI RCCL transport (ttsamd_dp_*: dlopen of librccl, communicator, blob
+  broadcast, length all-gather, packed fan-in) with a 1-rank communicator — everything but the peer
+  transfers, which need a second GPU.
+* `test_dp_two_ranks_one_device`: two processes share cuda:0 and exchange over gloo with host staging
+  (RCCL refuses two ranks on one GPU): real FastPitch + HiFi-GAN engines per rank, weights from rank 0
+  only, rank-sharded waves gathered on rank 0 == the same sub-batches computed by one process, bit for bit,
+  and == the unsharded 4-utterance batch within the waveform tolerance.
+* `test_bench_two_ranks_one_device`: `python bench.py --gpus 2` typed as is prints ONE json line, n_gpus 2.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+WAVE_TOL = 1e-4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _inputs(n, tokens=12):
+    """n utterances of equal token count whose durations are permutations of one row: every utterance has the
+    same number of frames, so FastPitch's padded-batch semantics do not depend on the sharding."""
+    from ttsamd import synth
+    ids = synth.synth_ids(n, tokens)
+    base = synth.synth_durations(1, tokens)[0]
+    rng = np.random.default_rng(5)
+    dur = np.stack([base[rng.permutation(tokens)] for _ in range(n)]).astype(np.float32)
+    return ids, dur
+
+
+def _synth(fp, hg, ids, dur, dev):
+    mel, dec_lens, *_ = fp.infer(torch.from_numpy(ids).to(dev), dur_tgt=torch.from_numpy(dur).to(dev))
+    wave = hg.forward(mel, dec_lens)
+    return wave, dec_lens * hg.hop
+
+
+def test_dp_rccl_world1():
+    """Own process: torch.distributed + a second RCCL communicator must not leak into the other tests."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, 'tts-arabic-pytorch_amd'))
+import numpy as np, torch, torch.distributed as dist
+from ttsamd import dp, synth
+from ttsamd.engine import FastPitchEngine, HifiGanEngine
+dev = torch.device('cuda:0'); torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+dpx = dp.Dp(dev)
+assert dpx.transport == 'rccl' and dpx.comm is not None
+hg_sd = synth.hifigan_state_dict()
+hg = HifiGanEngine(hg_sd, device=dev)
+mel = torch.randn(2, 80, 9, device=dev)
+lens = torch.tensor([9, 5], device=dev)
+w0 = hg.forward(mel, lens).clone()
+dpx.broadcast_weights(hg)                       # root == self: weights must survive
+assert torch.equal(hg.forward(mel, lens), w0)
+sd = dpx.broadcast_state_dict({'a': np.arange(6, dtype=np.float32).reshape(2, 3)})
+assert sd['a'].tolist() == [[0, 1, 2], [3, 4, 5]]
+n = lens * hg.hop
+al = dpx.exchange_lens(n, b_cap=3)
+assert al.tolist() == [[2, 9 * 256, 5 * 256, 0]]
+for _ in range(2):
+    views = dpx.gather_audio(w0, n, all_lens=al)
+    assert len(views) == 2 and torch.equal(views[0], w0[0, :9 * 256]) and torch.equal(views[1], w0[1, :5 * 256])
+dpx.close(); dist.destroy_process_group()
+print('RCCL1 OK')
+''' % REPO
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port())))
+    assert p.returncode == 0 and b'RCCL1 OK' in p.stdout, p.stderr.decode()[-3000:]
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, os.path.join(REPO, 'tts-arabic-pytorch_amd'))
+    from ttsamd import dp, synth
+    from ttsamd.engine import FastPitchEngine, HifiGanEngine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(0)
+        dpx = dp.Dp(dev)
+        assert dpx.transport == 'torch' and dpx.host_staged
+        fp_sd = dpx.broadcast_state_dict(synth.fastpitch_state_dict() if rank == 0 else None)
+        hg_sd = dpx.broadcast_state_dict(synth.hifigan_state_dict() if rank == 0 else None)
+        fp, hg = FastPitchEngine(fp_sd, device=dev), HifiGanEngine(hg_sd, device=dev)
+        ids, dur = _inputs(4)
+        lo, hi = dp.shard_bounds(4, world, rank)
+        state = {}
+
+        def hook(dec_lens):
+            state['all'] = dpx.exchange_lens(dec_lens, 2)
+            return state['all'][rank, 1:3]
+        mel, dec_lens, *_ = fp.infer(torch.from_numpy(ids[lo:hi]).to(dev), dur_tgt=torch.from_numpy(dur[lo:hi]).to(dev),
+                                     lens_hook=hook)
+        wave = hg.forward(mel, dec_lens)
+        samples = state['all'].copy()
+        samples[:, 1:] *= hg.hop
+        views = dpx.gather_audio(wave, dec_lens * hg.hop, all_lens=samples)
+        if rank == 0:
+            assert len(views) == 4
+            got = [v.clone() for v in views]
+            for r in range(world):                      # same sub-batches in ONE process: bit-identical
+                l, h = dp.shard_bounds(4, world, r)
+                w, n = _synth(fp, hg, ids[l:h], dur[l:h], dev)
+                for i in range(h - l):
+                    assert torch.equal(got[l + i], w[i, :int(n[i])]), (r, i)
+            w, n = _synth(fp, hg, ids, dur, dev)        # unsharded batch: equal frame counts -> same result
+            for i in range(4):
+                assert int(n[i]) == got[i].numel()
+                assert float((w[i, :int(n[i])] - got[i]).abs().max()) < WAVE_TOL
+        else:
+            assert views is None
+        with open(os.path.join(tmpdir, f'ok{rank}'), 'w') as f:
+            f.write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_two_ranks_one_device(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')
+
+
+def test_bench_two_ranks_one_device():
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--batch', '4', '--tokens', '16'], capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['scaling'] == 'weak'
+    assert 'ONE device' in out['config']['parallelism']

@@ -1,0 +1,73 @@
+"""GPU parity at BASELINE's FULL sizes, every utterance (pytest -m gpu): the whole bench.py workload
+(config 2: 32 utterances x 64 tokens, forced durations) and config 3's per-GPU share in its bf16 modes.
+
+The checker is oracle/tts_oracle.py — the restatement of the reference pinned to the real reference by
+tests/test_oracle_golden.py — run with its tensors ON THE GPU (torch-ROCm: MIOpen / rocBLAS fp32), because on
+the host it needs ~1 s per utterance.  It follows the reference's plumbing exactly: FastPitch on the padded
+batch, then the vocoder looped per utterance on exact-length mels (models/fastpitch/networks.py:334-345).
+Tolerances (BASELINE.json north_star): mel 1e-3, wave 1e-4 max-abs, dec_lens exact; bf16 operands have their own
+stated tolerances (tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL, WAVE_TOL = 1e-3, 1e-4                  # fp32 and split-bf16
+BF16_MEL_TOL, BF16_WAVE_TOL = 6e-2, 4e-2        # plain bf16 operands (8-bit mantissa) through ~75 convs
+B, LT = 32, 64
+
+
+@pytest.fixture(scope='module')
+def workload(synth_weights):
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    import tts_oracle as O
+    from ttsamd import synth
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    dev = torch.device('cuda:0')
+    ids_np, dur_np = synth.synth_ids(B, LT), synth.synth_durations(B, LT)
+    fw = {k: v.to(dev) for k, v in O.to_torch(synth_weights['fastpitch']).items()}
+    hw = {k: v.to(dev) for k, v in O.fold_weight_norm(synth_weights['hifigan']).items()}
+    with torch.inference_mode(), torch.device(dev):
+        mel_ref, lens_ref, waves_ref = O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids_np,
+                                                   dur_tgt=torch.from_numpy(dur_np).to(dev))
+    torch.cuda.synchronize()
+    # the GPU-resident checker itself against the host oracle on one utterance (the longest: batch-independent)
+    lens = np.asarray(lens_ref.cpu())
+    bmax = int(np.argmax(lens))
+    with torch.inference_mode():
+        m1, l1, w1 = O.tts_batch(O.to_torch(synth_weights['fastpitch']), NET_CONFIG,
+                                 O.fold_weight_norm(synth_weights['hifigan']), HIFIGAN_CONFIG, ids_np[bmax:bmax + 1],
+                                 dur_tgt=dur_np[bmax:bmax + 1])
+    assert int(l1[0]) == int(lens[bmax])
+    assert float((mel_ref[bmax, :, :int(l1[0])].cpu() - m1[0, :, :int(l1[0])]).abs().max()) < 1e-4
+    assert float((waves_ref[bmax].cpu().reshape(-1) - w1[0].reshape(-1)).abs().max()) < 2e-5
+    return {'dev': dev, 'ids': torch.from_numpy(ids_np).to(dev), 'dur': torch.from_numpy(dur_np).to(dev),
+            'mel': mel_ref.cpu(), 'lens': lens, 'waves': [w.reshape(-1).cpu() for w in waves_ref]}
+
+
+@pytest.mark.parametrize('mode,mel_tol,wave_tol', [('f32', MEL_TOL, WAVE_TOL), ('bf16x3', MEL_TOL, WAVE_TOL),
+                                                   ('bf16', BF16_MEL_TOL, BF16_WAVE_TOL)])
+def test_full_batch_every_utterance(workload, synth_weights, mode, mel_tol, wave_tol):
+    from ttsamd.engine import FastPitchEngine, HifiGanEngine, set_precision
+    set_precision(mode)
+    try:
+        dev = workload['dev']
+        fp, hg = FastPitchEngine(synth_weights['fastpitch'], device=dev), HifiGanEngine(synth_weights['hifigan'], device=dev)
+        mel, dec_lens, *_ = fp.infer(workload['ids'], dur_tgt=workload['dur'])
+        wave = hg.forward(mel, dec_lens)
+        torch.cuda.synchronize()
+        dl = dec_lens.cpu().numpy()
+        assert np.array_equal(dl, workload['lens'])                                  # exact
+        mel, wave = mel.cpu(), wave.cpu()
+        worst_mel = worst_wave = 0.0
+        for b in range(B):
+            n = int(dl[b])
+            worst_mel = max(worst_mel, float((mel[b, :, :n] - workload['mel'][b, :, :n]).abs().max()))
+            assert workload['waves'][b].numel() == 256 * n
+            worst_wave = max(worst_wave, float((wave[b, :256 * n] - workload['waves'][b]).abs().max()))
+            assert float(wave[b, 256 * n:].abs().max()) == 0.0 if 256 * n < wave.shape[1] else True
+        print(f'full-size {mode}: mel max-abs {worst_mel:.2e} (tol {mel_tol}), wave max-abs {worst_wave:.2e} (tol {wave_tol})')
+        assert worst_mel < mel_tol and worst_wave < wave_tol
+    finally:
+        set_precision('f32')

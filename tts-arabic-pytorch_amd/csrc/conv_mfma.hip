@@ -122,17 +122,45 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
         if (p.scale) ep_scale = p.scale[co_];
     }
 
-    f32x16 acc[MT][NTL];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int qw0 = wn * NTL * 32;
     const bool wave_active = (q0 + qw0) < n_out;   // wave-uniform
     const int kk = lane >> 5, l31 = lane & 31;
+
+    // Residual preload: the accumulators START from the residual tile (y = res + sum ..., then + bias in the epilogue)
+    // instead of the epilogue reading it.  The loads go out with the first chunk's staging loads and land directly in
+    // the accumulator registers in the MFMA C layout (row = 8*(r>>2) + 4*kk + (r&3), 32 consecutive columns per
+    // half-wave = one 128-byte line per row), so the residual costs no extra registers and no memory round trip after
+    // the main loop: the row epilogue becomes LDS transposition + bias + stores, nothing to wait for.  (Before: one
+    // residual round trip per row iteration, with every vmcnt wait also draining the previous row's store; the epilogue
+    // lasted as long as the main loop)
+#ifdef TTS_NO_PRELOAD
+    const bool preload = false;
+#else
+    const bool preload = EPI == 0 && p.res != nullptr && p.scale == nullptr;
+#endif
+    f32x16 acc[MT][NTL];
+    // issued between the first chunk's staging loads and its LDS writes (see the prologue), so that the operands the
+    // first MFMA needs are at the head of the memory queue
+#define TTS_INIT_ACC()                                                                                       \
+    if (preload) {                                                                                           \
+        const float* __restrict__ rbp = p.res + (int64_t)b * p.r_bs;                                         \
+        const int r_cs = p.r_cs, co_lim = p.Cout - 1;                                                        \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
+            _Pragma("unroll") for (int j = 0; j < NTL; ++j) {                                                \
+                const int q = q0 + qw0 + j * 32 + l31;                                                       \
+                const bool q_ok = q < n_out;                                                                 \
+                const float* __restrict__ rq = rbp + (q_ok ? q : 0);                                         \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+                    const int co = co_blk0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;        \
+                    const float v = rq[(int64_t)min(co, co_lim) * r_cs];                                     \
+                    acc[i][j][r] = q_ok ? v : 0.f;                                                           \
+                }                                                                                            \
+            }                                                                                                \
+    } else {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
+            _Pragma("unroll") for (int j = 0; j < NTL; ++j)                                                  \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;                           \
+    }
 
     // ---- staging registers.  X item it = (oc, kk, col): the 4 channels 8*oc + 2p + kk, p = 0..3,
     // at one input position -> one float4; W is a linear float4 copy.  Loads are unconditional
@@ -224,20 +252,20 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
         for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB_(J, sx, sw, xc0, wc0)
 #pragma unroll
         for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB_(J, sxb, swb, xc1, wc1)
+        TTS_INIT_ACC()
 #pragma unroll
         for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB_(J, smem4, sx, sw)
 #pragma unroll
         for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB_(J, smem4 + G::BUF4, sxb, swb)
     } else {
-        for (int c0 = 0; c0 < NSTAGE - 1 && c0 < n_chunks; ++c0) {
-            const float* __restrict__ xc = xb + (int64_t)c0 * KC * x_cs;
-            const float4* __restrict__ wc = wp4 + (int64_t)c0 * G::NOCT * K * 2 * CoutP;
-            float4* sbp = smem4 + c0 * G::BUF4;
+        // one stage to fill: two-stage ring, or a single chunk (n_chunks >= 1 always)
+        const float* __restrict__ xc = xb;
+        const float4* __restrict__ wc = wp4;
 #pragma unroll
-            for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
+        for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
+        TTS_INIT_ACC()
 #pragma unroll
-            for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, sbp)
-        }
+        for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, smem4)
     }
     __syncthreads();
 #pragma unroll
@@ -308,6 +336,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
         }
         stage = stage_next;
     }
+#undef TTS_INIT_ACC
 #undef TTS_LOAD_JOB
 #undef TTS_WRITE_JOB
 #undef TTS_LOAD_JOB_
@@ -332,7 +361,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
             float* ep = reinterpret_cast<float*>(smem4);
             float* epb = ep + LDS_F - 2 * CO_BLK;                               // [CO_BLK] bias, [CO_BLK] scale
             float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
-            const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+            const float* __restrict__ rb = (p.res && !preload) ? p.res + (int64_t)b * p.r_bs : nullptr;
             const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
             const float div = p.div;
 #pragma unroll

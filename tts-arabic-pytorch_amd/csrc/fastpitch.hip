@@ -33,6 +33,7 @@ struct FastPitch {
     ttsamd_fastpitch_cfg cfg;
     float* dev = nullptr;
     uint16_t* dev16 = nullptr;
+    int64_t dev_n = 0, dev16_n = 0;   // element counts of the two blobs (ttsamd_dp_broadcast_weights)
     std::vector<FftLayer> enc, dec;
     Predictor dur, pitch, energy;
     int64_t word_emb, pos_enc, pos_dec, spk_emb = -1, proj_b;
@@ -191,6 +192,8 @@ int32_t fastpitch_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_f
     }
     int32_t rc = b.rc;
     if (rc == 0) {
+        h->dev_n = (int64_t)b.blob.size();
+        h->dev16_n = (int64_t)b.blob16.size();
         hipError_t e = hipMalloc((void**)&h->dev, b.blob.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, b.blob.data(), b.blob.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&h->dev16, b.blob16.size() * sizeof(uint16_t));
@@ -390,6 +393,11 @@ int32_t fastpitch_decode(const FastPitch* h, float* x, const int64_t* dec_lens, 
     TTS_TRY(run_fft(h, h->dec, c.out_fft_d_head, x, dec_lens, B, T, w, s));
     // proj + permute (model.py:406-408): channel-first output IS the permuted layout
     return run_conv(h, h->proj, x, mel, nullptr, B, T, nullptr, 0, s);
+}
+
+void fastpitch_blobs(const void* hv, void** f32, int64_t* n_f32, void** b16, int64_t* n_b16) {
+    const FastPitch* h = (const FastPitch*)hv;
+    *f32 = h->dev; *n_f32 = h->dev_n; *b16 = h->dev16; *n_b16 = h->dev16_n;
 }
 
 }  // namespace ttsamd

@@ -24,6 +24,7 @@ struct HifiGan {
     ttsamd_hifigan_cfg cfg;
     float* dev = nullptr;  // one blob with every packed weight and bias
     uint16_t* dev16 = nullptr;  // bf16 hi/lo planes of the same packed weights
+    int64_t dev_n = 0, dev16_n = 0;  // element counts of the two blobs (ttsamd_dp_broadcast_weights)
     ConvW conv_pre, conv_post;
     std::vector<ConvW> ups;
     std::vector<ConvW> c1, c2;  // [stage*n_kernels + j][m]
@@ -208,6 +209,8 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
         }
     }
     if (rc == 0) {
+        h->dev_n = (int64_t)blob.size();
+        h->dev16_n = (int64_t)blob16.size();
         hipError_t e = hipMalloc((void**)&h->dev, blob.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&h->dev16, blob16.size() * sizeof(uint16_t));
@@ -367,6 +370,11 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                              h->dev + h->conv_post.b_off, lens, mul, B, h->conv_post.cin, L, 0.01f, wave,
                              (int64_t)L, s));
     return 0;
+}
+
+void hifigan_blobs(const void* hv, void** f32, int64_t* n_f32, void** b16, int64_t* n_b16) {
+    const HifiGan* h = (const HifiGan*)hv;
+    *f32 = h->dev; *n_f32 = h->dev_n; *b16 = h->dev16; *n_b16 = h->dev16_n;
 }
 
 }  // namespace ttsamd

@@ -204,6 +204,21 @@ class FastPitch2Wave(nn.Module):
         return wave[0].cpu()
 
     @torch.inference_mode()
+    def tts_batch_device(self, batch: List[str], speed: float = 1, speaker_id: int = 0, denoise: float = 0,
+                         vowelizer=None, pitch_mul: float = 1., pitch_add: float = 0., return_mel: bool = False):
+        """`tts_batch` without the device->host copy: (wave [B, n_max] float32, n_samples int64 [B]), both in HBM,
+        rows in the order of `batch` (zeros past n_samples[b]).  What the data-parallel gather (ttsamd.dp) and
+        any GPU-side consumer take; `tts_batch` is this plus one D2H."""
+        mel, dec_lens, reverse_ids = self.model._ttmel_batch_padded(batch, speed, speaker_id, vowelizer, pitch_mul,
+                                                                    pitch_add)
+        wave = self.vocoder.engine().forward(mel, dec_lens)             # one ragged batched launch sequence
+        n = (dec_lens * self.vocoder.engine().hop)
+        if denoise > 0:
+            wave = self.denoiser.forward_batch(wave, n, denoise)
+        rev = reverse_ids.to(wave.device)
+        return wave.index_select(0, rev), n.index_select(0, rev)
+
+    @torch.inference_mode()
     def tts_batch(self, batch: List[str], speed: float = 1, speaker_id: int = 0, denoise: float = 0, vowelizer=None,
                   pitch_mul: float = 1., pitch_add: float = 0., return_mel: bool = False):
         mel, dec_lens, reverse_ids = self.model._ttmel_batch_padded(batch, speed, speaker_id, vowelizer, pitch_mul,

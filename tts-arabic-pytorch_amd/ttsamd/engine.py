@@ -151,11 +151,13 @@ class FastPitchEngine:
             self.handle = None
 
     def infer(self, ids, pace=1.0, dur_tgt=None, pitch_tgt=None, energy_tgt=None, pitch_mul=1.0, pitch_add=0.0,
-              max_duration=75, speaker=0, return_idx=False):
+              max_duration=75, speaker=0, return_idx=False, lens_hook=None):
         """Same contract as FastPitch.infer (model.py:351-353) with pitch_transform restricted to
         the affine pitch_trf the reference wrappers install (networks.py:38-42,121-122).
         ids int64 [B,L] zero-padded at the end.  Returns (mel [B,80,T_max], dec_lens int64 [B],
-        dur_pred [B,L], pitch_pred [B,1,L], energy_pred [B,L] or None)."""
+        dur_pred [B,L], pitch_pred [B,1,L], energy_pred [B,L] or None).
+        `lens_hook(dec_lens_device) -> host ints [B]` replaces the one device->host read of the call (the
+        data-parallel path all-gathers every rank's lengths in that same synchronisation, ttsamd.dp)."""
         dev = self.device
         ids = torch.as_tensor(ids).to(device=dev, dtype=torch.int64).contiguous()
         B, Lt = ids.shape
@@ -176,7 +178,10 @@ class FastPitchEngine:
                                                 float(max_duration), _ptr(enc), _ptr(dur_pred), _ptr(pitch_pred),
                                                 _ptr(energy_pred), _ptr(reps), _ptr(dec_lens), _ptr(ws), nb, _stream()),
                     'fastpitch_encode')
-            t_max = int(dec_lens.max().item())          # the reference syncs here too (model.py:76)
+            if lens_hook is None:
+                t_max = int(dec_lens.max().item())      # the reference syncs here too (model.py:76)
+            else:
+                t_max = int(max(lens_hook(dec_lens), default=0))
             x = torch.empty(B, d, t_max, dtype=torch.float32, device=dev)
             idx = torch.empty(B, t_max, dtype=torch.int32, device=dev) if return_idx else None
             mel = torch.empty(B, self.n_mel, t_max, dtype=torch.float32, device=dev)

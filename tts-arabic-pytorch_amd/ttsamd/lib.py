@@ -89,6 +89,16 @@ SYMBOLS = {
     'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     'ttsamd_set_precision': (_I32, [_I32]),
     'ttsamd_get_precision': (_I32, []),
+    'ttsamd_dp_unique_id': (_I32, [_P]),
+    'ttsamd_dp_init': (_I32, [_I32, _I32, _P, C.POINTER(_P)]),
+    'ttsamd_dp_destroy': (_I32, [_P]),
+    'ttsamd_dp_rank': (_I32, [_P]),
+    'ttsamd_dp_world': (_I32, [_P]),
+    'ttsamd_dp_broadcast': (_I32, [_P, _P, _I64, _I32, _P]),
+    'ttsamd_dp_broadcast_weights': (_I32, [_P, _I32, _P, _I32, _P]),
+    'ttsamd_dp_allgather': (_I32, [_P, _P, _P, _I64, _P]),
+    'ttsamd_dp_pack_audio': (_I32, [_P, _I64, _P, _I32, _I64, _P, _P]),
+    'ttsamd_dp_gather_audio': (_I32, [_P, _P, _P, C.POINTER(_I64), C.POINTER(_I64), _I32, _P]),
     'ttsamd_profile_enable': (_I32, [_I32]),
     'ttsamd_profile_read': (_I32, [C.POINTER(C.c_double)]),
 }
