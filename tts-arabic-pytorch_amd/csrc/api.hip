@@ -28,10 +28,13 @@ struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev;   // pairs
     size_t used = 0;
+    size_t launches = 0;
     double flops_per_frame = 0.0;
 } g_prof;
 
-void prof_begin(hipStream_t s, double flops_per_frame) {
+// Opens an event pair on `s` (a single launch, or a fork..join section of concurrent launches on several streams: the
+// pair then measures the wall time of the section on the stream that forks and joins, never a sum of overlapping spans).
+void prof_section_begin(hipStream_t s) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (g_prof.used + 2 > g_prof.ev.size()) {
@@ -41,16 +44,30 @@ void prof_begin(hipStream_t s, double flops_per_frame) {
         g_prof.ev.push_back(b);
     }
     (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-    g_prof.flops_per_frame += flops_per_frame;
 }
 
-void prof_end(hipStream_t s) {
+void prof_section_end(hipStream_t s) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (g_prof.used + 2 > g_prof.ev.size()) return;
     (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
     g_prof.used += 2;
 }
+
+// Counts one conv launch (and its algorithmic FLOPs per frame) inside an open section.
+void prof_add(double flops_per_frame) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.launches += 1;
+    g_prof.flops_per_frame += flops_per_frame;
+}
+
+void prof_begin(hipStream_t s, double flops_per_frame) {
+    prof_section_begin(s);
+    prof_add(flops_per_frame);
+}
+
+void prof_end(hipStream_t s) { prof_section_end(s); }
 
 struct HifiGan;
 struct FastPitch;
@@ -343,6 +360,7 @@ int32_t ttsamd_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = on != 0;
     g_prof.used = 0;
+    g_prof.launches = 0;
     g_prof.flops_per_frame = 0.0;
     return 0;
 }
@@ -358,7 +376,7 @@ int32_t ttsamd_profile_read(double* out3) {
         ms += t;
     }
     out3[0] = ms;
-    out3[1] = (double)(g_prof.used / 2);
+    out3[1] = (double)g_prof.launches;
     out3[2] = g_prof.flops_per_frame;
     return 0;
 }

@@ -96,10 +96,13 @@ struct ConvParams {
     int32_t y_packed;         // write y in that layout (requires Cout % 8 == 0, y_ts == 1, mode 0, no phases)
     float pack_slope;         // ... after applying leaky-relu with this slope
     int32_t x_packed;         // read x in that layout (x_cs = positions per row; in_slope is ignored)
+    int32_t tile_major;       // set by the launcher: blockIdx.x = utterance slot, blockIdx.z = time tile (ragged batches)
     unsigned long long* timing;   // tools/conv_bench -DTTS_TIMING only: [blocks][8] clock samples (nullptr otherwise)
 };
 constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)
 
+// block order of a launch (conv_mfma.hip)
+bool tile_major_order(const ConvParams& p, unsigned n_tiles);
 // Launches the kernel; returns 0 or a negative code.
 int32_t launch_conv(const ConvParams& p, hipStream_t stream);
 // Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]

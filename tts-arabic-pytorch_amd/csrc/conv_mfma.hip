@@ -67,6 +67,8 @@ struct Geo {
 //   0: row-major float4 epilogue, bias / scale / residual / ReLU / accumulate modes   (every ResBlock and FFT conv)
 //   1: the same plus GELU and tanh                                                    (Vocos pwconv1, Tacotron2 postnet)
 //   2: per-lane epilogue for everything else: polyphase upsamplers, unaligned rows, split-K partial sums
+//   3: row epilogue with the residual (and, in the accumulate modes, the previous y) PRELOADED into the accumulators
+//      (every c2 conv of a ResBlock, o_net and the second conv-FF conv): nothing is read after the main loop
 template <int K, int MT, int NTL, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
@@ -76,20 +78,33 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     constexpr int KC = G::KC, WS = G::WS, NXI = G::NXI, NW = G::NW, NGRP = G::NGRP, NSTAGE = G::NSTAGE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int b = blockIdx.z;
+    // ragged batches: tile-major block order (x = utterance slot, z = time tile), see ConvParams::tile_major
+    const int b = p.tile_major ? (int)((blockIdx.x + blockIdx.z) % (unsigned)p.batch) : (int)blockIdx.z;
     const int n_co_tiles = p.CoutP / CO_BLK;
     const int tiles_y = n_co_tiles * p.n_phase;
     const int ks = blockIdx.y / tiles_y, by = blockIdx.y % tiles_y;   // ks = split-K slice (0 when ksplit == 1)
     const int phase = by / n_co_tiles;
     const int co_blk0 = (by % n_co_tiles) * CO_BLK;
-    const int q0 = blockIdx.x * NT_BLK;
+    const int q0 = (p.tile_major ? blockIdx.z : blockIdx.x) * NT_BLK;
 
     int n_out = p.Nout;
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
-    if (q0 >= n_out) return;
 #ifdef TTS_TIMING   /* tools/conv_bench: block timeline (start, prologue done, main loop done, end) per block */
     const unsigned long long t_start = wall_clock64();
-    unsigned long long t_pro = 0, t_main = 0;
+    if (q0 >= n_out) {   // dead block of a ragged batch: stamp it too (pro = main = 0)
+        if (p.timing && threadIdx.x == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            unsigned long long* tp = p.timing + (size_t)lin * 8;
+            tp[0] = t_start; tp[1] = 0; tp[2] = 0; tp[3] = wall_clock64();
+        }
+        return;
+    }
+#else
+    if (q0 >= n_out) return;
+#endif
+#ifdef TTS_TIMING
+    const unsigned long long c_start = clock64();   // s_memtime: shader-clock ticks
+    unsigned long long t_pro = 0, t_main = 0, t_e1 = 0;
 #endif
     int in_len = p.Lin;
     if (p.lens_in) in_len = min(in_len, (int)p.lens_in[b] * p.len_in_mul);
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     // main loop, so that the rolled row loop reads them with lgkmcnt waits only (a vmcnt wait would also wait for the
     // previous row's store on this ISA)
     float ep_bias = 0.f, ep_scale = 1.f;
-    if (EPI < 2 && tid < CO_BLK) {
+    if (EPI != 2 && tid < CO_BLK) {
         const int co_ = min(co_blk0 + tid, p.Cout - 1);
         if (p.bias) ep_bias = p.bias[co_];
         if (p.scale) ep_scale = p.scale[co_];
@@ -126,36 +141,53 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     const bool wave_active = (q0 + qw0) < n_out;   // wave-uniform
     const int kk = lane >> 5, l31 = lane & 31;
 
-    // Residual preload: the accumulators START from the residual tile (y = res + sum ..., then + bias in the epilogue)
-    // instead of the epilogue reading it.  The loads go out with the first chunk's staging loads and land directly in
+    // Residual preload: the accumulators START from the residual tile -- plus, in the accumulate modes, the previous
+    // value of y -- (y = [y_prev +] res + sum ..., then + bias [, / div] in the epilogue) instead of the epilogue reading them.  The loads go out with the first chunk's staging loads and land directly in
     // the accumulator registers in the MFMA C layout (row = 8*(r>>2) + 4*kk + (r&3), 32 consecutive columns per
     // half-wave = one 128-byte line per row), so the residual costs no extra registers and no memory round trip after
     // the main loop: the row epilogue becomes LDS transposition + bias + stores, nothing to wait for.  (Before: one
     // residual round trip per row iteration, with every vmcnt wait also draining the previous row's store; the epilogue
     // lasted as long as the main loop)
-#ifdef TTS_NO_PRELOAD
-    const bool preload = false;
-#else
-    const bool preload = EPI == 0 && p.res != nullptr && p.scale == nullptr;
-#endif
+    constexpr bool preload = EPI == 3;
     f32x16 acc[MT][NTL];
     // issued between the first chunk's staging loads and its LDS writes (see the prologue), so that the operands the
     // first MFMA needs are at the head of the memory queue
+    // buffer loads: ONE per-lane 32-bit offset per column tile + a scalar row offset per load (64 flat loads would keep
+    // 64 x 64-bit addresses live: +44 VGPRs, one resident block less per CU).  Rows >= Cout fall outside num_records and
+    // read as zero; out-of-range columns read column 0 (never stored).
 #define TTS_INIT_ACC()                                                                                       \
     if (preload) {                                                                                           \
-        const float* __restrict__ rbp = p.res + (int64_t)b * p.r_bs;                                         \
-        const int r_cs = p.r_cs, co_lim = p.Cout - 1;                                                        \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
-            _Pragma("unroll") for (int j = 0; j < NTL; ++j) {                                                \
-                const int q = q0 + qw0 + j * 32 + l31;                                                       \
-                const bool q_ok = q < n_out;                                                                 \
-                const float* __restrict__ rq = rbp + (q_ok ? q : 0);                                         \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
-                    const int co = co_blk0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;        \
-                    const float v = rq[(int64_t)min(co, co_lim) * r_cs];                                     \
-                    acc[i][j][r] = q_ok ? v : 0.f;                                                           \
+        const int wm_s = __builtin_amdgcn_readfirstlane(wm);                                                 \
+        const int row0 = co_blk0 + wm_s * MT * 32;                                                           \
+        int voff[NTL];                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < NTL; ++j) {                                                    \
+            const int q = q0 + qw0 + j * 32 + l31;                                                           \
+            voff[j] = (q < n_out ? q : 0) * 4;                                                               \
+        }                                                                                                    \
+        {                                                                                                    \
+            const int r_cs = p.r_cs;                                                                         \
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res + (int64_t)b * p.r_bs), 0, \
+                                                              p.Cout * r_cs * 4, 0x00020000);                \
+            const int vk = 4 * kk * r_cs * 4;                                                                \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                   \
+                _Pragma("unroll") for (int j = 0; j < NTL; ++j)                                              \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+                        acc[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(       \
+                            rs, voff[j] + vk, (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * r_cs * 4, 0));      \
+        }                                                                                                    \
+        if (p.mode != 0) {                                                                                   \
+            const int y_cs_ = p.y_cs;                                                                        \
+            const auto ys = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)b * p.y_bs, 0, p.Cout * y_cs_ * 4, 0x00020000); \
+            const int vk = 4 * kk * y_cs_ * 4;                                                               \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                   \
+                _Pragma("unroll") for (int j = 0; j < NTL; ++j) {                                            \
+                    f32x16 t;                                                                                \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+                        t[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(               \
+                            ys, voff[j] + vk, (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * y_cs_ * 4, 0));     \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = t[r] + acc[i][j][r];       \
                 }                                                                                            \
-            }                                                                                                \
+        }                                                                                                    \
     } else {                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
             _Pragma("unroll") for (int j = 0; j < NTL; ++j)                                                  \
@@ -349,7 +381,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #endif
     // ---- epilogue: bias, residual, activation, accumulate modes ------------------------------------------
     const int co_w0 = co_blk0 + wm * MT * 32;
-    if constexpr (EPI < 2) {
+    if constexpr (EPI != 2) {
         {
 
             constexpr int LDS_F = NSTAGE * G::BUF4 * 4;                         // floats of LDS this block owns
@@ -375,13 +407,55 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                            if (row >= ps * ROWS_P && row < (ps + 1) * ROWS_P)
+                            if (NPASS == 1 || (row >= ps * ROWS_P && row < (ps + 1) * ROWS_P))   // NPASS > 1: a branch per element
                                 ep[(row - ps * ROWS_P) * NT_BLK + qw0 + j * 32 + l31] = acc[i][j][r];
                         }
                 __syncthreads();
+#ifdef TTS_TIMING
+                if (ps == 0) t_e1 = wall_clock64();
+#endif
                 constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                     // rows per wave instruction
                 constexpr int CPL = LPR >= 64 ? LPR / 64 : 1;                     // float4 columns groups per lane
                 constexpr int NR = (ROWS_P + 4 * RPI - 1) / (4 * RPI);            // row iterations per wave
+                if (preload || (!rb && mode == 0 && relu_out < 2)) {
+                    // nothing to read from memory (no residual, or it came in through the accumulators): a loop without
+                    // a single vmcnt wait -- on this ISA a vmcnt wait also drains the wave's previous STORE, which made
+                    // every row iteration of the generic loop below one full memory round trip (~1.7 us)
+                    const float lo = relu_out == 1 ? 0.f : -__builtin_inff();
+                    const bool do_div = mode == 2;
+#pragma unroll 4
+                    for (int it = 0; it < NR; ++it) {
+                        const int r0 = wid * RPI + it * 4 * RPI;
+                        const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
+                        const int co = co_blk0 + ps * ROWS_P + rl;
+                        if (rl >= ROWS_P || ps * ROWS_P + rl >= CO_BLK || co >= Cout) continue;
+                        const float bsv = epb[ps * ROWS_P + rl], scv = epb[CO_BLK + ps * ROWS_P + rl];
+#pragma unroll
+                        for (int cg = 0; cg < CPL; ++cg) {
+                            const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
+                            const int q = q0 + col;
+                            if (q >= n_out) continue;
+                            const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
+                            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = fmaxf((v[e] + bsv) * scv, lo);
+                                if (do_div) x = x / div;
+                                v[e] = x;
+                            }
+                            float* yp = yb + (int64_t)co * p.y_cs + q;
+                            if (q + 3 < n_out) {
+                                *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (q + e < n_out) yp[e] = v[e];
+                            }
+                        }
+                    }
+                    continue;
+                }
+                if constexpr (!preload) {
 #pragma unroll 2
                 for (int it = 0; it < NR; ++it) {
                     const int r0 = wid * RPI + it * 4 * RPI;
@@ -431,6 +505,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                         }
                     }
                 }
+                }   // !preload
             }
 #ifdef TTS_TIMING
             if (p.timing && threadIdx.x == 0) {
@@ -439,7 +514,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 unsigned long long* tp = p.timing + (size_t)lin * 8;
-                tp[0] = t_start; tp[1] = t_pro; tp[2] = t_main; tp[3] = wall_clock64(); tp[4] = hwid; tp[5] = xcc;
+                tp[0] = t_start; tp[1] = t_pro; tp[2] = t_main; tp[3] = wall_clock64(); tp[4] = hwid; tp[5] = xcc; tp[6] = t_e1; tp[7] = clock64() - c_start;
             }
 #endif
             return;
@@ -544,6 +619,18 @@ static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_
     return 0;
 }
 
+// Block order experiment for ragged batches (TTSAMD_TILE_MAJOR=1; default off).  With the time tile in blockIdx.x every
+// utterance ends in a run of dead blocks (tiles past its length).  On a stand-alone ragged launch whose utterances are
+// 16 % shorter than the padded length on average, the in-order workgroup dispatcher leaves slots empty behind those runs
+// (1.59 resident blocks per CU instead of 1.90, tools/conv_slots.py) and tile-major order (x = utterance slot, z = time
+// tile, utterance = (slot + tile) % batch so that the XCD <-> utterance assignment rotates) recovers +4-5 % there.  On the
+// bench workload (10 % shorter on average) it measures -0.5 % (84.2 vs 83.8 ms per step: neighbouring blocks no longer
+// share their halo columns in L2), so the default stays time-major.
+bool tile_major_order(const ConvParams& p, unsigned n_tiles) {
+    static const int force = [] { const char* e = getenv("TTSAMD_TILE_MAJOR"); return e ? atoi(e) : 0; }();
+    return force != 0 && p.lens_out != nullptr && p.batch > 1 && n_tiles <= 65535;
+}
+
 template <int K, int MT, int NTL, int WM, int WN>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
@@ -553,6 +640,8 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
     ConvParams q = p;
     q.ksplit = 1;
+    q.tile_major = tile_major_order(p, grid.x) ? 1 : 0;
+    if (q.tile_major) std::swap(grid.x, grid.z);
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
     const int n_chunks = p.Cin / G::KC;
     if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < 320 && n_chunks >= 8) {
@@ -570,10 +659,19 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
 #else
     // GELU (Vocos pwconv1, k = 1) and tanh (Tacotron2 postnet, k = 5) are compiled into those kernel sizes only
     TTS_REQUIRE(p.relu_out < 2 || K == 1 || K == 5, "conv: GELU / tanh epilogues are built for kernel sizes 1 and 5 only (K=%d)", K);
-    const int epi = !vec_ok ? 2 : (p.relu_out >= 2 ? 1 : 0);
+    // the residual rides in through the accumulators (EPI 3) unless a per-channel scale sits between conv and residual
+    // (Vocos gamma) or the kernel was built without it
+#ifdef TTS_NO_PRELOAD
+    const bool pre_ok = false;
+#else
+    const bool pre_ok = p.res != nullptr && p.scale == nullptr && p.relu_out < 2 &&
+                        (int64_t)p.Cout * std::max(p.r_cs, p.y_cs) * 4 < ((int64_t)1 << 31);
+#endif
+    const int epi = !vec_ok ? 2 : (p.relu_out >= 2 ? 1 : (pre_ok ? 3 : 0));
 #endif
     int32_t rc;
-    if (epi == 0) rc = launch_epi<K, MT, NTL, WM, WN, 0>(q, grid, lds, stream);
+    if (epi == 3) rc = launch_epi<K, MT, NTL, WM, WN, 3>(q, grid, lds, stream);
+    else if (epi == 0) rc = launch_epi<K, MT, NTL, WM, WN, 0>(q, grid, lds, stream);
     else if (epi == 1) rc = launch_epi<K, MT, NTL, WM, WN, (K == 1 || K == 5) ? 1 : 2>(q, grid, lds, stream);
     else rc = launch_epi<K, MT, NTL, WM, WN, 2>(q, grid, lds, stream);
     if (rc != 0) return rc;
@@ -632,6 +730,11 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     if (p.Nout <= 0) return 0;
     if (p.precision != 0) return launch_conv_bf16_any(p, stream);
     TTS_REQUIRE(!p.x_packed && !p.y_packed, "conv: packed bf16 activations exist only in the bf16 mode");
+#ifdef TTS_ONLY_K   /* kernel experiments: compile one kernel size only (tools/conv_bench, 10 s instead of 90 s) */
+    if (p.K == TTS_ONLY_K) return launch_k<TTS_ONLY_K>(p, stream);
+    set_error("conv: built with TTS_ONLY_K=%d", TTS_ONLY_K);
+    return TTSAMD_EINVAL;
+#else
     switch (p.K) {
         case 1: return launch_k<1>(p, stream);
         case 2: return launch_k<2>(p, stream);
@@ -643,6 +746,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
             set_error("conv: kernel size %d not instantiated (1,2,3,5,7,11)", p.K);
             return TTSAMD_EINVAL;
     }
+#endif
 }
 
 // torch Conv1d weight [Cout][Cin][K] -> [Cin/8][K][2][CoutP][4]:

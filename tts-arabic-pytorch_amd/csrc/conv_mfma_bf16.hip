@@ -50,11 +50,12 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     constexpr int KC = G::KC, WS = G::WS, NXI = G::NXI, NW = G::NW, NGRP = G::NGRP, NSTAGE = G::NSTAGE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int b = blockIdx.z;
+    // ragged batches: tile-major block order (x = utterance slot, z = time tile), see ConvParams::tile_major
+    const int b = p.tile_major ? (int)((blockIdx.x + blockIdx.z) % (unsigned)p.batch) : (int)blockIdx.z;
     const int n_co_tiles = p.CoutP / CO_BLK;
     const int phase = blockIdx.y / n_co_tiles;
     const int co_blk0 = (blockIdx.y % n_co_tiles) * CO_BLK;
-    const int q0 = blockIdx.x * NT_BLK;
+    const int q0 = (p.tile_major ? blockIdx.z : blockIdx.x) * NT_BLK;
 
     int n_out = p.Nout;
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
@@ -469,7 +470,8 @@ static int32_t launch_act_bf16(const ConvParams& p, dim3 grid, size_t lds, hipSt
 }
 
 template <int K, int MT, int NTL, int WM, int WN, int NPL>
-static int32_t launch_cfg_bf16(const ConvParams& p, hipStream_t stream) {
+static int32_t launch_cfg_bf16(const ConvParams& p_in, hipStream_t stream) {
+    ConvParams p = p_in;
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
     using G = GeoB<K, NT_BLK, CO_BLK, NPL>;
     TTS_REQUIRE(p.Cin % G::KC == 0, "conv: Cin=%d must be a multiple of %d for K=%d", p.Cin, G::KC, K);
@@ -481,6 +483,8 @@ static int32_t launch_cfg_bf16(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.relu_out < 2 || HAS_ACT, "conv: GELU / tanh epilogues are built for kernel sizes 1 and 5 only (K=%d)", K);
     const size_t lds = (size_t)G::NSTAGE * G::BUF4 * sizeof(uint2);
     dim3 grid((p.Nout + NT_BLK - 1) / NT_BLK, (p.CoutP / CO_BLK) * p.n_phase, p.batch);
+    p.tile_major = tile_major_order(p, grid.x) ? 1 : 0;
+    if (p.tile_major) std::swap(grid.x, grid.z);
     const bool vec_ok = !p.y_packed && p.y_ts == 1 && p.n_phase == 1 && (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 &&
                         ((uintptr_t)p.y & 15) == 0 &&
                         (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0));

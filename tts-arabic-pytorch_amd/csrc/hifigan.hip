@@ -36,18 +36,20 @@ struct HifiGan {
     mutable hipEvent_t ev_fork = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
 };
 
-// The ResBlocks of one stage are independent until their sum.  When a launch cannot fill the chip for long
-// (batch 1..8: 1-3 rounds of blocks per launch, so up to a third of the chip idles in each launch's tail) they
-// are issued on three streams; only the last conv of each branch, which accumulates into the stage output, is
-// chained j = 0 -> 1 -> 2 by events, so the sum is formed in the reference's order (bit-identical results).
-// Measured gain: +6 % at batch 1, +7 % at 8, +4-5 % at 12-16, +3 % at 24, +2 % at 32.  From 14 000 frames per call on
-// (batch 32 x 448) the branches stay on one stream so that per-launch durations remain meaningful for profiling and
-// for bench.py's roofline line (TTSAMD_HIFIGAN_STREAMS=0/1 forces either schedule).
+// The ResBlocks of one stage are independent until their sum.  A launch is a few rounds of equally long blocks, so up to
+// a third of the chip idles in its tail (stage 1 at batch 32: 3.5 rounds of 200 us blocks; batch 1..8: 1-3 rounds
+// everywhere); the three branches are therefore issued on three streams and fill each other's tails.  Only the last conv
+// of each branch, which accumulates into the stage output, is chained j = 0 -> 1 -> 2 by events, so the sum is formed in
+// the reference's order (bit-identical results, test_hifigan_branch_streams_bit_identical).  Measured gain: +6 % at batch 1,
+// +7 % at 8, +4-5 % at 12-16, +2 % at 32.  Profiling (ttsamd_profile_*) brackets each fork..join section with ONE event
+// pair on the caller's stream -- wall time of the section, never a sum of overlapping launches.
+// TTSAMD_HIFIGAN_STREAMS=0/1 forces either schedule.
 static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
     if (h->cfg.n_kernels != 3) return false;
     const char* env = std::getenv("TTSAMD_HIFIGAN_STREAMS");   // read per call: the tests flip it
     if (env) return env[0] == '1';
-    return (int64_t)B * T < 14000;
+    (void)B; (void)T;
+    return true;
 }
 
 using TensorMap = std::map<std::string, const ttsamd_tensor*>;
@@ -281,6 +283,13 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         bs[2] = h->side[1];
     }
 
+    // any failure below must not leave the side streams running on a workspace the caller is about to recycle
+    struct Join {
+        bool on; hipStream_t a, b;
+        ~Join() { if (on) { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); } }
+    } join{false, bs[1], bs[2]};
+    const auto fail = [&](int32_t rc) { join.on = multi && rc != 0; return rc; };
+
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.batch = B;
@@ -291,6 +300,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     // (ConvParams::y_packed / x_packed; same rounding point as the fp32 buffer + round-on-load, bit-identical)
     const char* pk_env = std::getenv("TTSAMD_BF16_PACKED_T");
     const bool pack_t = default_precision() == 1 && !(pk_env && pk_env[0] == '0');
+    bool in_section = false;   // inside a multi-stream fork..join section (profiling brackets the section)
     int pack_io = 0;   // bit 0: x is packed, bit 1: write y packed (set around the c1 / c2 launches below)
     auto conv = [&](const ConvW& cw, const float* x, hipStream_t st, float* y, const float* res, int L, int mul,
                     int dil, float slope, int mode, float div) -> int32_t {
@@ -305,14 +315,18 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         p.n_phase = 1; p.phase_p = 0;
         p.in_slope = slope; p.relu_out = 0; p.mode = mode; p.div = div;
         p.x_packed = (pack_io & 1) ? 1 : 0; p.y_packed = (pack_io & 2) ? 1 : 0; p.pack_slope = 0.1f;
-        prof_begin(st, 2.0 * cw.cout * cw.cin * cw.k * mul);
+        // in the three-stream schedule the whole fork..join section is bracketed once (below): per-launch spans overlap
+        if (in_section) prof_add(2.0 * cw.cout * cw.cin * cw.k * mul);
+        else prof_begin(st, 2.0 * cw.cout * cw.cin * cw.k * mul);
         const int32_t rc = launch_conv(p, st);
-        prof_end(st);
+        if (!in_section) prof_end(st);
         return rc;
     };
 
+#define HG_TRY(expr) do { int32_t rc_ = (expr); if (rc_ != 0) return fail(rc_); } while (0)
+#define HG_CHECK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return fail(TTSAMD_EHIP); } } while (0)
     // conv_pre (models.py:112)
-    TTS_TRY(conv(h->conv_pre, mel, s, cur, nullptr, T, 1, 1, 1.0f, 0, 1.f));
+    HG_TRY(conv(h->conv_pre, mel, s, cur, nullptr, T, 1, 1, 1.0f, 0, 1.f));
     int L = T, mul = 1;
     for (int i = 0; i < cfg.n_ups; ++i) {
         const int u = cfg.upsample_rates[i], kt = cfg.upsample_kernel_sizes[i];
@@ -331,44 +345,54 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         prof_begin(s, 2.0 * uw.cout * uw.cin * 2 * u * mul);
         int32_t rc = launch_conv(p, s);
         prof_end(s);
-        TTS_TRY(rc);
+        HG_TRY(rc);
         L *= u; mul *= u;
         // 3 ResBlock1 on the same input, averaged (models.py:116-122, 46-53)
-        if (multi) TTS_CHECK_HIP(hipEventRecord(h->ev_fork, s));
+        if (multi) {
+            prof_section_begin(s);
+            in_section = true;
+            HG_CHECK_HIP(hipEventRecord(h->ev_fork, s));
+        }
         for (int j = 0; j < cfg.n_kernels; ++j) {
             hipStream_t st = bs[j % 3];
             float *Tb = Tbs[j % 3], *R = Rs[j % 3];
             p.splitk_ws = splitks[j % 3];
-            if (multi && j > 0) TTS_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
+            if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
             const float* src = ups_out;
             for (int m = 0; m < cfg.n_dilations; ++m) {
                 const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
                 const int d = cfg.resblock_dilations[j][m];
                 pack_io = pack_t ? 2 : 0;
-                TTS_TRY(conv(h->c1[li], src, st, Tb, nullptr, L, mul, d, 0.1f, 0, 1.f));
+                HG_TRY(conv(h->c1[li], src, st, Tb, nullptr, L, mul, d, 0.1f, 0, 1.f));
                 pack_io = pack_t ? 1 : 0;
                 if (m + 1 < cfg.n_dilations) {
-                    TTS_TRY(conv(h->c2[li], Tb, st, R, src, L, mul, 1, 0.1f, 0, 1.f));
+                    HG_TRY(conv(h->c2[li], Tb, st, R, src, L, mul, 1, 0.1f, 0, 1.f));
                     pack_io = 0;
                     src = R;
                 } else {
                     const int mode = (j == 0) ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2);
                     const int md = cfg.n_kernels == 1 ? 0 : mode;
                     // the accumulation into `cur` follows branch j-1's
-                    if (multi && j > 0) TTS_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
-                    TTS_TRY(conv(h->c2[li], Tb, st, cur, src, L, mul, 1, 0.1f, md, (float)cfg.n_kernels));
+                    if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
+                    HG_TRY(conv(h->c2[li], Tb, st, cur, src, L, mul, 1, 0.1f, md, (float)cfg.n_kernels));
                     pack_io = 0;
-                    if (multi) TTS_CHECK_HIP(hipEventRecord(h->ev_done[j], st));
+                    if (multi) HG_CHECK_HIP(hipEventRecord(h->ev_done[j], st));
                 }
             }
         }
         p.splitk_ws = splitks[0];
-        if (multi) TTS_CHECK_HIP(hipStreamWaitEvent(s, h->ev_done[cfg.n_kernels - 1], 0));
+        if (multi) {
+            HG_CHECK_HIP(hipStreamWaitEvent(s, h->ev_done[cfg.n_kernels - 1], 0));
+            in_section = false;
+            prof_section_end(s);
+        }
     }
     // leaky_relu (default slope 0.01) + conv_post + tanh (models.py:123-125)
-    TTS_TRY(launch_conv_post(cur, (int64_t)h->conv_post.cin * L, L, h->dev + h->conv_post.w_off,
+    HG_TRY(launch_conv_post(cur, (int64_t)h->conv_post.cin * L, L, h->dev + h->conv_post.w_off,
                              h->dev + h->conv_post.b_off, lens, mul, B, h->conv_post.cin, L, 0.01f, wave,
                              (int64_t)L, s));
+#undef HG_TRY
+#undef HG_CHECK_HIP
     return 0;
 }
 

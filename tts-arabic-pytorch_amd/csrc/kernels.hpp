@@ -64,5 +64,9 @@ int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* fram
 // Profiling of conv launches (bench roofline)
 void prof_begin(hipStream_t s, double flops);
 void prof_end(hipStream_t s);
+// fork..join sections of concurrent launches: ONE event pair on the forking stream + per-launch counting
+void prof_section_begin(hipStream_t s);
+void prof_section_end(hipStream_t s);
+void prof_add(double flops);
 
 }  // namespace ttsamd
