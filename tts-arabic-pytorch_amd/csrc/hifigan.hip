@@ -300,6 +300,8 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     // (ConvParams::y_packed / x_packed; same rounding point as the fp32 buffer + round-on-load, bit-identical)
     const char* pk_env = std::getenv("TTSAMD_BF16_PACKED_T");
     const bool pack_t = default_precision() == 1 && !(pk_env && pk_env[0] == '0');
+    const char* fz_env = std::getenv("TTSAMD_FUSED_PAIR");
+    const bool fused_ok = default_precision() == 0 && !(fz_env && fz_env[0] == '0');
     bool in_section = false;   // inside a multi-stream fork..join section (profiling brackets the section)
     int pack_io = 0;   // bit 0: x is packed, bit 1: write y packed (set around the c1 / c2 launches below)
     auto conv = [&](const ConvW& cw, const float* x, hipStream_t st, float* y, const float* res, int L, int mul,
@@ -362,6 +364,28 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
             for (int m = 0; m < cfg.n_dilations; ++m) {
                 const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
                 const int d = cfg.resblock_dilations[j][m];
+                // C = 32 stage, fp32: the c1 -> c2 pair in one launch with the intermediate in LDS (resblock_fused.hip);
+                // x and y must differ (halo reads), so the pair outputs alternate between R and the unused c1 buffer
+                {
+                    const bool last = m + 1 == cfg.n_dilations;
+                    float* dst = last ? cur : (src == R ? Tb : R);
+                    const ConvW &w1 = h->c1[li], &w2 = h->c2[li];
+                    if (fused_ok && w1.cin == 32 && w1.cout == 32 && w2.cin == 32 && w2.cout == 32 && w1.k == w2.k &&
+                        fused_pair_supported(32, w1.k, d, L, src, dst)) {
+                        const int mode = !last ? 0 : (cfg.n_kernels == 1 ? 0 : (j == 0 ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2)));
+                        if (multi && last && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
+                        const double fl = 2.0 * (2.0 * 32 * 32 * w1.k) * mul;
+                        if (in_section) prof_add(fl); else prof_begin(st, fl);
+                        const int32_t frc = launch_fused_pair_c32(src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
+                                                                  h->dev + w2.b_off, w1.k, d, lens, mul, L, B, mode,
+                                                                  (float)cfg.n_kernels, 0.1f, st);
+                        if (!in_section) prof_end(st);
+                        HG_TRY(frc);
+                        if (multi && last) HG_CHECK_HIP(hipEventRecord(h->ev_done[j], st));
+                        src = dst;
+                        continue;
+                    }
+                }
                 pack_io = pack_t ? 2 : 0;
                 HG_TRY(conv(h->c1[li], src, st, Tb, nullptr, L, mul, d, 0.1f, 0, 1.f));
                 pack_io = pack_t ? 1 : 0;
