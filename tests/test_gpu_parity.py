@@ -595,3 +595,52 @@ def test_bf16_packed_intermediate_bit_identical(dev, precision, hifigan_engine, 
         monkeypatch.setenv('TTSAMD_BF16_PACKED_T', '1')
         out = hifigan_engine.forward(mel, lens)
         assert torch.equal(out, ref), (B, T, float((out - ref).abs().max()))
+
+
+# ---------------------------------------------------------------------------------------
+# error behaviour at the edges the reference raises on: indices, tiny utterances
+# ---------------------------------------------------------------------------------------
+def test_out_of_range_ids_raise_like_nn_embedding(dev, checkpoints):
+    from models.fastpitch import FastPitch
+    model = FastPitch(checkpoints[0]).to(dev)
+    n = model.net_config['n_symbols']
+    with pytest.raises(IndexError):
+        model.infer(torch.tensor([[1, 2, n]]))
+    with pytest.raises(IndexError):
+        model.infer(torch.tensor([[1, -1, 2]]))
+    mel, dec_lens, *_ = model.infer(torch.tensor([[1, 2, n - 1]]))          # the last valid id is fine
+    assert mel.shape[0] == 1 and int(dec_lens[0]) == mel.shape[2]
+
+
+def test_negative_forced_durations_give_zero_repeats(dev, fastpitch_engine):
+    ids = torch.tensor([[3, 4, 5, 6]])
+    dur = torch.tensor([[2.0, -3.0, 1.0, -0.2]])
+    mel, dec_lens, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
+    assert int(dec_lens[0]) == 3 and mel.shape[2] == 3 and bool(torch.isfinite(mel).all())
+
+
+def test_denoiser_rejects_utterances_of_at_most_512_samples(dev, hifigan_engine):
+    """torch's reflect pad (Spectrogram(center=True), denoiser.py:43-48) raises when n <= n_fft/2; the ragged batch
+    path must not read outside the row instead (2 mel frames = 512 samples next to a normal utterance)."""
+    from vocoder.hifigan.denoiser import Denoiser
+    from vocoder.hifigan.models import Generator
+    from ttsamd.engine import DenoiserEngine
+    eng = DenoiserEngine(device=dev)
+    wave = torch.randn(2, 4096, device=dev) * 0.1
+    ns = torch.tensor([4096, 512], device=dev)
+    bias = torch.rand(513, device=dev) * 0.01
+    ref = wave.clone()
+    out = eng.denoise(wave.clone(), ns, bias, 0.1)                          # engine level: memory-safe, finite
+    assert bool(torch.isfinite(out).all()) and torch.equal(out[1, 512:], ref[1, 512:])
+    solo = eng.denoise(ref[:1].clone(), ns[:1], bias, 0.1)
+    assert torch.equal(out[0], solo[0])                                     # the short neighbour does not leak into row 0
+
+    class _Voc:                                                             # wrapper level: raises like the reference
+        device = dev
+
+        def __call__(self, mel):
+            return hifigan_engine.forward(mel)
+    den = Denoiser.__new__(Denoiser)
+    torch.nn.Module.__init__(den)
+    with pytest.raises(ValueError):
+        Denoiser.forward_batch(den, wave.clone(), ns, 0.1)

@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restric
         int i = t * HOP + k - NFFT / 2;
         if (i < 0) i = -i;
         if (i >= n) i = 2 * (n - 1) - i;
-        v = wave[(int64_t)b * wave_bs + i];
+        // n <= NFFT/2 (an utterance of 0-2 frames) would reflect past the other end: torch's reflect pad raises there and
+        // so do the Python wrappers; here the index is only kept inside the row
+        i = min(max(i, 0), max(n - 1, 0));
+        v = n > 0 ? wave[(int64_t)b * wave_bs + i] : 0.f;
     }
     X[((int64_t)b * NFFT + k) * F + t] = v;
 }

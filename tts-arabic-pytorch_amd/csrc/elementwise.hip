@@ -224,7 +224,7 @@ int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const 
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids,
                                                     const float* __restrict__ word_emb,
                                                     const float* __restrict__ pos, int pos_stride,
-                                                    const float* __restrict__ spk, int pad_idx, int L, int C,
+                                                    const float* __restrict__ spk, int pad_idx, int n_symbols, int L, int C,
                                                     float* __restrict__ x, int64_t* __restrict__ lens) {
     const int b = blockIdx.y;
     const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
     if (t >= L) return;
     const int64_t id = idb[t];
     const float m = (id != pad_idx) ? 1.f : 0.f;
-    const float* er = word_emb + id * C;
+    // out-of-range ids never leave the table (the host-side wrappers raise IndexError as nn.Embedding does)
+    const float* er = word_emb + min(max(id, (int64_t)0), (int64_t)n_symbols - 1) * C;
     float* xb = x + (int64_t)b * C * L;
     for (int c = g + 4 * blockIdx.z; c < C; c += 4 * gridDim.z) {
         float v = er[c] + pos[(int64_t)c * pos_stride + t] * m;
@@ -249,9 +250,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 }
 
 int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos_table, int32_t pos_stride,
-                     const float* spk, int32_t pad_idx, int32_t B, int32_t L, int32_t C, float* x, int64_t* lens, hipStream_t s) {
+                     const float* spk, int32_t pad_idx, int32_t n_symbols, int32_t B, int32_t L, int32_t C, float* x, int64_t* lens, hipStream_t s) {
     dim3 grid((L + 63) / 64, B, 8);     // z: channel slices (the kernel is latency-bound at one block per utterance)
-    hipLaunchKernelGGL(embed_kernel, grid, dim3(256), 0, s, ids, word_emb, pos_table, pos_stride, spk, pad_idx, L,
+    hipLaunchKernelGGL(embed_kernel, grid, dim3(256), 0, s, ids, word_emb, pos_table, pos_stride, spk, pad_idx, n_symbols, L,
                        C, x, lens);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
@@ -481,7 +482,8 @@ __global__ __launch_bounds__(64) void durations_to_reps_kernel(const float* __re
     long long tot = 0;
     for (int i = lane; i < L; i += 64) {
         const float r = dur[(int64_t)b * L + i] / pace + 0.5f;   // fp32, as durations.float()/pace + 0.5
-        const long long n = (long long)r;                        // .long(): truncation toward zero
+        const long long n = max((long long)r, 0ll);              // .long(): truncation toward zero; negative dur_tgt -> 0 repeats
+                                                                 // (the reference's cumsum/one-hot would misbehave; the scan needs >= 0)
         reps[(int64_t)b * L + i] = n;
         tot += n;
     }

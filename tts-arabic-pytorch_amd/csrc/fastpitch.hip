@@ -338,7 +338,7 @@ int32_t fastpitch_encode(const FastPitch* h, const int64_t* ids, int32_t B, int3
     SplitKScope splitk(w.f.splitk);
     float* x = enc_cond;
     const float* spk = (c.n_speakers > 1 && h->spk_emb >= 0) ? h->dev + h->spk_emb + (int64_t)speaker * d : nullptr;
-    TTS_TRY(launch_embed(ids, h->dev + h->word_emb, h->dev + h->pos_enc, h->pos_cap, spk, c.padding_idx, B, L, d, x,
+    TTS_TRY(launch_embed(ids, h->dev + h->word_emb, h->dev + h->pos_enc, h->pos_cap, spk, c.padding_idx, c.n_symbols, B, L, d, x,
                          w.lens, s));
     TTS_TRY(run_fft(h, h->enc, c.in_fft_d_head, x, w.lens, B, L, w.f, s));
     // durations (model.py:367-368)

@@ -22,7 +22,8 @@ int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const 
 // Encoder input: x[b][c][t] = word_emb[ids[b][t]][c] + pos[t][c]*(ids!=pad) + spk[c]
 // (transformer.py:212-219; model.py:355-361).  Also writes lens[b] = #non-pad tokens.
 int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos_table, int32_t pos_stride,
-                     const float* spk, int32_t pad_idx, int32_t B, int32_t L, int32_t C, float* x, int64_t* lens, hipStream_t s);
+                     const float* spk, int32_t pad_idx, int32_t n_symbols, int32_t B, int32_t L, int32_t C, float* x, int64_t* lens,
+                     hipStream_t s);
 
 // 1-head self attention over channel-first q,k,v = rows [0,D),[D,2D),[2D,3D) of qkv [B][3D][S]
 // (transformer.py:131-141): out[b][d][i] = sum_j softmax_j(q_i.k_j * scale | j < lens[b]) v_j[d]

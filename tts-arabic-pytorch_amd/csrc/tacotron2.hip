@@ -238,11 +238,11 @@ void tacotron2_destroy(Taco2* h) {
 // ------------------------------------------------------------------------------------ kernels
 
 __global__ __launch_bounds__(256) void taco_embed_kernel(const int64_t* __restrict__ tok, const float* __restrict__ emb,
-                                                         int E, int L, float* __restrict__ x) {
+                                                         int n_symbol, int E, int L, float* __restrict__ x) {
     const int b = blockIdx.y, tl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + tl;
     if (t >= L) return;
-    const float* er = emb + tok[(int64_t)b * L + t] * E;
+    const float* er = emb + min(max(tok[(int64_t)b * L + t], (int64_t)0), (int64_t)n_symbol - 1) * E;   // clamped: memory safety
     for (int c = g; c < E; c += 4) x[((int64_t)b * E + c) * L + t] = er[c];
 }
 
@@ -285,9 +285,9 @@ __global__ __launch_bounds__(256) void taco_bilstm_kernel(const float* __restric
 }
 
 __global__ void taco_spk_kernel(float* __restrict__ memory, const float* __restrict__ spk, const int64_t* __restrict__ sids,
-                                int L, int M, int E, int S) {
+                                int n_spk, int L, int M, int E, int S) {
     const int b = blockIdx.y, t = blockIdx.x, j = threadIdx.x;
-    if (j < S) memory[((int64_t)b * L + t) * M + E + j] = spk[sids[b] * S + j];
+    if (j < S) memory[((int64_t)b * L + t) * M + E + j] = spk[min(max(sids[b], (int64_t)0), (int64_t)n_spk - 1) * S + j];
 }
 
 // pm[b][t][h] = sum_m memory[b][t][m] * wmT[m][h]      (attention memory_layer, no bias)
@@ -727,7 +727,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     const int E = c.encoder_embedding_dim, M = h->mem_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, P = c.prenet_dim;
     const float* W = h->dev;
     // ---- encoder
-    hipLaunchKernelGGL(taco_embed_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, tokens, W + h->emb, E, L, w.x0);
+    hipLaunchKernelGGL(taco_embed_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, tokens, W + h->emb, h->cfg.n_symbol, E, L, w.x0);
     TTS_CHECK_HIP(hipGetLastError());
     float *cur = w.x0, *nxt = w.x1;
     for (const TConv& cv : h->enc_convs) {
@@ -739,8 +739,8 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     hipLaunchKernelGGL(taco_bilstm_kernel, dim3(B, 2), dim3(256), 0, s, w.xproj, W + h->enc_whhT[0], W + h->enc_whhT[1],
                        lengths, L, M, w.memory);
     if (c.num_speakers > 1)
-        hipLaunchKernelGGL(taco_spk_kernel, dim3(L, B), dim3(128), 0, s, w.memory, W + h->spk, speaker_ids, L, M, E,
-                           c.speaker_embedding_dim);
+        hipLaunchKernelGGL(taco_spk_kernel, dim3(L, B), dim3(128), 0, s, w.memory, W + h->spk, speaker_ids, c.num_speakers, L, M,
+                           E, c.speaker_embedding_dim);
     hipLaunchKernelGGL(taco_pm_kernel, dim3(L, B), dim3(128), 0, s, w.memory, W + h->wmT, L, M, w.pm);
     TTS_CHECK_HIP(hipGetLastError());
     // ---- decoder state

@@ -80,6 +80,10 @@ class FastPitch(_HipModule):
     def infer(self, inputs, pace=1.0, dur_tgt=None, pitch_tgt=None, energy_tgt=None, pitch_transform=None,
               max_duration=75, speaker=0):
         ids = torch.as_tensor(inputs).long()
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.net_config['n_symbols']):
+            raise IndexError(f'token id out of range [0, {self.net_config["n_symbols"]}) (nn.Embedding raises here too)')
+        if self.net_config['n_speakers'] > 1 and not 0 <= int(speaker) < self.net_config['n_speakers']:
+            raise IndexError(f'speaker {speaker} out of range [0, {self.net_config["n_speakers"]})')
         nz = (ids != self.net_config['padding_idx'])
         lens = nz.sum(1)
         if not bool((nz == (torch.arange(ids.shape[1], device=ids.device)[None] < lens[:, None])).all()):

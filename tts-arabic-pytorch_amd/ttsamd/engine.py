@@ -50,6 +50,15 @@ def _f32(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _check_ids(t, n, what):
+    """nn.Embedding raises IndexError on an out-of-range index; the HIP gathers only clamp.  Checked where it is free:
+    on tensors that still live on the host (the drop-in wrappers tokenise on the CPU)."""
+    if isinstance(t, torch.Tensor) and t.device.type == 'cpu' and t.numel():
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= n:
+            raise IndexError(f'{what}: index out of range [0, {n}) (got min {lo}, max {hi})')
+
+
 class _Workspace:
     def __init__(self):
         self.buf = None
@@ -321,6 +330,9 @@ class Tacotron2Engine:
     def infer(self, tokens, speaker_ids=None, lengths=None, max_step=None, dropout_seed=-1):
         """tokens int64 [B,L] -> (mel_postnet [B,80,T], mel_lens int32 [B], alignments [B,T,L]);
         dropout_seed None draws a fresh seed per call (the reference's always-on prenet dropout)."""
+        _check_ids(tokens, self.config['n_symbol'], 'Tacotron2 tokens')
+        if speaker_ids is not None and self.config['num_speakers'] > 1:
+            _check_ids(speaker_ids, self.config['num_speakers'], 'Tacotron2 speaker_ids')
         tokens = tokens.to(device=self.device, dtype=torch.int64).contiguous()
         B, Ltok = tokens.shape
         if lengths is None:
@@ -369,6 +381,7 @@ class TaggerEngine:
             cfg.dense_dim[i] = v
         cfg.hard_sigmoid, cfg.bn_after_lstm0, cfg.bn_eps = c['hard_sigmoid'], c['bn_after_lstm0'], c['bn_eps']
         self.n_classes = c['dense_dim'][-1]
+        self.n_vocab = c['n_vocab']
         arr, keep = L.make_tensors({self.RENAME.get(k, k): v for k, v in state_dict.items()})
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -383,7 +396,9 @@ class TaggerEngine:
 
     def forward(self, ids):
         """ids int64 [B, T] -> probs [B, T, n_classes] on the device"""
-        ids = torch.as_tensor(ids).to(device=self.device, dtype=torch.int64).contiguous()
+        ids = torch.as_tensor(ids)
+        _check_ids(ids, self.n_vocab, 'tagger ids')
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
         B, T = ids.shape
         probs = torch.empty(B, T, self.n_classes, dtype=torch.float32, device=self.device)
         if T == 0:

@@ -47,5 +47,9 @@ class Denoiser(_HipModule):
     @torch.inference_mode()
     def forward_batch(self, wave, nsamples, strength):
         """Ragged batch (extension): wave [B, n_max] float32 on the GPU, nsamples int64 [B]."""
+        if wave.shape[0] and int(nsamples.min()) <= 512:
+            # the reference's Spectrogram(center=True, pad_mode='reflect') needs more than n_fft/2 samples and raises
+            raise ValueError('Denoiser: every utterance needs more than 512 samples (reflect padding of n_fft/2); '
+                             f'shortest has {int(nsamples.min())}')
         eng = self._engine(lambda d: DenoiserEngine(device=d))
         return eng.denoise(wave.contiguous(), nsamples, self._bias_spec(wave.device), strength)
