@@ -101,6 +101,8 @@ struct ConvParams {
 };
 constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)
 
+void conv_log(const char* kind, int K, int cin, int cout, int nout, int batch, int has_res, int mode, int len_mul, int ragged,
+              int n_phase);
 // block order of a launch (conv_mfma.hip)
 bool tile_major_order(const ConvParams& p, unsigned n_tiles);
 // Launches the kernel; returns 0 or a negative code.

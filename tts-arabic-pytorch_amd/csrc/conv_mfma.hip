@@ -30,6 +30,7 @@
 //    the LDS write; bias / residual / ReLU / ResBlock sum and /3 are fused in the epilogue.
 // Ragged batches: positions >= lens_in[b] read as zero at the INPUT of every layer
 // (SURVEY.md §3.4-5), tiles past lens_out[b] exit early.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -723,11 +724,23 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
     return launch_cfg<K, 1, 1, 1, 4>(p, stream);                                                        //  32 co x 128 t
 }
 
+// TTSAMD_CONV_LOG=<file>: one CSV line per conv launch, in launch order (= rocprofv3 dispatch order), so that
+// profiles/traffic_from_pmc.py can put the algorithmic HBM bytes of each launch next to the measured ones.
+void conv_log(const char* kind, int K, int cin, int cout, int nout, int batch, int has_res, int mode, int len_mul, int ragged,
+              int n_phase) {
+    static FILE* f = [] { const char* e = getenv("TTSAMD_CONV_LOG"); return e ? fopen(e, "a") : (FILE*)nullptr; }();
+    if (!f) return;
+    fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d\n", kind, K, cin, cout, nout, batch, has_res, mode, len_mul, ragged, n_phase);
+    fflush(f);
+}
+
 int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.CoutP % 32 == 0 && p.CoutP >= p.Cout, "conv: bad CoutP=%d", p.CoutP);
     TTS_REQUIRE(p.n_phase >= 1 && p.batch >= 1, "conv: bad n_phase/batch");
     TTS_REQUIRE(p.dil >= -DMAX && p.dil <= DMAX && p.dil != 0, "conv: dilation %d outside [-%d,%d]", p.dil, DMAX, DMAX);
     if (p.Nout <= 0) return 0;
+    conv_log(p.precision == 0 ? "f32" : "bf16", p.K, p.Cin, p.Cout, p.Nout, p.batch, p.res != nullptr, p.mode, p.len_out_mul,
+             p.lens_out != nullptr, p.n_phase);
     if (p.precision != 0) return launch_conv_bf16_any(p, stream);
     TTS_REQUIRE(!p.x_packed && !p.y_packed, "conv: packed bf16 activations exist only in the bf16 mode");
 #ifdef TTS_ONLY_K   /* kernel experiments: compile one kernel size only (tools/conv_bench, 10 s instead of 90 s) */

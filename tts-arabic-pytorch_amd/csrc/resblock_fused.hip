@@ -315,6 +315,7 @@ int32_t launch_fused_pair_c32(const float* x, float* y, const float* w1, const f
                               int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
                               int32_t mode, float div, float slope, hipStream_t stream) {
     TTS_REQUIRE(fused_pair_supported(32, k, dil, L, x, y), "fused ResBlock pair: unsupported geometry (k=%d, dil=%d, L=%d)", k, dil, L);
+    conv_log("fused_pair", k, 32, 32, L, batch, 1, mode, len_mul, lens != nullptr, 1);
     FusedPairParams p;
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.y = y;
