@@ -107,6 +107,9 @@ void conv_log(const char* kind, int K, int cin, int cout, int nout, int batch, i
 bool tile_major_order(const ConvParams& p, unsigned n_tiles);
 // Launches the kernel; returns 0 or a negative code.
 int32_t launch_conv(const ConvParams& p, hipStream_t stream);
+// ConvTranspose1d with all output phases per wave (convt_mfma.hip): takes the polyphase ConvParams of the generic engine
+bool convt_supported(const ConvParams& p);
+int32_t launch_convt(const ConvParams& p, hipStream_t stream);
 // One launch for a c1 -> c2 pair of a C = 32 ResBlock1 with the intermediate in LDS (resblock_fused.hip); x != y.
 bool fused_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y);
 int32_t launch_fused_pair_c32(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -302,6 +302,8 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     const bool pack_t = default_precision() == 1 && !(pk_env && pk_env[0] == '0');
     const char* fz_env = std::getenv("TTSAMD_FUSED_PAIR");
     const bool fused_ok = default_precision() == 0 && !(fz_env && fz_env[0] == '0');
+    const char* ct_env = std::getenv("TTSAMD_CONVT");
+    const bool convt_ok = !(ct_env && ct_env[0] == '0');   // all-phases-per-wave transposed conv (convt_mfma.hip)
     bool in_section = false;   // inside a multi-stream fork..join section (profiling brackets the section)
     int pack_io = 0;   // bit 0: x is packed, bit 1: write y packed (set around the c1 / c2 launches below)
     auto conv = [&](const ConvW& cw, const float* x, hipStream_t st, float* y, const float* res, int L, int mul,
@@ -345,7 +347,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         p.in_slope = 0.1f; p.relu_out = 0; p.mode = 0; p.div = 1.f;
         p.x_packed = 0; p.y_packed = 0;
         prof_begin(s, 2.0 * uw.cout * uw.cin * 2 * u * mul);
-        int32_t rc = launch_conv(p, s);
+        int32_t rc = (convt_ok && convt_supported(p)) ? launch_convt(p, s) : launch_conv(p, s);
         prof_end(s);
         HG_TRY(rc);
         L *= u; mul *= u;
