@@ -12,14 +12,15 @@ python3 bench.py > $O/final_bench_line.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-small > $O/stats.log 2>&1
 # one-stream schedule: per-launch durations that do not overlap (per-instantiation TFLOP/s table)
 TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-small > $O/stats1.log 2>&1
+# (the PMC passes below run the one-stream schedule: dispatch order = the library's launch log order)
 # counter calibration: every kernel of tools/bin/traffic_calib moves exactly 1 GiB
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -- tools/bin/traffic_calib > $O/cal.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_write -- tools/bin/traffic_calib >> $O/cal.log 2>&1
 python3 profiles/traffic_calib.py $O/cal_fetch $O/cal_write > $O/traffic_calib.json
 rm -f $O/conv_log.csv
-TTSAMD_CONV_LOG=$O/conv_log.csv rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small > $O/pmc_mfma.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 TTSAMD_CONV_LOG=$O/conv_log.csv rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small > $O/pmc_fetch.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small > $O/pmc_write.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small > $O/pmc_mfma.log 2>&1
 FRAMES=$(python3 -c "import json;print(json.load(open('$O/final_bench_line.json'))['config']['frames_per_step_rank0'])")
 python3 profiles/traffic_from_pmc.py $O/pmc_fetch $O/pmc_write $O/conv_log.csv $FRAMES $O/traffic_calib.json > $O/traffic.json
 for p in bf16x3 bf16; do python3 bench.py --precision $p --no-cpu-baseline --no-small > $O/${p}_bench_line.json 2>> $O/bench.err; done
