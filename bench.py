@@ -234,6 +234,23 @@ def main():
     step = make_step(ids, dur)
     sync = torch.cuda.synchronize
     barrier = dist.barrier if world > 1 else None
+    if world > 1 and transport == 'rccl':
+        # first DP step under guard: if the C-ABI RCCL exchange raises on ANY rank, every rank switches to the same
+        # exchanges through torch.distributed (same wire) instead of failing the run; the line reports which one ran
+        try:
+            step()
+            sync()
+            ok = 1
+        except Exception as e:                                   # noqa: BLE001
+            print(f'bench.py rank {rank}: ttsamd_dp_* step failed ({e}); falling back to torch.distributed', file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            dpx.close()
+            transport = 'torch'
+            dpx = dp.Dp(dev, transport=transport)
+            step = make_step(ids, dur)
     for _ in range(args.warmup):
         step()
     sync()

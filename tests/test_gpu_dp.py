@@ -78,7 +78,18 @@ assert al.tolist() == [[2, 9 * 256, 5 * 256, 0]]
 for _ in range(2):
     views = dpx.gather_audio(w0, n, all_lens=al)
     assert len(views) == 2 and torch.equal(views[0], w0[0, :9 * 256]) and torch.equal(views[1], w0[1, :5 * 256])
-dpx.close(); dist.destroy_process_group()
+dpx.close()
+# the same exchanges through torch.distributed's RCCL (dist.broadcast / all_gather_into_tensor / gather): bench.py's fallback
+dpt = dp.Dp(dev, transport='torch')
+assert dpt.transport == 'torch' and not dpt.host_staged
+sd = dpt.broadcast_state_dict({'a': np.arange(6, dtype=np.float32).reshape(2, 3)})
+assert sd['a'].tolist() == [[0, 1, 2], [3, 4, 5]]
+al2 = dpt.exchange_lens(n, b_cap=3)
+assert al2.tolist() == al.tolist()
+for _ in range(2):
+    views = dpt.gather_audio(w0, n, all_lens=al2)
+    assert len(views) == 2 and torch.equal(views[0], w0[0, :9 * 256]) and torch.equal(views[1], w0[1, :5 * 256])
+dist.destroy_process_group()
 print('RCCL1 OK')
 ''' % REPO
     p = subprocess.run([sys.executable, '-c', code], capture_output=True, timeout=600,

@@ -239,12 +239,33 @@ class Dp:
         return list(torch.split(flat, sizes)) if sizes else []
 
     def _gather_torch(self, packed, recv, counts, offsets, dst):
-        """The fan-in with torch.distributed point-to-point ops (nccl: device buffers; gloo: host staging)."""
-        mine = int(counts[self.rank])
+        """The fan-in through torch.distributed.  nccl: ONE `dist.gather` of equal-size slots (the longest rank's count;
+        a persistent padded send buffer) — the most travelled primitive of the backend, then a device-side compaction on
+        the root; gloo (CPU tests, one-device debug mode): point-to-point isend / irecv of the exact counts, staged
+        through pinned host buffers when the tensors live on the GPU."""
+        mine, total = int(counts[self.rank]), int(counts.sum())
+        if self.backend == 'nccl':
+            cap = max(int(counts.max()), 1)
+            if not hasattr(self, '_slot_send'):
+                self._slot_send = _Grow(torch.float32, self.device)
+                self._slot_recv = _Grow(torch.float32, self.device)
+            send = self._slot_send.get(cap)
+            send[:mine].copy_(packed[:mine])
+            slots = None
+            if self.rank == dst:
+                flat = self._slot_recv.get(cap * self.world)
+                slots = [flat[r * cap:(r + 1) * cap] for r in range(self.world)]
+            dist.gather(send, slots, dst=dst)
+            if self.rank == dst:
+                for r in range(self.world):
+                    c = int(counts[r])
+                    if c:
+                        recv[int(offsets[r]):int(offsets[r]) + c].copy_(slots[r][:c])
+            return
         if self.host_staged:
             send = self._stage_send.get(max(mine, 1))[:mine]
             send.copy_(packed)
-            rbuf = self._stage_recv.get(max(int(counts.sum()), 1)) if self.rank == dst else None
+            rbuf = self._stage_recv.get(max(total, 1)) if self.rank == dst else None
         else:
             send, rbuf = packed, recv
         if self.rank == dst:
@@ -254,7 +275,7 @@ class Dp:
             for q in reqs:
                 q.wait()
             if self.host_staged:
-                recv[:int(counts.sum())].copy_(rbuf[:int(counts.sum())])
+                recv[:total].copy_(rbuf[:total])
         elif mine > 0:
             dist.send(send, dst=dst)
 
