@@ -644,3 +644,28 @@ def test_denoiser_rejects_utterances_of_at_most_512_samples(dev, hifigan_engine)
     torch.nn.Module.__init__(den)
     with pytest.raises(ValueError):
         Denoiser.forward_batch(den, wave.clone(), ns, 0.1)
+
+
+def test_fused_pair_and_all_phase_convt_match_the_generic_engine(dev, synth_weights, hifigan_engine, monkeypatch):
+    """Round-2 kernels against the generic MFMA conv engine they replace, same weights, ragged batch with a 1-frame and a
+    2-tile utterance: `resblock_pair_c32` (c1 -> c2 of the C = 32 stage in one launch, intermediate in LDS, halo recompute)
+    and `convt_mfma_f32` (all output phases of a transposed conv per wave).  Only the summation order differs (bias first,
+    residual in the accumulator), so the waves agree far inside the waveform tolerance; each schedule is bit-reproducible."""
+    rng = np.random.default_rng(21)
+    lens = torch.tensor([41, 1, 17, 2]).to(dev)
+    mel = torch.from_numpy((rng.standard_normal((4, 80, 41)) * 1.5 - 4.0).astype(np.float32)).to(dev)
+    monkeypatch.setenv('TTSAMD_FUSED_PAIR', '0')
+    monkeypatch.setenv('TTSAMD_CONVT', '0')
+    ref = hifigan_engine.forward(mel, lens).clone()
+    for fused, convt in (('1', '0'), ('0', '1'), ('1', '1')):
+        monkeypatch.setenv('TTSAMD_FUSED_PAIR', fused)
+        monkeypatch.setenv('TTSAMD_CONVT', convt)
+        out = hifigan_engine.forward(mel, lens).clone()
+        assert maxabs(out, ref) < 5e-6, (fused, convt)
+        assert torch.equal(hifigan_engine.forward(mel, lens), out)
+        for b in range(4):
+            n = 256 * int(lens[b])
+            assert float(out[b, n:].abs().max()) == 0.0 if n < out.shape[1] else True
+    monkeypatch.delenv('TTSAMD_FUSED_PAIR')
+    monkeypatch.delenv('TTSAMD_CONVT')
+    assert torch.equal(hifigan_engine.forward(mel, lens), out)          # both are the default
