@@ -39,7 +39,8 @@ struct GeoB {
 // ACT: GELU / tanh compiled in (Vocos pwconv1, Tacotron2 postnet only): their inline expansions for 64 accumulators
 // per lane were most of the 70-100 KB of kernel code (64 KB instruction cache per CU pair)
 // EPI 0: row-major float4 epilogue through the dead LDS ring (same as the fp32 kernel's); EPI 2: per-lane epilogue
-// (polyphase upsamplers, unaligned rows, packed bf16 output)
+// (polyphase upsamplers, unaligned rows, packed bf16 output); EPI 3: row epilogue with the residual (+ running sum) PRELOADED
+// into the accumulators and a load-free store loop, as conv_mfma.hip's EPI 3
 template <int K, int MT, int NTL, int WM, int WN, int NPL, int EPI, bool ACT>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const ConvParams p) {
     // NPL = 1: plain bf16 operands; NPL = 2: split bf16 (hi + lo planes, 3 MFMAs per product)
@@ -82,23 +83,56 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     const int x_cs = p.x_cs, CoutP = p.CoutP;
 
     float ep_bias = 0.f, ep_scale = 1.f;     // see conv_mfma.hip: parked in LDS for the rolled row epilogue
-    if (EPI == 0 && tid < CO_BLK) {
+    if (EPI != 2 && tid < CO_BLK) {
         const int co_ = min(co_blk0 + tid, p.Cout - 1);
         if (p.bias) ep_bias = p.bias[co_];
         if (p.scale) ep_scale = p.scale[co_];
     }
 
-    f32x16 acc[MT][NTL];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int qw0 = wn * NTL * 32;
     const bool wave_active = (q0 + qw0) < n_out;   // wave-uniform
     const int kk = lane >> 5, l31 = lane & 31;
+    constexpr bool preload = EPI == 3;
+    f32x16 acc[MT][NTL];
+    // see conv_mfma.hip: buffer loads in the MFMA C layout, one per-lane offset per column tile + a scalar row offset per load
+#define TTS_INIT_ACC()                                                                                       \
+    if (preload) {                                                                                           \
+        const int wm_s = __builtin_amdgcn_readfirstlane(wm);                                                 \
+        const int row0 = co_blk0 + wm_s * MT * 32;                                                           \
+        int voff[NTL];                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < NTL; ++j) {                                                    \
+            const int q = q0 + qw0 + j * 32 + l31;                                                           \
+            voff[j] = (q < n_out ? q : 0) * 4;                                                               \
+        }                                                                                                    \
+        {                                                                                                    \
+            const int r_cs = p.r_cs;                                                                         \
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res + (int64_t)b * p.r_bs), 0, \
+                                                              p.Cout * r_cs * 4, 0x00020000);                \
+            const int vk = 4 * kk * r_cs * 4;                                                                \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                   \
+                _Pragma("unroll") for (int j = 0; j < NTL; ++j)                                              \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+                        acc[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(       \
+                            rs, voff[j] + vk, (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * r_cs * 4, 0));      \
+        }                                                                                                    \
+        if (p.mode != 0) {                                                                                   \
+            const int y_cs_ = p.y_cs;                                                                        \
+            const auto ys = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)b * p.y_bs, 0, p.Cout * y_cs_ * 4, 0x00020000); \
+            const int vk = 4 * kk * y_cs_ * 4;                                                               \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                   \
+                _Pragma("unroll") for (int j = 0; j < NTL; ++j) {                                            \
+                    f32x16 t;                                                                                \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+                        t[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(               \
+                            ys, voff[j] + vk, (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * y_cs_ * 4, 0));     \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = t[r] + acc[i][j][r];       \
+                }                                                                                            \
+        }                                                                                                    \
+    } else {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
+            _Pragma("unroll") for (int j = 0; j < NTL; ++j)                                                  \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;                           \
+    }
 
     // ---- staging registers.  X item it = (oc, kk, col): the 4 channels 8*oc + 2p + kk, p = 0..3,
     // at one input position -> one float4; W is a linear float4 copy.  Loads are unconditional
@@ -199,9 +233,11 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
         uint2* sbp = smem4 + c0 * G::BUF4;
 #pragma unroll
         for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
+        if (c0 == 0) TTS_INIT_ACC()
 #pragma unroll
         for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, sbp)
     }
+    if (NSTAGE < 2 || n_chunks < 1) TTS_INIT_ACC()
     __syncthreads();
 #pragma unroll
     for (int P = 0; P < NF; ++P) TTS_FETCH_PART(0, 0, 0, P)
@@ -279,12 +315,13 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
         }
         stage = stage_next;
     }
+#undef TTS_INIT_ACC
 #undef TTS_LOAD_JOB
 #undef TTS_WRITE_JOB
 #undef TTS_FETCH_PART
 #undef TTS_LRELU
 
-    if constexpr (EPI == 0) {
+    if constexpr (EPI != 2) {
         {
 
             constexpr int LDS_F = NSTAGE * G::BUF4 * 2;                         // floats of LDS this block owns
@@ -296,7 +333,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
             float* ep = reinterpret_cast<float*>(smem4);
             float* epb = ep + LDS_F - 2 * CO_BLK;                               // [CO_BLK] bias, [CO_BLK] scale
             float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
-            const float* __restrict__ rb = p.res ? p.res + (int64_t)b * p.r_bs : nullptr;
+            const float* __restrict__ rb = (p.res && !preload) ? p.res + (int64_t)b * p.r_bs : nullptr;
             const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
             const float div = p.div;
 #pragma unroll
@@ -310,13 +347,50 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                            if (row >= ps * ROWS_P && row < (ps + 1) * ROWS_P)
+                            if (NPASS == 1 || (row >= ps * ROWS_P && row < (ps + 1) * ROWS_P))
                                 ep[(row - ps * ROWS_P) * NT_BLK + qw0 + j * 32 + l31] = acc[i][j][r];
                         }
                 __syncthreads();
                 constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                     // rows per wave instruction
                 constexpr int CPL = LPR >= 64 ? LPR / 64 : 1;                     // float4 columns groups per lane
                 constexpr int NR = (ROWS_P + 4 * RPI - 1) / (4 * RPI);            // row iterations per wave
+                if (preload || (!rb && mode == 0 && (!ACT || relu_out < 2))) {
+                    // nothing to read from memory: a store loop without a vmcnt wait (conv_mfma.hip)
+                    const float lo = relu_out == 1 ? 0.f : -__builtin_inff();
+                    const bool do_div = mode == 2;
+#pragma unroll 4
+                    for (int it = 0; it < NR; ++it) {
+                        const int r0 = wid * RPI + it * 4 * RPI;
+                        const int rl = r0 + (LPR >= 64 ? 0 : lane / LPR);
+                        const int co = co_blk0 + ps * ROWS_P + rl;
+                        if (rl >= ROWS_P || ps * ROWS_P + rl >= CO_BLK || co >= Cout) continue;
+                        const float bsv = epb[ps * ROWS_P + rl], scv = epb[CO_BLK + ps * ROWS_P + rl];
+#pragma unroll
+                        for (int cg = 0; cg < CPL; ++cg) {
+                            const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
+                            const int q = q0 + col;
+                            if (q >= n_out) continue;
+                            const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
+                            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = fmaxf((v[e] + bsv) * scv, lo);
+                                if (do_div) x = x / div;
+                                v[e] = x;
+                            }
+                            float* yp = yb + (int64_t)co * p.y_cs + q;
+                            if (q + 3 < n_out) {
+                                *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (q + e < n_out) yp[e] = v[e];
+                            }
+                        }
+                    }
+                    continue;
+                }
+                if constexpr (!preload) {
 #pragma unroll 2
                 for (int it = 0; it < NR; ++it) {
                     const int r0 = wid * RPI + it * 4 * RPI;
@@ -366,6 +440,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
                         }
                     }
                 }
+                }   // !preload
             }
             return;
         }
@@ -489,8 +564,11 @@ static int32_t launch_cfg_bf16(const ConvParams& p_in, hipStream_t stream) {
                         ((uintptr_t)p.y & 15) == 0 &&
                         (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0));
     const bool act = HAS_ACT && p.relu_out >= 2;
+    const bool pre_ok = p.res != nullptr && p.scale == nullptr && p.relu_out < 2 &&
+                        (int64_t)p.Cout * std::max(p.r_cs, p.y_cs) * 4 < ((int64_t)1 << 31);
     if (vec_ok) {
         if (act) return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 0, HAS_ACT>(p, grid, lds, stream);
+        if (pre_ok) return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 3, false>(p, grid, lds, stream);
         return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 0, false>(p, grid, lds, stream);
     }
     if (act) return launch_act_bf16<K, MT, NTL, WM, WN, NPL, 2, HAS_ACT>(p, grid, lds, stream);
