@@ -18,7 +18,7 @@ def dispatches(d, counter):
     rows = {}
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and ('conv1d_mfma' in r['Kernel_Name'] or 'resblock_pair' in r['Kernel_Name']):
+            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'convt_mfma')):
                 k = int(r['Dispatch_Id'])
                 name = r['Kernel_Name'].split('(')[0].replace('void ttsamd::', '')
                 g = None
