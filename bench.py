@@ -155,7 +155,7 @@ def main():
     # TTSAMD_BENCH_ONE_DEVICE=1 (set by _self_launch on a box with fewer GPUs than ranks): all ranks share GPU 0
     # and exchange over gloo with host staging — exercises the N>1 code path on a 1-GPU box; the real
     # multi-GPU run is one rank per GPU over RCCL.
-    one_dev = os.environ.get('TTSAMD_BENCH_ONE_DEVICE') == '1'
+    one_dev = os.environ.get('TTSAMD_BENCH_ONE_DEVICE') == '1' or world > torch.cuda.device_count()
     if one_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
