@@ -8,6 +8,8 @@
   only, rank-sharded waves gathered on rank 0 == the same sub-batches computed by one process, bit for bit,
   and == the unsharded 4-utterance batch within the waveform tolerance.
 * `test_bench_two_ranks_one_device`: `python bench.py --gpus 2` typed as is prints ONE json line, n_gpus 2.
+* `test_tts_sharded_dropin_two_ranks`: `ttsamd.dp.tts_sharded` with the drop-in `FastPitch2Wave` (text in, waves out, denoiser on)
+  on two ranks sharing the GPU == `model.tts(...)` of one process on the same sub-batches, bit for bit, in the original order.
 """
 import json
 import os
@@ -160,3 +162,60 @@ def test_bench_two_ranks_one_device():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['scaling'] == 'weak'
     assert 'ONE device' in out['config']['parallelism']
+
+
+def _sharded_worker(rank, world, port, tmpdir):
+    for p in (os.path.join(REPO, 'tts-arabic-pytorch_amd'), os.path.join(REPO, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import text
+    from ttsamd import dp, synth
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    from models.fastpitch import FastPitch2Wave
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(0)
+        d = os.path.join(tmpdir, f'ckpt{rank}')
+        os.makedirs(d, exist_ok=True)
+        fp = {k: torch.from_numpy(v.copy()) for k, v in synth.fastpitch_state_dict().items()}
+        torch.save({'model': fp, 'config': dict(NET_CONFIG), 'symbols': list(text.symbols)}, os.path.join(d, 'fp.pth'))
+        torch.save({'generator': {k: torch.from_numpy(v.copy()) for k, v in synth.hifigan_state_dict().items()}},
+                   os.path.join(d, 'hg.pth'))
+        with open(os.path.join(d, 'config.json'), 'w') as f:
+            json.dump(HIFIGAN_CONFIG, f)
+        model = FastPitch2Wave(os.path.join(d, 'fp.pth'), vocoder_sd=os.path.join(d, 'hg.pth'),
+                               vocoder_config=os.path.join(d, 'config.json')).to(dev)
+        with open(os.path.join(REPO, 'tests', 'golden', 'infer_text_lines.json'), encoding='utf-8') as f:
+            lines = json.load(f)
+        texts = [lines[i] for i in (3, 0, 7, 1, 5)]
+        dpx = dp.Dp(dev)
+        res = dp.tts_sharded(model, texts, batch_size=2, dp=dpx, denoise=0.005)
+        if rank == 0:
+            assert len(res) == len(texts) and all(w.device.type == 'cpu' and w.dim() == 1 for w in res)
+            # one process, the same sub-batches: length-sorted order, contiguous shards, chunks of batch_size
+            order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))
+            ref = [None] * len(texts)
+            for r in range(world):
+                lo, hi = dp.shard_bounds(len(order), world, r)
+                for c0 in range(lo, hi, 2):
+                    chunk = order[c0:min(hi, c0 + 2)]
+                    waves = model.tts_batch([texts[i] for i in chunk], denoise=0.005)
+                    for i, w in zip(chunk, waves):
+                        ref[i] = w
+            for i in range(len(texts)):
+                assert torch.equal(res[i], ref[i]), i
+        else:
+            assert res is None
+        with open(os.path.join(tmpdir, f'sharded_ok{rank}'), 'w') as f:
+            f.write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tts_sharded_dropin_two_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / 'sharded_ok0') and os.path.exists(tmp_path / 'sharded_ok1')
