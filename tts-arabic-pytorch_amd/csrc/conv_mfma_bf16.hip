@@ -161,7 +161,6 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
     constexpr int NWJ = NXI + NPL * NW;        // write jobs per chunk
     constexpr int NM = (NPL == 2 ? 3 : 1) * MT * NTL;   // MFMAs per operand group
     constexpr int NF = NPL * (MT + NTL);       // ds_read_b64 per operand fetch
-    constexpr int NFU = NF < NM ? NF : NM;     // fetch parts are spread over the first gaps
     constexpr int GL = (NGRP - 1) * NM;        // gaps carrying load jobs
     static_assert(NGRP >= 2, "operand group layout");
 #define TTS_LOAD_JOB(J)                                                                              \
