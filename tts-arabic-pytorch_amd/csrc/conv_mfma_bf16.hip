@@ -232,11 +232,11 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
         uint2* sbp = smem4 + c0 * G::BUF4;
 #pragma unroll
         for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J)
-        if (c0 == 0) TTS_INIT_ACC()
+        if (c0 == 0) { TTS_INIT_ACC() }
 #pragma unroll
         for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, sbp)
     }
-    if (NSTAGE < 2 || n_chunks < 1) TTS_INIT_ACC()
+    if (NSTAGE < 2 || n_chunks < 1) { TTS_INIT_ACC() }
     __syncthreads();
 #pragma unroll
     for (int P = 0; P < NF; ++P) TTS_FETCH_PART(0, 0, 0, P)
