@@ -96,6 +96,7 @@ struct ConvParams {
     int32_t y_packed;         // write y in that layout (requires Cout % 8 == 0, y_ts == 1, mode 0, no phases)
     float pack_slope;         // ... after applying leaky-relu with this slope
     int32_t x_packed;         // read x in that layout (x_cs = positions per row; in_slope is ignored)
+    int32_t xcd_w;            // set by the launcher: gcd(n_co_tiles, 8) co-tile classes, one per XCD residue (weight locality; 0 = off)
     int32_t tile_major;       // set by the launcher: blockIdx.x = utterance slot, blockIdx.z = time tile (ragged batches)
     unsigned long long* timing;   // tools/conv_bench -DTTS_TIMING only: [blocks][8] clock samples (nullptr otherwise)
 };

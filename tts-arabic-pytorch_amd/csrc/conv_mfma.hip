@@ -80,13 +80,25 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     // ragged batches: tile-major block order (x = utterance slot, z = time tile), see ConvParams::tile_major
-    const int b = p.tile_major ? (int)((blockIdx.x + blockIdx.z) % (unsigned)p.batch) : (int)blockIdx.z;
+    unsigned bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+    if (p.xcd_w) {
+        // weight locality: workgroups go to the 8 XCDs round-robin by linear id; every XCD gets its own class of co-tiles, so
+        // that the weight slice its 4 MB L2 has to hold next to the streaming activations is 1/g of the layer (C=256 k=11:
+        // 2.9 MB of weights were re-fetched ~36x per XCD and launch; stand-alone +4 % there, +2.4 % for C=128 k=11, production
+        // +0.2 % because three concurrent launches share the L2; TTSAMD_XCD_W=0 disables)
+        // g = gcd(n_co_tiles, 8) classes of co-tiles; XCD x serves class x % g = the n_co_tiles / g co-tiles {x % g + g*k}
+        const unsigned lin = bx_ + gridDim.x * (by_ + gridDim.y * bz_), xcd = lin & 7u, slot = lin >> 3;
+        const unsigned nct = gridDim.y, g = (unsigned)p.xcd_w, per = nct / g;
+        const unsigned idx2 = slot * (8u / g) + xcd / g, rest = idx2 / per;
+        by_ = xcd % g + g * (idx2 % per); bx_ = rest % gridDim.x; bz_ = rest / gridDim.x;
+    }
+    const int b = p.tile_major ? (int)((bx_ + bz_) % (unsigned)p.batch) : (int)bz_;
     const int n_co_tiles = p.CoutP / CO_BLK;
     const int tiles_y = n_co_tiles * p.n_phase;
-    const int ks = blockIdx.y / tiles_y, by = blockIdx.y % tiles_y;   // ks = split-K slice (0 when ksplit == 1)
+    const int ks = by_ / tiles_y, by = by_ % tiles_y;   // ks = split-K slice (0 when ksplit == 1)
     const int phase = by / n_co_tiles;
     const int co_blk0 = (by % n_co_tiles) * CO_BLK;
-    const int q0 = (p.tile_major ? blockIdx.z : blockIdx.x) * NT_BLK;
+    const int q0 = (p.tile_major ? bz_ : bx_) * NT_BLK;
 
     int n_out = p.Nout;
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
@@ -643,6 +655,12 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     q.ksplit = 1;
     q.tile_major = tile_major_order(p, grid.x) ? 1 : 0;
     if (q.tile_major) std::swap(grid.x, grid.z);
+    {
+        static const bool xw = [] { const char* e = getenv("TTSAMD_XCD_W"); return !(e && e[0] == '0'); }();
+        const unsigned nct = grid.y;
+        const unsigned g = (nct % 8 == 0) ? 8 : (nct % 4 == 0 ? 4 : (nct % 2 == 0 ? 2 : 1));
+        q.xcd_w = (xw && !q.tile_major && p.n_phase == 1 && g > 1 && ((int64_t)grid.x * grid.y * grid.z) % 8 == 0) ? (int)g : 0;
+    }
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
     const int n_chunks = p.Cin / G::KC;
     if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < 320 && n_chunks >= 8) {
