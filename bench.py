@@ -332,7 +332,8 @@ def main():
                                    f'{world}xMI355X', 'batch_per_gpu': B, 'n_tokens': Lt,
                        'frames_per_step_rank0': frames, 'parallelism': par, 'dp_transport': transport},
             'roofline': {'bound': 'mfma' if args.precision == 'f32' else 'hbm (fp32 activations; MFMA figures for reference)',
-                         'kernel': ('conv1d_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
+                         'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair_c32 + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
+                         'kernel_time_basis': 'HIP events on the launch stream: one pair per launch, one pair per fork..join section of the three-stream ResBlock schedule (wall time of the section)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
                          'launches': int(n_launch), 'avg_launch_ms': conv_ms / max(1.0, n_launch),
