@@ -57,8 +57,9 @@ struct Geo {
     static constexpr int NSTAGE = TTS_FORCE_NSTAGE;
 #else
     // three stages when they fit in half of the LDS; the 32-channel tiles (HiFi-GAN stage 4: 4 chunks per block, all
-    // prologue and epilogue) do better with two stages and one more resident block (+2...5 %, tools/conv_bench)
-    static constexpr int NSTAGE = (CO_BLK > 32 && 3 * BUF4 * 16 <= 80 * 1024) ? 3 : 2;
+    // prologue and epilogue) do better with two stages and one more resident block (+2...5 %, tools/conv_bench), and
+    // so do the 64-channel k = 7 tiles (64 x 128: 4 resident blocks instead of 2, +3.8 % on stage 1; 64 x 256: +2.2 %)
+    static constexpr int NSTAGE = (CO_BLK > 32 && 3 * BUF4 * 16 <= 80 * 1024 && !(K == 7 && CO_BLK == 64 && NT_BLK >= 128)) ? 3 : 2;
 #endif
     static constexpr int NGRP = NOCT * K;                     // operand groups per chunk
 };
@@ -728,7 +729,7 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
         // a launch is then 2-4 rounds of blocks and its tail costs 15-19 %: finer tiles pay there
         const bool few_long = p.Cin >= 256 && p.CoutP <= p.Cin && !tiny && blocks(128, 128) < 4 * want;
         if (few_long && K == 3 && blocks(128, 64) >= want) return launch_cfg<K, 1, 2, 4, 1>(p, stream);  // 128 co x 64 t
-        if (few_long && K == 11 && blocks(64, 128) >= want) return launch_cfg<K, 1, 2, 2, 2>(p, stream); //  64 co x 128 t
+        if (few_long && K >= 7 && blocks(64, 128) >= want) return launch_cfg<K, 1, 2, 2, 2>(p, stream);  //  64 co x 128 t
         if (K < 11 && !tiny && blocks(128, 128) >= want) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
         if (K == 11 && !tiny && blocks(64, 256) >= want) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
         if (blocks(128, 64) >= want || (tiny && blocks(64, 64) < 2 * want)) return launch_cfg<K, 1, 2, 4, 1>(p, stream);   // 128 co x 64 t
