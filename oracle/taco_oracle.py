@@ -124,6 +124,8 @@ def tacotron2_infer(w, cfg, tokens, speaker_ids=None, lengths=None, max_step=Non
         if trace is not None:
             trace.setdefault('gate', []).append(gate.squeeze(1).clone())   # test aid: stop-token logits per step
             trace.setdefault('hc', []).append(hc.clone())                  # and the gate layer's input
+            trace.setdefault('att_h', []).append(att_h.clone())
+            trace.setdefault('prenet', []).append(p.clone())
         mel_lens[~finished] += 1
         finished |= torch.sigmoid(gate.squeeze(1)) > cfg['gate_threshold']
         if bool(torch.all(finished)):

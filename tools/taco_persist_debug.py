@@ -1,0 +1,56 @@
+"""Debugging aid: the persistent decoder's state after N steps (TTSAMD_TACO_DUMP) against oracle/taco_oracle.py's trace."""
+import os
+import sys
+
+import numpy as np
+
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, os.path.join(R, 'tts-arabic-pytorch_amd'))
+sys.path.insert(0, os.path.join(R, 'oracle'))
+import torch  # noqa: E402
+
+
+def main():
+    import taco_oracle as T
+    from ttsamd.config import TACOTRON2_CONFIG
+    from ttsamd.synth import tacotron2_state_dict
+    from ttsamd.engine import Tacotron2Engine
+    nspk = int(os.environ.get('NSPK', '1'))
+    B, L = 3, 23
+    cfg = dict(TACOTRON2_CONFIG, num_speakers=nspk)
+    sd = tacotron2_state_dict(cfg, seed=0, gate_bias=-20.0)
+    eng = Tacotron2Engine(sd, cfg, device=torch.device('cuda:0'))
+    g = torch.Generator().manual_seed(B)
+    lens = torch.sort(torch.randint(max(1, L // 2), L + 1, (B,), generator=g), descending=True).values
+    lens[0] = L
+    tok = torch.randint(1, 40, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    sids = (torch.arange(B) % nspk) if nspk > 1 else None
+    for steps in (1, 2):
+        tr = {}
+        mel_ref, _, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=steps, seed=-1, trace=tr)
+        os.environ['TTSAMD_TACO_PERSISTENT'] = '1'
+        os.environ['TTSAMD_TACO_DUMP'] = '/tmp/taco_dump.bin'
+        mel, ml, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=-1)
+        raw = open('/tmp/taco_dump.bin', 'rb').read()
+        hdr = np.frombuffer(raw[:64], dtype=np.int32)
+        x = np.frombuffer(raw[64:], dtype=np.float32)
+        Bq, Lq, M, nst, pre_o, h0_o, a0, a1, d0, d1, ctx_o, aw_o, cum_o, ep_o, fin_o, n = hdr.tolist()
+        last = steps - 1
+        po = (last & 1) ^ 1
+        att_h = x[(a0, a1)[po]:][:B * 1024].reshape(B, 1024)
+        dec_h = x[(d0, d1)[po]:][:B * 1024].reshape(B, 1024)
+        ctx = x[ctx_o:][:B * M].reshape(B, M)
+        aw = x[aw_o:][:B * L].reshape(B, L)
+        hc = tr['hc'][last].numpy()
+        print(f'steps {steps}: att_h {np.abs(att_h - tr["att_h"][last].numpy()).max():.2e}  dec_h {np.abs(dec_h - hc[:, :1024]).max():.2e} '
+              f'ctx {np.abs(ctx - hc[:, 1024:]).max():.2e}  aw {np.abs(aw - al_ref[:, last].numpy()).max():.2e}  '
+              f'mel_post {np.abs(mel.cpu().numpy() - mel_ref.numpy()).max():.2e}')
+        if steps == 1:
+            d = np.abs(dec_h - hc[:, :1024])
+            print('   dec_h worst units', np.argsort(-d.max(0))[:12].tolist(), 'mean err', float(d.mean()), 'ref absmean', float(np.abs(hc[:, :1024]).mean()))
+            d = np.abs(att_h - tr["att_h"][last].numpy())
+            print('   att_h worst units', np.argsort(-d.max(0))[:12].tolist(), 'mean err', float(d.mean()))
+
+
+if __name__ == '__main__':
+    main()

@@ -23,6 +23,10 @@
 
 namespace ttsamd {
 
+#ifndef TP_SKIP
+#define TP_SKIP 0
+#endif
+
 struct TConv {
     int64_t w_off = 0, b_off = 0, w16_off = 0;
     int cin = 0, cout = 0, k = 0;
@@ -40,6 +44,7 @@ struct Taco2 {
     int64_t att_wih, att_whh, att_b, dec_wih, dec_whh, dec_b;
     int64_t wq, wmT, v, loc_conv, loc_denseT;
     int64_t proj_w, proj_b;
+    int64_t loc_fold = 0, projx_w = 0, projx_b = 0;   // persistent decoder: folded location filter, projection + folded prenet layer 1
     int mem_dim = 0;
     // host side of the stop test (one infer call at a time per handle: guarded by mu)
     mutable std::mutex mu;
@@ -195,6 +200,45 @@ int32_t tacotron2_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_t
             bias[cfg->n_mels] = gb[0];
             h->proj_w = b.push(w.data(), (int64_t)w.size());
             h->proj_b = b.push(bias.data(), (int64_t)bias.size());
+            // persistent decoder (taco_decoder_persistent): rows 0..80 as above, rows 81..336 = prenet layer 1 folded
+            // into the projection, W0 * Wp and W0 * bp (the prenet has no bias and nothing but the mel projection
+            // between it and [dec_h | ctx]); accumulated in double so the fold adds no rounding of its own
+            const float* w0 = b.get("decoder.prenet.layers.0.weight", (int64_t)P * cfg->n_mels);
+            if (w0) {
+                const int KP = D + M, NM = cfg->n_mels;
+                std::vector<float> wx((size_t)(NM + 1 + P) * KP), bx(NM + 1 + P);
+                std::memcpy(wx.data(), w.data(), w.size() * sizeof(float));
+                std::memcpy(bx.data(), bias.data(), bias.size() * sizeof(float));
+                std::vector<double> row(KP);
+                for (int j = 0; j < P; ++j) {
+                    std::fill(row.begin(), row.end(), 0.0);
+                    double bj = 0.0;
+                    for (int m = 0; m < NM; ++m) {
+                        const double a = w0[(size_t)j * NM + m];
+                        const float* pr = pw + (size_t)m * KP;
+                        for (int k = 0; k < KP; ++k) row[k] += a * pr[k];
+                        bj += a * pb[m];
+                    }
+                    for (int k = 0; k < KP; ++k) wx[(size_t)(NM + 1 + j) * KP + k] = (float)row[k];
+                    bx[NM + 1 + j] = (float)bj;
+                }
+                h->projx_w = b.push(wx.data(), (int64_t)wx.size());
+                h->projx_b = b.push(bx.data(), (int64_t)bx.size());
+            }
+        }
+    }
+    {   // location layer folded: G[h][c][k] = sum_q dense[h][q] * conv[q][c][k]   (no nonlinearity between the two)
+        const float* lc = b.get("decoder.attention_layer.location_layer.location_conv.weight", (int64_t)NF * 2 * KS);
+        const float* ld = b.get("decoder.attention_layer.location_layer.location_dense.weight", (int64_t)Hd * NF);
+        if (!b.rc) {
+            std::vector<float> g((size_t)Hd * 2 * KS);
+            for (int hh = 0; hh < Hd; ++hh)
+                for (int i = 0; i < 2 * KS; ++i) {
+                    double a = 0.0;
+                    for (int q = 0; q < NF; ++q) a += (double)ld[(size_t)hh * NF + q] * lc[(size_t)q * 2 * KS + i];
+                    g[(size_t)hh * 2 * KS + i] = (float)a;
+                }
+            h->loc_fold = b.push(g.data(), (int64_t)g.size());
         }
     }
     for (int i = 0; i < cfg->postnet_n_convolution && !b.rc; ++i) {
@@ -629,12 +673,470 @@ __global__ __launch_bounds__(256) void taco_proj_kernel(const float* __restrict_
 
 __global__ void taco_advance_kernel(int* step_base, int n) { *step_base += n; }
 
+// ---- the whole decoder loop as ONE persistent cooperative kernel ------------------------------------------------------
+// 256 blocks x 256 threads, one block per CU, resident for every step of the utterance batch (B <= 8, L <= 256):
+//   * the 71 MB of LSTMCell weights never leave the chip: block i owns hidden units 4i..4i+3 of BOTH cells, the 16 gate
+//     rows of the attention cell sit in its LDS (112-120 KB), the 16 rows of the decoder cell in its registers (160-192
+//     VGPRs per thread, one wave per SIMD), the cell states c in the registers of the 32 threads that apply the gates;
+//   * the query rows, the folded location filter, this block's slice of processed_memory and of the encoder memory, its
+//     rows of the mel / gate projection and of the prenet are resident too (registers / LDS);
+//   * the phases of a step are separated by a grid barrier WITHOUT cache maintenance: everything that crosses blocks
+//     (h, ctx, alignment weights, partial energies, prenet activations: the `xch` arena) is written and read with
+//     device-coherent buffer accesses (sc1), an s_waitcnt orders the data before the block's barrier slot.  A barrier
+//     with __threadfence / acquire fences costs 27-33 us on the 8-XCD part (every fence walks the XCD's L2), this one
+//     3.6 us (tools/grid_barrier_bench.hip);
+//   * six barriers per step:  attention LSTM | query + partial energies (attention dims split over 16 block groups) |
+//     softmax + context (32 column groups per utterance) | decoder LSTM | mel / gate projection + prenet layer 1 (folded
+//     into the projection: W0 Wp) | prenet layer 2;  the stop test runs on the device.
+struct TacoPersist {
+    const float *pre1, *att_wih, *att_whh, *att_b, *dec_wih, *dec_whh, *dec_b, *wq, *loc_fold, *v, *pm, *memory, *projx_w, *projx_b;
+    const int64_t* lens;
+    float* xch;
+    int xch_bytes;
+    int pre_o, h0_o, att_h_o[2], dec_h_o[2], ctx_o, aw_o, cum_o, epart_o, fin_o, slots_o, err_o, steps_o;
+    float *mel_out, *align_out;
+    int32_t* mel_lens;
+    int B, L, KS, Tcap, max_step, n_mels;
+    float thr;
+    long long seed;
+};
+
+template <int M_>
+struct PGeo {
+    static constexpr int KA = 256 + M_ + 1024, K4A = KA / 4, NJA = (K4A + 127) / 128;     // attention cell  [pre | ctx | h]
+    static constexpr int KD = 1024 + M_ + 1024, K4D = KD / 4, NJD = (K4D + 127) / 128;    // decoder cell    [att_h | ctx | h]
+    static constexpr int KP = 1024 + M_, K4P = KP / 4;                                    // projection      [dec_h | ctx]
+    static constexpr int MC = M_ / 32, NS = 256 / MC;                                     // context columns per block, t slices
+};
+
+// Device-coherent accesses to the exchange arena.  (clang's __builtin_amdgcn_raw_buffer_load_b128 of this ROCm lowers to an
+// i32 load whose value is splatted over the vector; the LLVM intrinsics are declared directly, as composable_kernel does.)
+typedef int taco_i4 __attribute__((ext_vector_type(4)));
+typedef float taco_f4 __attribute__((ext_vector_type(4)));
+__device__ taco_f4 taco_buffer_load_f4(taco_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float taco_buffer_load_f1(taco_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void taco_buffer_store_f1(float v, taco_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+#define XLD(foff) taco_buffer_load_f1(rs, (foff) * 4, 0, 16)                      /* aux 16 = sc1: device scope */
+#define XST(foff, val) taco_buffer_store_f1((float)(val), rs, (foff) * 4, 0, 16)
+#define XLD4(dst, foff) { const taco_f4 r_ = taco_buffer_load_f4(rs, (foff) * 4, 0, 16); dst = make_float4(r_.x, r_.y, r_.z, r_.w); }
+
+__device__ __forceinline__ float taco_dot4(const float4 w, const float4 x, float acc) {
+    return fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, fmaf(w.w, x.w, acc))));
+}
+
+// sums the 32 per-thread partials v[i] over the 64 lanes of the wave: lanes 2i and 2i+1 end with the total of partial i
+__device__ __forceinline__ float taco_butterfly32(float (&v)[32], int lane) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int m = 32 >> s, half = 16 >> s;
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            float lo = v[j], hi = v[j + half];
+            asm volatile("" : "+v"(lo), "+v"(hi));       // values, not addresses: in this (large) kernel the optimizer otherwise
+            const float send = upper ? lo : hi;          // turns the two selects into v[dynamic index] = 32 compare/select pairs
+            const float keep = upper ? hi : lo;
+            v[j] = keep + __shfl_xor(send, m);
+        }
+    }
+    return v[0] + __shfl_xor(v[0], 1);
+}
+
+// grid barrier over the resident blocks: no cache maintenance (see above); false after a spin time-out
+__device__ __forceinline__ bool taco_grid_barrier(unsigned* slots, unsigned epoch, int32_t* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bool ok = true;
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) __hip_atomic_store(slots + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sidx = 4 * (int)threadIdx.x + i;
+                const unsigned val = sidx < (int)gridDim.x ? __hip_atomic_load(slots + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+                all = all && (int)(val - epoch) >= 0;
+            }
+            if (__all(all)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 20)) { ok = false; break; }
+        }
+        if (!ok && threadIdx.x == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::: "memory");
+    ok = __syncthreads_and(ok);
+    asm volatile("" ::: "memory");
+    return ok;
+}
+
+template <int M_>
+__global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist p) {
+    using G = PGeo<M_>;
+    extern __shared__ float4 taco_smem4[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, bid = blockIdx.x;
+    const int B = p.B, L = p.L, KS = p.KS, half = (KS - 1) / 2, BL = B * L;
+    const int PT = (BL + 15) / 16;                                   // (utterance, token) pairs per energy tile
+    float4* sWa = taco_smem4;                                        // [16 rows][K4A] attention cell weights
+    float* sf = reinterpret_cast<float*>(taco_smem4 + 16 * G::K4A);
+    float* sMem = sf;  sf += L * G::MC;                              // [L][MC] this block's encoder-memory columns
+    float* sPm = sf;   sf += PT * 8;                                 // [pair][8 dims] processed memory of this tile
+    float* sG = sf;    sf += 8 * 2 * KS;                             // [8 dims][2][KS] folded location filter
+    float* sAw = sf;   sf += PT + 2 * half;                          // alignment weights window of this tile
+    float* sCum = sf;  sf += PT + 2 * half;
+    float* part = sf;  sf += 256;
+    float* gates = sf; sf += 128;
+    float* sPq = sf;   sf += 64;
+    float* sW = sf;    sf += 256;
+    float* sRed = sf;  sf += G::NS * G::MC;
+    float* red = sf;   sf += 8;
+    float* sV = sf;    sf += 8;
+    taco_i4 rs;                                                      // raw buffer over the exchange arena, offsets in bytes
+    {
+        const unsigned long long a = (unsigned long long)p.xch;
+        rs.x = (int)(unsigned)a; rs.y = (int)(unsigned)(a >> 32); rs.z = p.xch_bytes; rs.w = 0x00020000;
+    }
+    unsigned* slots = reinterpret_cast<unsigned*>(p.xch + p.slots_o);
+    int32_t* err = reinterpret_cast<int32_t*>(p.xch + p.err_o);
+
+    // ---------------- residency set-up (constant data: ordinary loads)
+    const int u0 = bid * 4;                                          // hidden units of both cells
+    for (int i = tid; i < 16 * G::K4A; i += 256) {
+        const int r = i / G::K4A, g = i - r * G::K4A, k = 4 * g;
+        const int64_t row = (int64_t)(r & 3) * 1024 + u0 + (r >> 2);  // row r = (unit r >> 2, gate r & 3)
+        sWa[i] = *reinterpret_cast<const float4*>(k < 256 + M_ ? p.att_wih + row * (256 + M_) + k : p.att_whh + row * 1024 + (k - 256 - M_));
+    }
+    const int hf = wid >> 1, tl = tid & 127;                         // wave pair hf owns gate rows 8 hf .. 8 hf + 7
+    float4 wd[8][G::NJD];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int R = 8 * hf + r;
+        const int64_t row = (int64_t)(R & 3) * 1024 + u0 + (R >> 2);
+#pragma unroll
+        for (int j = 0; j < G::NJD; ++j) {
+            const int g = tl + 128 * j, k = 4 * min(g, G::K4D - 1);
+            const float4 wv = *reinterpret_cast<const float4*>(k < 1024 + M_ ? p.dec_wih + row * (1024 + M_) + k : p.dec_whh + row * 1024 + (k - 1024 - M_));
+            wd[r][j] = g < G::K4D ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const int g16 = bid & 15, tile = bid >> 4;                       // attention dims 8 g16 .. +7, energy tile
+    for (int i = tid; i < 8 * 2 * KS; i += 256) sG[i] = p.loc_fold[(int64_t)8 * g16 * 2 * KS + i];
+    if (tid < 8) sV[tid] = p.v[8 * g16 + tid];
+    const int p0 = tile * PT, p1 = min(p0 + PT, BL);
+    for (int i = tid; i < (p1 - p0) * 8; i += 256) sPm[i] = p.pm[(int64_t)(p0 + (i >> 3)) * 128 + 8 * g16 + (i & 7)];
+    const int b4 = bid >> 5, cg = bid & 31;                          // softmax / context: utterance, column group
+    if (b4 < B)
+        for (int i = tid; i < L * G::MC; i += 256) {
+            const int t = i / G::MC, c = i - t * G::MC;
+            sMem[i] = p.memory[((int64_t)b4 * L + t) * M_ + cg * G::MC + c];
+        }
+    float4 wpA[2], wpB[2];                                           // projection rows: 81 + bid (prenet layer 1 folded), bid (mel / gate)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = tid + 256 * j, k = 4 * min(g, G::K4P - 1);
+        const float4 a = *reinterpret_cast<const float4*>(p.projx_w + (int64_t)(p.n_mels + 1 + bid) * G::KP + k);
+        const float4 b = *reinterpret_cast<const float4*>(p.projx_w + (int64_t)min(bid, p.n_mels) * G::KP + k);
+        const bool ok = g < G::K4P;
+        wpA[j] = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+        wpB[j] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float biasA = p.projx_b[p.n_mels + 1 + bid], biasB = p.projx_b[min(bid, p.n_mels)];
+    const float w1 = p.pre1[(int64_t)bid * 256 + tid];               // prenet layer 2: row bid
+    float ba[4], bd[4];                                              // gate biases of this thread's unit (threads < 32)
+    {
+        const int uu = (tid >> 3) & 3;
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) {
+            ba[gt] = p.att_b[gt * 1024 + u0 + uu];
+            bd[gt] = p.dec_b[gt * 1024 + u0 + uu];
+        }
+    }
+    float c_att = 0.f, c_dec = 0.f, cum = 0.f;
+    int fin = 0, mlen = 0;
+    unsigned epoch = 0;
+    int steps = p.max_step;
+    const int n4 = b4 < B ? min((int)p.lens[b4], L) : 0;
+    __syncthreads();
+
+    for (int s = 0; s < p.max_step; ++s) {
+        const int pi = s & 1, po = pi ^ 1;
+        // ---------------- S1: attention LSTMCell on [pre | ctx | att_h]
+#if !(TP_SKIP & 1)
+        {
+            int vz = 0;
+            asm volatile("" : "+v"(vz));                 // opaque zero: keeps the address arithmetic of this phase inside the
+            (void)vz;                                    // step loop (hoisted out of it, it costs more registers than there are)
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {             // utterances 4 ps .. 4 ps + 3: 32 partial sums per thread at a time
+                int vp = 0;
+                asm volatile("" : "+v"(vp));             // (and keeps the two passes' LDS reads apart: merged, they hold 128 registers)
+                const int tlz = tl + vz + vp;
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < G::NJA; ++j) {
+                    const int g = tlz + 128 * j, gc = min(g, G::K4A - 1), k = 4 * gc;
+                    float4 wa[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) wa[r] = sWa[(8 * hf + r) * G::K4A + gc];
+                    const int xbase = k < 256 ? p.pre_o + k : k < 256 + M_ ? p.ctx_o + (k - 256) : p.att_h_o[pi] + (k - 256 - M_);
+                    const int xstride = k < 256 ? 256 : k < 256 + M_ ? M_ : 1024;
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        float4 xv;
+                        XLD4(xv, xbase + min(4 * ps + bq, B - 1) * xstride)
+                        if (g >= G::K4A) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r * 4 + bq] = taco_dot4(wa[r], xv, v[r * 4 + bq]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one column group's loads in flight at a time: registers
+                }
+                const float tot = taco_butterfly32(v, lane);
+                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;   // [row][batch]
+            }
+            __syncthreads();
+            if (tid < 128) gates[tid] = part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)];
+            __syncthreads();
+            if (tid < 32) {
+                const int uu = tid >> 3, bb = tid & 7;
+                const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;       // [half][unit (2)][gate (4)][batch (8)]
+                const float gi = gp[0] + ba[0], gf = gp[8] + ba[1], gg = gp[16] + ba[2], go = gp[24] + ba[3];
+                c_att = sigmoidf_(gf) * c_att + sigmoidf_(gi) * tanhf(gg);
+                if (bb < B) XST(p.att_h_o[po] + bb * 1024 + u0 + uu, sigmoidf_(go) * tanhf(c_att));
+            }
+        }
+#endif
+        if (!taco_grid_barrier(slots, ++epoch, err)) return;
+#if !(TP_SKIP & 2)
+        // ---------------- S2+S3: processed query of this block's 8 attention dims, partial energies of its tile
+        {
+            int vz = 0;
+            asm volatile("" : "+v"(vz));
+            const int tidz = tid + vz;
+            float4 wq[8];                                // this block's 8 query rows (L2-resident constants, re-read per step)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) wq[r] = *reinterpret_cast<const float4*>(p.wq + (int64_t)(8 * g16 + r) * 1024 + 4 * tidz);
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                float v[32];
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) {
+                    float4 xv;
+                    XLD4(xv, p.att_h_o[po] + min(4 * ps + bq, B - 1) * 1024 + 4 * tidz)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r * 4 + bq] = fmaf(wq[r].x, xv.x, fmaf(wq[r].y, xv.y, fmaf(wq[r].z, xv.z, wq[r].w * xv.w)));
+                }
+                const float tot = taco_butterfly32(v, lane);
+                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;   // [dim][batch]
+            }
+            const int nw = (p1 - p0) + 2 * half;
+            for (int i = tid; i < nw; i += 256) {
+                const int fp = p0 - half + i;
+                const bool ok = fp >= 0 && fp < BL;
+                const float a = XLD(p.aw_o + (ok ? fp : 0)), c = XLD(p.cum_o + (ok ? fp : 0));
+                sAw[i] = ok ? a : 0.f;
+                sCum[i] = ok ? c : 0.f;
+            }
+            __syncthreads();
+            if (tid < 64) sPq[tid] = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];     // [dim][batch]
+            __syncthreads();
+            for (int it = tid; it < (p1 - p0) * 8; it += 256) {
+                const int pair = it >> 3, d = it & 7, pp = p0 + pair, b = pp / L, t = pp - b * L;
+                const float* gd = sG + d * 2 * KS;
+                float loc = 0.f;
+                for (int k = 0; k < KS; ++k) {
+                    const int tt = t + k - half;
+                    const bool ok = tt >= 0 && tt < L;
+                    loc = fmaf(gd[k], ok ? sAw[pair + k] : 0.f, loc);
+                    loc = fmaf(gd[KS + k], ok ? sCum[pair + k] : 0.f, loc);
+                }
+                float val = sV[d] * tanhf(sPq[d * 8 + b] + loc + sPm[pair * 8 + d]);
+                val += __shfl_xor(val, 1);
+                val += __shfl_xor(val, 2);
+                val += __shfl_xor(val, 4);
+                if (d == 0) XST(p.epart_o + g16 * BL + pp, val);
+            }
+        }
+#endif
+        if (!taco_grid_barrier(slots, ++epoch, err)) return;
+#if !(TP_SKIP & 4)
+        // ---------------- S4: masked softmax over the tokens of utterance b4, context columns cg MC .. +MC
+        if (b4 < B) {
+            const int t = tid;
+            float e = -INFINITY;
+            if (t < n4) {
+                e = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) e += XLD(p.epart_o + g * BL + b4 * L + t);
+            }
+            float mx = e;
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0) red[wid] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const float pr = t < n4 ? expf(e - mx) : 0.f;
+            float sm = pr;
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            if (lane == 0) red[4 + wid] = sm;
+            __syncthreads();
+            const float w = pr * (1.0f / (red[4] + red[5] + red[6] + red[7]));
+            sW[t] = w;
+            if (cg == 0 && t < L) {
+                cum += w;
+                XST(p.aw_o + b4 * L + t, w);
+                XST(p.cum_o + b4 * L + t, cum);
+                if (s < p.Tcap) p.align_out[((int64_t)b4 * p.Tcap + s) * L + t] = w;
+            }
+            __syncthreads();
+            if (tid < G::MC * G::NS) {
+                const int col = tid % G::MC, sl = tid / G::MC;
+                float a = 0.f;
+                for (int t2 = sl; t2 < n4; t2 += G::NS) a = fmaf(sW[t2], sMem[t2 * G::MC + col], a);
+                sRed[sl * G::MC + col] = a;
+            }
+            __syncthreads();
+            if (tid < G::MC) {
+                float a = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < G::NS; ++sl) a += sRed[sl * G::MC + tid];
+                XST(p.ctx_o + b4 * M_ + cg * G::MC + tid, a);
+            }
+        }
+#endif
+        if (!taco_grid_barrier(slots, ++epoch, err)) return;
+#if !(TP_SKIP & 8)
+        // ---------------- S5: decoder LSTMCell on [att_h | ctx | dec_h], weights in registers
+        {
+            int vz = 0;
+            asm volatile("" : "+v"(vz));
+            const int tlz = tl + vz;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < G::NJD; ++j) {
+                    const int g = tlz + 128 * j, k = 4 * min(g, G::K4D - 1);
+                    const int xbase = k < 1024 ? p.att_h_o[po] + k : k < 1024 + M_ ? p.ctx_o + (k - 1024) : p.dec_h_o[pi] + (k - 1024 - M_);
+                    const int xstride = k >= 1024 && k < 1024 + M_ ? M_ : 1024;
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        float4 xv;
+                        XLD4(xv, xbase + min(4 * ps + bq, B - 1) * xstride)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r * 4 + bq] = taco_dot4(wd[r][j], xv, v[r * 4 + bq]);   // wd is zero past K4D
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float tot = taco_butterfly32(v, lane);
+                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+            }
+            __syncthreads();
+            if (tid < 128) gates[tid] = part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)];
+            __syncthreads();
+            if (tid < 32) {
+                const int uu = tid >> 3, bb = tid & 7;
+                const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;
+                const float gi = gp[0] + bd[0], gf = gp[8] + bd[1], gg = gp[16] + bd[2], go = gp[24] + bd[3];
+                c_dec = sigmoidf_(gf) * c_dec + sigmoidf_(gi) * tanhf(gg);
+                if (bb < B) XST(p.dec_h_o[po] + bb * 1024 + u0 + uu, sigmoidf_(go) * tanhf(c_dec));
+            }
+        }
+#endif
+        if (!taco_grid_barrier(slots, ++epoch, err)) return;
+#if !(TP_SKIP & 16)
+        // ---------------- S6: mel / gate row bid (< 81) and prenet layer-1 unit bid (folded) from [dec_h | ctx]
+        {
+            float acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            int vz = 0;
+            asm volatile("" : "+v"(vz));
+            const int tidz = tid + vz;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = tidz + 256 * j, k = 4 * min(g, G::K4P - 1);
+                const int xbase = k < 1024 ? p.dec_h_o[po] + k : p.ctx_o + (k - 1024);
+                const int xstride = k < 1024 ? 1024 : M_;
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    float4 xv;
+                    XLD4(xv, xbase + min(bb, B - 1) * xstride)
+                    acc[bb] = taco_dot4(wpA[j], xv, acc[bb]);                    // weights are zero past K4P
+                    acc[8 + bb] = taco_dot4(wpB[j], xv, acc[8 + bb]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float a = acc[i];
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                if (lane == 0) part[wid * 16 + i] = a;
+            }
+            __syncthreads();
+            if (tid < 16) gates[tid] = part[tid] + part[16 + tid] + part[32 + tid] + part[48 + tid];
+            __syncthreads();
+            if (tid < 8 && tid < B) {
+                const int bb = tid;
+                float a = fmaxf(gates[bb] + biasA, 0.f);
+                if (p.seed >= 0) a *= taco_keep((unsigned)p.seed, 0u, (unsigned)(s + 1), (unsigned)bb, (unsigned)bid);
+                XST(p.h0_o + bb * 256 + bid, a);
+                const float m = gates[8 + bb] + biasB;
+                if (bid < p.n_mels) {
+                    p.mel_out[((int64_t)bb * p.n_mels + bid) * p.Tcap + s] = m;
+                } else if (bid == p.n_mels) {                                    // torchaudio _Decoder.infer stop bookkeeping
+                    if (!fin) mlen += 1;
+                    if (sigmoidf_(m) > p.thr) fin = 1;
+                    p.mel_lens[bb] = mlen;
+                    XST(p.fin_o + bb, __builtin_bit_cast(float, fin));
+                }
+            }
+        }
+#endif
+        if (!taco_grid_barrier(slots, ++epoch, err)) return;
+        {
+            int all = 1;
+            for (int b = 0; b < B; ++b) all &= __builtin_bit_cast(int, XLD(p.fin_o + b)) != 0;
+            if (all) { steps = s + 1; break; }
+        }
+        // ---------------- S7: prenet layer 2, unit bid (input of the next step's attention cell)
+        {
+            float pp[8];
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) pp[bb] = w1 * XLD(p.h0_o + min(bb, B - 1) * 256 + tid);
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                float a = pp[bb];
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                if (lane == 0) part[wid * 8 + bb] = a;
+            }
+            __syncthreads();
+            if (tid < 8 && tid < B) {
+                float a = fmaxf(part[tid] + part[8 + tid] + part[16 + tid] + part[24 + tid], 0.f);
+                if (p.seed >= 0) a *= taco_keep((unsigned)p.seed, 1u, (unsigned)(s + 1), (unsigned)tid, (unsigned)bid);
+                XST(p.pre_o + tid * 256 + bid, a);
+            }
+        }
+        if (!taco_grid_barrier(slots, ++epoch, err)) return;
+    }
+    if (bid == 0 && tid == 0) *reinterpret_cast<int32_t*>(p.xch + p.steps_o) = steps;
+}
+#undef XLD
+#undef XST
+#undef XLD4
+
 // ------------------------------------------------------------------------------------ host
 
 struct TWs {
     float *x0, *x1, *xproj, *memory, *pm, *pre, *pq, *energy, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
     float *post0, *post1;
     int32_t *finished, *step;
+    // the decoder state lives in ONE block (xch) so that the persistent decoder can address all of it through one buffer
+    // resource with cache-bypassing accesses; *_o are float offsets into it
+    float* xch;
+    int64_t xch_floats;
+    int pre_o, h0_o, att_h_o[2], dec_h_o[2], ctx_o, aw_o, cum_o, epart_o, fin_o, slots_o, err_o, steps_o;
 };
 
 static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
@@ -645,20 +1147,39 @@ static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
     w.xproj = a.take<float>((int64_t)B * 4 * E * L);
     w.memory = a.take<float>((int64_t)B * L * M);
     w.pm = a.take<float>((int64_t)B * L * 128);
-    w.pre = a.take<float>((int64_t)B * c.prenet_dim);
     w.pq = a.take<float>((int64_t)B * 128);
     w.energy = a.take<float>((int64_t)B * L);
-    for (int i = 0; i < 2; ++i) w.att_h[i] = a.take<float>((int64_t)B * c.attention_rnn_dim);
     w.att_c = a.take<float>((int64_t)B * c.attention_rnn_dim);
-    for (int i = 0; i < 2; ++i) w.dec_h[i] = a.take<float>((int64_t)B * c.decoder_rnn_dim);
     w.dec_c = a.take<float>((int64_t)B * c.decoder_rnn_dim);
-    w.aw = a.take<float>((int64_t)B * L);
-    w.aw_cum = a.take<float>((int64_t)B * L);
-    w.ctx = a.take<float>((int64_t)B * M);
     w.dec_in = a.take<float>((int64_t)B * c.n_mels);
+    {
+        int64_t o = 0;
+        auto sub = [&](int64_t n) { const int64_t r = o; o += align_up(n, 64); return (int)r; };
+        w.pre_o = sub((int64_t)B * c.prenet_dim);
+        w.h0_o = sub((int64_t)B * c.prenet_dim);
+        for (int i = 0; i < 2; ++i) w.att_h_o[i] = sub((int64_t)B * c.attention_rnn_dim);
+        for (int i = 0; i < 2; ++i) w.dec_h_o[i] = sub((int64_t)B * c.decoder_rnn_dim);
+        w.ctx_o = sub((int64_t)B * M);
+        w.aw_o = sub((int64_t)B * L);
+        w.cum_o = sub((int64_t)B * L);
+        w.epart_o = sub((int64_t)16 * B * L);
+        w.fin_o = sub(B);
+        w.slots_o = sub(256);
+        w.err_o = sub(1);
+        w.steps_o = sub(1);
+        w.xch_floats = o;
+        w.xch = a.take<float>(o);
+        float* x = w.xch;
+        w.pre = x ? x + w.pre_o : nullptr;
+        for (int i = 0; i < 2; ++i) w.att_h[i] = x ? x + w.att_h_o[i] : nullptr;
+        for (int i = 0; i < 2; ++i) w.dec_h[i] = x ? x + w.dec_h_o[i] : nullptr;
+        w.ctx = x ? x + w.ctx_o : nullptr;
+        w.aw = x ? x + w.aw_o : nullptr;
+        w.aw_cum = x ? x + w.cum_o : nullptr;
+    }
     w.post0 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
     w.post1 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
-    w.finished = a.take<int32_t>(B);
+    w.finished = w.xch ? reinterpret_cast<int32_t*>(w.xch + w.fin_o) : nullptr;
     w.step = a.take<int32_t>(1);
 }
 
@@ -744,17 +1265,82 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     hipLaunchKernelGGL(taco_pm_kernel, dim3(L, B), dim3(128), 0, s, w.memory, W + h->wmT, L, M, w.pm);
     TTS_CHECK_HIP(hipGetLastError());
     // ---- decoder state
-    TTS_CHECK_HIP(hipMemsetAsync(w.att_h[0], 0, (size_t)B * A * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0, (size_t)w.xch_floats * sizeof(float), s));   // h, ctx, alignment weights, prenet, stop flags, barrier slots
     TTS_CHECK_HIP(hipMemsetAsync(w.att_c, 0, (size_t)B * A * sizeof(float), s));
-    TTS_CHECK_HIP(hipMemsetAsync(w.dec_h[0], 0, (size_t)B * D * sizeof(float), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.dec_c, 0, (size_t)B * D * sizeof(float), s));
-    TTS_CHECK_HIP(hipMemsetAsync(w.aw, 0, (size_t)B * L * sizeof(float), s));
-    TTS_CHECK_HIP(hipMemsetAsync(w.aw_cum, 0, (size_t)B * L * sizeof(float), s));
-    TTS_CHECK_HIP(hipMemsetAsync(w.ctx, 0, (size_t)B * M * sizeof(float), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.dec_in, 0, (size_t)B * c.n_mels * sizeof(float), s));
-    TTS_CHECK_HIP(hipMemsetAsync(w.finished, 0, (size_t)B * sizeof(int32_t), s));
     TTS_CHECK_HIP(hipMemsetAsync(mel_lens, 0, (size_t)B * sizeof(int32_t), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.step, 0, sizeof(int32_t), s));
+    static const bool dbg = getenv("TTSAMD_TACO_DEBUG") != nullptr;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    int steps = 0;
+    bool done = false;
+    // ---- the persistent decoder (one cooperative launch for the whole loop) when the geometry fits its residency plan
+    {
+        const char* e = getenv("TTSAMD_TACO_PERSISTENT");
+        const bool want = e && e[0] == '1';      // opt-in while the exchange still bypasses L2 (65 us per step vs 57 on the graph path)
+        const int KS = c.attention_location_kernel_size, half = (KS - 1) / 2, PT = (B * L + 15) / 16;
+        const int MC = M / 32, NS = MC ? 256 / MC : 0, K4A = (P + M + A) / 4;
+        const size_t lds = (size_t)16 * K4A * 16 +
+                           sizeof(float) * ((size_t)L * MC + (size_t)PT * 8 + 16 * KS + 2 * (PT + 2 * half) + 256 + 128 + 64 + 256 + NS * MC + 16);
+        int dev_id = 0, n_cu = 0, coop = 0;
+        (void)hipGetDevice(&dev_id);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
+        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev_id);
+        const bool fits = want && B <= 8 && L <= 256 && (M == 512 || M == 640) && A == 1024 && D == 1024 && P == 256 && KS % 2 == 1 &&
+                          lds <= 160 * 1024 && n_cu >= 256 && coop && w.xch_floats * 4 < (int64_t)1 << 31;
+        if (e && e[0] == '1' && !fits) {
+            set_error("tacotron2_infer: TTSAMD_TACO_PERSISTENT=1 but batch %d / tokens %d / memory dim %d / %d CUs do not fit the persistent decoder", B, L, M, n_cu);
+            return TTSAMD_EINVAL;
+        }
+        if (fits) {
+            TacoPersist q;
+            q.pre1 = W + h->pre1;
+            q.att_wih = W + h->att_wih; q.att_whh = W + h->att_whh; q.att_b = W + h->att_b;
+            q.dec_wih = W + h->dec_wih; q.dec_whh = W + h->dec_whh; q.dec_b = W + h->dec_b;
+            q.wq = W + h->wq; q.loc_fold = W + h->loc_fold; q.v = W + h->v;
+            q.pm = w.pm; q.memory = w.memory;
+            q.projx_w = W + h->projx_w; q.projx_b = W + h->projx_b;
+            q.lens = lengths;
+            q.xch = w.xch; q.xch_bytes = (int)(w.xch_floats * 4);
+            q.pre_o = w.pre_o; q.h0_o = w.h0_o;
+            for (int i = 0; i < 2; ++i) { q.att_h_o[i] = w.att_h_o[i]; q.dec_h_o[i] = w.dec_h_o[i]; }
+            q.ctx_o = w.ctx_o; q.aw_o = w.aw_o; q.cum_o = w.cum_o; q.epart_o = w.epart_o; q.fin_o = w.fin_o;
+            q.slots_o = w.slots_o; q.err_o = w.err_o; q.steps_o = w.steps_o;
+            q.mel_out = mel_raw; q.align_out = alignments; q.mel_lens = mel_lens;
+            q.B = B; q.L = L; q.KS = KS; q.Tcap = Tcap; q.max_step = max_step; q.n_mels = c.n_mels;
+            q.thr = c.gate_threshold; q.seed = (long long)dropout_seed;
+            const void* fn = M == 512 ? (const void*)taco_decoder_persistent<512> : (const void*)taco_decoder_persistent<640>;
+            std::lock_guard<std::mutex> lock(h->mu);
+            TTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            void* args[] = {&q};
+            const double t0 = now_us();
+            TTS_CHECK_HIP(hipLaunchCooperativeKernel(fn, dim3(256), dim3(256), args, (unsigned)lds, s));
+            int32_t tail[2] = {0, 0};                                   // err_o and steps_o are 64 floats apart: two copies
+            TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.err_o, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            TTS_CHECK_HIP(hipMemcpyAsync(&tail[1], w.xch + w.steps_o, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            TTS_CHECK_HIP(hipStreamSynchronize(s));
+            if (dbg) fprintf(stderr, "[taco] persistent decoder: %.0f us for %d steps (%zu B of LDS per block)\n", now_us() - t0, (int)tail[1], lds);
+            if (tail[0] != 0) {
+                set_error("tacotron2_infer: the persistent decoder's grid barrier timed out (are 256 CUs free for it?)");
+                return TTSAMD_EHIP;
+            }
+            steps = tail[1];
+            done = true;
+            if (const char* dump = getenv("TTSAMD_TACO_DUMP")) {        // debugging aid: the decoder state after the loop
+                std::vector<float> hx((size_t)w.xch_floats);
+                TTS_CHECK_HIP(hipMemcpy(hx.data(), w.xch, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
+                if (FILE* f = fopen(dump, "wb")) {
+                    const int32_t hdr[16] = {B, L, M, steps, w.pre_o, w.h0_o, w.att_h_o[0], w.att_h_o[1], w.dec_h_o[0], w.dec_h_o[1],
+                                             w.ctx_o, w.aw_o, w.cum_o, w.epart_o, w.fin_o, (int32_t)w.xch_floats};
+                    fwrite(hdr, sizeof(hdr), 1, f);
+                    fwrite(hx.data(), sizeof(float), hx.size(), f);
+                    fclose(f);
+                }
+            }
+        }
+    }
+    if (!done) {
     // The loop is launch-bound when issued kernel by kernel (7 dependent launches of 4-14 us per step), so
     // 8 steps are captured once into a hipGraph (the step index lives in device memory and is advanced by the
     // graph's last node) and replayed.  The stop flags come back through pinned memory two replays late, so
@@ -776,8 +1362,6 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     TTS_CHECK_HIP(hipEventRecord(h->ev_in, caller));          // encoder + state resets were queued on the caller's stream
     s = h->loop_stream;
     TTS_CHECK_HIP(hipStreamWaitEvent(s, h->ev_in, 0));
-    static const bool dbg = getenv("TTSAMD_TACO_DEBUG") != nullptr;
-    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (dbg) (void)hipStreamSynchronize(s);
     const double t_cap0 = now_us();
     if (dbg) fprintf(stderr, "[taco] encoder + state reset (synced): %.0f us\n", t_cap0 - t_enter);
@@ -813,7 +1397,6 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         return TTSAMD_EHIP;
     }
     const double t_loop0 = now_us();
-    int steps = 0;
     hipError_t run_err = hipSuccess;
     for (int g = 0; steps < max_step && run_err == hipSuccess; ++g) {
         run_err = hipGraphLaunch(exec, s);
@@ -839,6 +1422,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         set_error("tacotron2_infer: decoder loop failed: %s", hipGetErrorString(run_err));
         return TTSAMD_EHIP;
     }
+    }   // graph path
     // number of frames the reference would have produced: it stops at the step the last utterance finishes
     std::vector<int32_t> lens_h(B);
     TTS_CHECK_HIP(hipMemcpyAsync(lens_h.data(), mel_lens, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
