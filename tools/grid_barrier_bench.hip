@@ -7,6 +7,18 @@
 #include <cstdlib>
 #include <vector>
 
+// (clang's __builtin_amdgcn_raw_buffer_load_b128 of ROCm 7.2 lowers to ONE dword load splatted over the vector: declare the LLVM intrinsics)
+typedef int bi4 __attribute__((ext_vector_type(4)));
+typedef float bf4 __attribute__((ext_vector_type(4)));
+__device__ bf4 bench_buffer_load_f4(bi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void bench_buffer_store_f1(float v, bi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ inline bi4 bench_rsrc(const void* p, int bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    bi4 r;
+    r.x = (int)(unsigned)a; r.y = (int)(unsigned)(a >> 32); r.z = bytes; r.w = 0x00020000;
+    return r;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 __device__ __forceinline__ bool grid_barrier(unsigned* cnt, unsigned target, int* err) {
@@ -144,11 +156,11 @@ __global__ __launch_bounds__(256) void barrier_loop(unsigned* cnt, int iters, fl
     }
     for (int it = 0; it < iters; ++it) {
         if (MODE == 1 && variant >= 2) {
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(xch + (size_t)(it & 1) * 8192, 0, 8192 * 4, 0x00020000);
+            const bi4 rs = bench_rsrc(xch + (size_t)(it & 1) * 8192, 8192 * 4);
             const float v = (float)((it & 15) + blockIdx.x);
             if (threadIdx.x < 32) {
-                if (variant != 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (blockIdx.x * 32 + threadIdx.x) * 4, 0, 16);
-                else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (blockIdx.x * 32 + threadIdx.x) * 4, 0, 17);
+                if (variant != 4) bench_buffer_store_f1(v, rs, (blockIdx.x * 32 + threadIdx.x) * 4, 0, 16);
+                else bench_buffer_store_f1(v, rs, (blockIdx.x * 32 + threadIdx.x) * 4, 0, 17);
             }
         } else if (MODE == 1) {
             float* dst = xch + (size_t)(it & 1) * 8192;
@@ -160,13 +172,12 @@ __global__ __launch_bounds__(256) void barrier_loop(unsigned* cnt, int iters, fl
                                       : grid_barrier_xcd(bar, (unsigned)(it + 1), xcc, pop, live, err, (unsigned)variant - 2u - (variant >= 5 ? 3u : 0u));
         if (!okb) return;
         if (MODE == 1 && variant >= 2) {
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(xch + (size_t)(it & 1) * 8192, 0, 8192 * 4, 0x00020000);
-            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const bi4 rs = bench_rsrc(xch + (size_t)(it & 1) * 8192, 8192 * 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const u4 r = variant != 4 ? __builtin_amdgcn_raw_buffer_load_b128(rs, (threadIdx.x + 256 * i) * 16, 0, 16)
-                                          : __builtin_amdgcn_raw_buffer_load_b128(rs, (threadIdx.x + 256 * i) * 16, 0, 17);
-                acc += __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y) + __builtin_bit_cast(float, r.z) + __builtin_bit_cast(float, r.w);
+                const bf4 r = variant != 4 ? bench_buffer_load_f4(rs, (threadIdx.x + 256 * i) * 16, 0, 16)
+                                           : bench_buffer_load_f4(rs, (threadIdx.x + 256 * i) * 16, 0, 17);
+                acc += r.x + r.y + r.z + r.w;
             }
         } else if (MODE == 1) {
             const float* src = xch + (size_t)(it & 1) * 8192;

@@ -32,15 +32,15 @@ def main():
         os.environ['TTSAMD_TACO_DUMP'] = '/tmp/taco_dump.bin'
         mel, ml, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=-1)
         raw = open('/tmp/taco_dump.bin', 'rb').read()
-        hdr = np.frombuffer(raw[:64], dtype=np.int32)
-        x = np.frombuffer(raw[64:], dtype=np.float32)
-        Bq, Lq, M, nst, pre_o, h0_o, a0, a1, d0, d1, ctx_o, aw_o, cum_o, ep_o, fin_o, n = hdr.tolist()
+        hdr = np.frombuffer(raw[:32], dtype=np.int32)
+        x = np.frombuffer(raw[32:], dtype=np.float32)
+        Bq, Lq, M, nst, Lp, PTp, stepf, _ = hdr.tolist()
         last = steps - 1
-        po = (last & 1) ^ 1
-        att_h = x[(a0, a1)[po]:][:B * 1024].reshape(B, 1024)
-        dec_h = x[(d0, d1)[po]:][:B * 1024].reshape(B, 1024)
-        ctx = x[ctx_o:][:B * M].reshape(B, M)
-        aw = x[aw_o:][:B * L].reshape(B, L)
+        att_h = x[0:8192].reshape(256, 8, 4).transpose(1, 0, 2).reshape(8, 1024)[:B]          # [block][utterance][unit]
+        dec_h = x[8192:16384].reshape(256, 8, 4).transpose(1, 0, 2).reshape(8, 1024)[:B]
+        mc = M // 32
+        ctx = x[16384:24576].reshape(8, 32, 32)[:B, :, :mc].reshape(B, M)
+        aw = x[34816:34816 + 8 * Lp].reshape(8, Lp)[:B, :L]
         hc = tr['hc'][last].numpy()
         print(f'steps {steps}: att_h {np.abs(att_h - tr["att_h"][last].numpy()).max():.2e}  dec_h {np.abs(dec_h - hc[:, :1024]).max():.2e} '
               f'ctx {np.abs(ctx - hc[:, 1024:]).max():.2e}  aw {np.abs(aw - al_ref[:, last].numpy()).max():.2e}  '

@@ -691,15 +691,30 @@ __global__ void taco_advance_kernel(int* step_base, int n) { *step_base += n; }
 struct TacoPersist {
     const float *pre1, *att_wih, *att_whh, *att_b, *dec_wih, *dec_whh, *dec_b, *wq, *loc_fold, *v, *pm, *memory, *projx_w, *projx_b;
     const int64_t* lens;
-    float* xch;
-    int xch_bytes;
-    int pre_o, h0_o, att_h_o[2], dec_h_o[2], ctx_o, aw_o, cum_o, epart_o, fin_o, slots_o, err_o, steps_o;
+    float* xch;                 // (max_step + 1) regions of `step_floats`, then the barrier slots / error flag / step count
+    int64_t tail_o;             // float offset of the tail (slots [256], err, steps)
+    int step_floats, Lp, PTp;   // region size; padded row / tile strides (multiples of 32 floats = one 128-byte line)
     float *mel_out, *align_out;
     int32_t* mel_lens;
     int B, L, KS, Tcap, max_step, n_mels;
     float thr;
     long long seed;
 };
+
+// One REGION of the exchange arena per decoder step.  Everything step s produces goes to region s + 1 (region 0 = the zero
+// initial state), so no address is ever read before its final value is in memory: the readers use ordinary L2-cached loads
+// (a first version read with sc1 loads that bypass L2 -- 256 blocks x 80-160 KB per phase through the fabric, 7-12 us per
+// phase) and only the STORES are device-coherent write-throughs.  Every 128-byte line has exactly one writer block
+// (layouts below), so no XCD's L2 ever holds a line that another XCD completes later.
+//   att_h, dec_h : [block 256][utterance 8][unit 4]        a reader's float4 column group g of utterance b = line g, +4 b
+//   ctx          : [utterance 8][column group 32][32]      (MC = 16 / 20 floats used per line)
+//   pre          : [unit group 64][utterance 8][unit 4]
+//   h0           : [unit 256][32]                          (8 utterances used)
+//   aw, cum      : [utterance 8][Lp]
+//   epart        : [attention-dim group 16][tile 16][PTp]
+//   fin          : [32]
+constexpr int TR_ATT = 0, TR_DEC = 8192, TR_CTX = 16384, TR_PRE = 24576, TR_H0 = 26624, TR_AW = 34816;
+__host__ __device__ inline int taco_region_floats(int Lp, int PTp) { return TR_AW + 16 * Lp + 256 * PTp + 32; }
 
 template <int M_>
 struct PGeo {
@@ -716,10 +731,14 @@ typedef float taco_f4 __attribute__((ext_vector_type(4)));
 __device__ taco_f4 taco_buffer_load_f4(taco_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float taco_buffer_load_f1(taco_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void taco_buffer_store_f1(float v, taco_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
-#define XLD(foff) taco_buffer_load_f1(rs, (foff) * 4, 0, 16)                      /* aux 16 = sc1: device scope */
-#define XST(foff, val) taco_buffer_store_f1((float)(val), rs, (foff) * 4, 0, 16)
-#define XLD4(dst, foff) { const taco_f4 r_ = taco_buffer_load_f4(rs, (foff) * 4, 0, 16); dst = make_float4(r_.x, r_.y, r_.z, r_.w); }
+#define XST(foff, val) taco_buffer_store_f1((float)(val), rs, (foff) * 4, 0, 16)      /* aux 16 = sc1: write-through, device scope */
+#define XLD4(dst, ptr) dst = *reinterpret_cast<const float4*>(ptr);
 
+typedef float taco_f2 __attribute__((ext_vector_type(2)));
+// two fp32 FMAs per instruction (v_pk_fma_f32): the accumulator pair holds the even-k and the odd-k partial sums
+__device__ __forceinline__ taco_f2 taco_pk_dot4(const taco_f4 w, const taco_f4 x, taco_f2 acc) {
+    return __builtin_elementwise_fma(w.zw, x.zw, __builtin_elementwise_fma(w.xy, x.xy, acc));
+}
 __device__ __forceinline__ float taco_dot4(const float4 w, const float4 x, float acc) {
     return fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, fmaf(w.w, x.w, acc))));
 }
@@ -791,13 +810,9 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
     float* sRed = sf;  sf += G::NS * G::MC;
     float* red = sf;   sf += 8;
     float* sV = sf;    sf += 8;
-    taco_i4 rs;                                                      // raw buffer over the exchange arena, offsets in bytes
-    {
-        const unsigned long long a = (unsigned long long)p.xch;
-        rs.x = (int)(unsigned)a; rs.y = (int)(unsigned)(a >> 32); rs.z = p.xch_bytes; rs.w = 0x00020000;
-    }
-    unsigned* slots = reinterpret_cast<unsigned*>(p.xch + p.slots_o);
-    int32_t* err = reinterpret_cast<int32_t*>(p.xch + p.err_o);
+    unsigned* slots = reinterpret_cast<unsigned*>(p.xch + p.tail_o);
+    int32_t* err = reinterpret_cast<int32_t*>(p.xch + p.tail_o + 256);
+    const int Lp = p.Lp, PTp = p.PTp, R_CUM = TR_AW + 8 * Lp, R_EP = TR_AW + 16 * Lp, R_FIN = R_EP + 256 * PTp;
 
     // ---------------- residency set-up (constant data: ordinary loads)
     const int u0 = bid * 4;                                          // hidden units of both cells
@@ -807,7 +822,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         sWa[i] = *reinterpret_cast<const float4*>(k < 256 + M_ ? p.att_wih + row * (256 + M_) + k : p.att_whh + row * 1024 + (k - 256 - M_));
     }
     const int hf = wid >> 1, tl = tid & 127;                         // wave pair hf owns gate rows 8 hf .. 8 hf + 7
-    float4 wd[8][G::NJD];
+    // decoder-cell weights: 8 rows x NJD float4 column groups per thread, parked in ACCUMULATION registers (the "a" constraint)
+    // and moved to a VGPR where they are used -- left to the register allocator they compete with the x operands in flight
+    float wd[8][G::NJD][4];
+#define TACO_ACC_PUT(dst, val) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(val))
+#define TACO_ACC_GET(dst, src) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dst) : "a"(src))
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int R = 8 * hf + r;
@@ -815,8 +834,12 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #pragma unroll
         for (int j = 0; j < G::NJD; ++j) {
             const int g = tl + 128 * j, k = 4 * min(g, G::K4D - 1);
-            const float4 wv = *reinterpret_cast<const float4*>(k < 1024 + M_ ? p.dec_wih + row * (1024 + M_) + k : p.dec_whh + row * 1024 + (k - 1024 - M_));
-            wd[r][j] = g < G::K4D ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 wv = *reinterpret_cast<const float4*>(k < 1024 + M_ ? p.dec_wih + row * (1024 + M_) + k : p.dec_whh + row * 1024 + (k - 1024 - M_));
+            if (g >= G::K4D) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            TACO_ACC_PUT(wd[r][j][0], wv.x);
+            TACO_ACC_PUT(wd[r][j][1], wv.y);
+            TACO_ACC_PUT(wd[r][j][2], wv.z);
+            TACO_ACC_PUT(wd[r][j][3], wv.w);
         }
     }
     const int g16 = bid & 15, tile = bid >> 4;                       // attention dims 8 g16 .. +7, energy tile
@@ -841,7 +864,6 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         wpB[j] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float biasA = p.projx_b[p.n_mels + 1 + bid], biasB = p.projx_b[min(bid, p.n_mels)];
-    const float w1 = p.pre1[(int64_t)bid * 256 + tid];               // prenet layer 2: row bid
     float ba[4], bd[4];                                              // gate biases of this thread's unit (threads < 32)
     {
         const int uu = (tid >> 3) & 3;
@@ -859,39 +881,62 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
     __syncthreads();
 
     for (int s = 0; s < p.max_step; ++s) {
-        const int pi = s & 1, po = pi ^ 1;
+        const float* prv = p.xch + (int64_t)s * p.step_floats;      // what step s - 1 left (region 0: zeros)
+        float* curw = p.xch + (int64_t)(s + 1) * p.step_floats;     // what this step produces
+        const float* cur = curw;
+#ifdef TP_TIMING
+        unsigned tstamp[13];
+        int tsi = 0;
+#define TP_STAMP() tstamp[tsi++] = (unsigned)wall_clock64();
+#else
+#define TP_STAMP()
+#endif
+        TP_STAMP()
+        taco_i4 rs;                                                  // raw buffer over this step's region: the coherent stores
+        {
+            const unsigned long long a = (unsigned long long)curw;
+            rs.x = (int)(unsigned)a; rs.y = (int)(unsigned)(a >> 32); rs.z = p.step_floats * 4; rs.w = 0x00020000;
+        }
         // ---------------- S1: attention LSTMCell on [pre | ctx | att_h]
 #if !(TP_SKIP & 1)
         {
             int vz = 0;
             asm volatile("" : "+v"(vz));                 // opaque zero: keeps the address arithmetic of this phase inside the
             (void)vz;                                    // step loop (hoisted out of it, it costs more registers than there are)
-#pragma unroll
+#pragma unroll 1
             for (int ps = 0; ps < 2; ++ps) {             // utterances 4 ps .. 4 ps + 3: 32 partial sums per thread at a time
                 int vp = 0;
                 asm volatile("" : "+v"(vp));             // (and keeps the two passes' LDS reads apart: merged, they hold 128 registers)
                 const int tlz = tl + vz + vp;
-                float v[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) v[i] = 0.f;
+                taco_f4 xs[G::NJA][4];                   // all of this pass's operands in flight at once: one memory round trip
 #pragma unroll
                 for (int j = 0; j < G::NJA; ++j) {
                     const int g = tlz + 128 * j, gc = min(g, G::K4A - 1), k = 4 * gc;
-                    float4 wa[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) wa[r] = sWa[(8 * hf + r) * G::K4A + gc];
-                    const int xbase = k < 256 ? p.pre_o + k : k < 256 + M_ ? p.ctx_o + (k - 256) : p.att_h_o[pi] + (k - 256 - M_);
-                    const int xstride = k < 256 ? 256 : k < 256 + M_ ? M_ : 1024;
+                    const int kc = k - 256, cgx = kc / G::MC;                                 // (ctx: column group, column)
+                    const int xbase = k < 256 ? TR_PRE + gc * 32 : k < 256 + M_ ? TR_CTX + cgx * 32 + (kc - cgx * G::MC) : TR_ATT + (gc - (256 + M_) / 4) * 32;
+                    const int xstride = k >= 256 && k < 256 + M_ ? 1024 : 4;
 #pragma unroll
                     for (int bq = 0; bq < 4; ++bq) {
-                        float4 xv;
-                        XLD4(xv, xbase + min(4 * ps + bq, B - 1) * xstride)
-                        if (g >= G::K4A) xv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r * 4 + bq] = taco_dot4(wa[r], xv, v[r * 4 + bq]);
+                        xs[j][bq] = *reinterpret_cast<const taco_f4*>(prv + xbase + min(4 * ps + bq, B - 1) * xstride);
+                        if (g >= G::K4A) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};
                     }
-                    __builtin_amdgcn_sched_barrier(0);   // one column group's loads in flight at a time: registers
                 }
+                taco_f2 vv[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) vv[i] = taco_f2{0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < G::NJA; ++j) {
+                    const int gc = min(tlz + 128 * j, G::K4A - 1);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(8 * hf + r) * G::K4A + gc]);
+#pragma unroll
+                        for (int bq = 0; bq < 4; ++bq) vv[r * 4 + bq] = taco_pk_dot4(wa, xs[j][bq], vv[r * 4 + bq]);
+                    }
+                }
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = vv[i].x + vv[i].y;
                 const float tot = taco_butterfly32(v, lane);
                 if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;   // [row][batch]
             }
@@ -903,11 +948,13 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;       // [half][unit (2)][gate (4)][batch (8)]
                 const float gi = gp[0] + ba[0], gf = gp[8] + ba[1], gg = gp[16] + ba[2], go = gp[24] + ba[3];
                 c_att = sigmoidf_(gf) * c_att + sigmoidf_(gi) * tanhf(gg);
-                if (bb < B) XST(p.att_h_o[po] + bb * 1024 + u0 + uu, sigmoidf_(go) * tanhf(c_att));
+                if (bb < B) XST(TR_ATT + bid * 32 + bb * 4 + uu, sigmoidf_(go) * tanhf(c_att));
             }
         }
 #endif
+        TP_STAMP()
         if (!taco_grid_barrier(slots, ++epoch, err)) return;
+        TP_STAMP()
 #if !(TP_SKIP & 2)
         // ---------------- S2+S3: processed query of this block's 8 attention dims, partial energies of its tile
         {
@@ -917,13 +964,13 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             float4 wq[8];                                // this block's 8 query rows (L2-resident constants, re-read per step)
 #pragma unroll
             for (int r = 0; r < 8; ++r) wq[r] = *reinterpret_cast<const float4*>(p.wq + (int64_t)(8 * g16 + r) * 1024 + 4 * tidz);
-#pragma unroll
+#pragma unroll 1
             for (int ps = 0; ps < 2; ++ps) {
                 float v[32];
 #pragma unroll
                 for (int bq = 0; bq < 4; ++bq) {
                     float4 xv;
-                    XLD4(xv, p.att_h_o[po] + min(4 * ps + bq, B - 1) * 1024 + 4 * tidz)
+                    XLD4(xv, cur + TR_ATT + tidz * 32 + min(4 * ps + bq, B - 1) * 4)
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r * 4 + bq] = fmaf(wq[r].x, xv.x, fmaf(wq[r].y, xv.y, fmaf(wq[r].z, xv.z, wq[r].w * xv.w)));
                 }
@@ -934,7 +981,8 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             for (int i = tid; i < nw; i += 256) {
                 const int fp = p0 - half + i;
                 const bool ok = fp >= 0 && fp < BL;
-                const float a = XLD(p.aw_o + (ok ? fp : 0)), c = XLD(p.cum_o + (ok ? fp : 0));
+                const int fb = ok ? fp / L : 0, fo = fb * Lp + (ok ? fp - fb * L : 0);
+                const float a = prv[TR_AW + fo], c = prv[R_CUM + fo];
                 sAw[i] = ok ? a : 0.f;
                 sCum[i] = ok ? c : 0.f;
             }
@@ -955,20 +1003,24 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 val += __shfl_xor(val, 1);
                 val += __shfl_xor(val, 2);
                 val += __shfl_xor(val, 4);
-                if (d == 0) XST(p.epart_o + g16 * BL + pp, val);
+                if (d == 0) XST(R_EP + (g16 * 16 + tile) * PTp + pair, val);
             }
         }
 #endif
+        TP_STAMP()
         if (!taco_grid_barrier(slots, ++epoch, err)) return;
+        TP_STAMP()
 #if !(TP_SKIP & 4)
         // ---------------- S4: masked softmax over the tokens of utterance b4, context columns cg MC .. +MC
         if (b4 < B) {
             const int t = tid;
             float e = -INFINITY;
             if (t < n4) {
+                const int pp = b4 * L + t, tp = pp / PT;
+                const float* ep = cur + R_EP + tp * PTp + (pp - tp * PT);
                 e = 0.f;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) e += XLD(p.epart_o + g * BL + b4 * L + t);
+                for (int g = 0; g < 16; ++g) e += ep[g * 16 * PTp];
             }
             float mx = e;
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -984,8 +1036,8 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             sW[t] = w;
             if (cg == 0 && t < L) {
                 cum += w;
-                XST(p.aw_o + b4 * L + t, w);
-                XST(p.cum_o + b4 * L + t, cum);
+                XST(TR_AW + b4 * Lp + t, w);
+                XST(R_CUM + b4 * Lp + t, cum);
                 if (s < p.Tcap) p.align_out[((int64_t)b4 * p.Tcap + s) * L + t] = w;
             }
             __syncthreads();
@@ -1000,36 +1052,51 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 float a = 0.f;
 #pragma unroll
                 for (int sl = 0; sl < G::NS; ++sl) a += sRed[sl * G::MC + tid];
-                XST(p.ctx_o + b4 * M_ + cg * G::MC + tid, a);
+                XST(TR_CTX + (b4 * 32 + cg) * 32 + tid, a);
             }
         }
 #endif
+        TP_STAMP()
         if (!taco_grid_barrier(slots, ++epoch, err)) return;
+        TP_STAMP()
 #if !(TP_SKIP & 8)
         // ---------------- S5: decoder LSTMCell on [att_h | ctx | dec_h], weights in registers
         {
             int vz = 0;
             asm volatile("" : "+v"(vz));
             const int tlz = tl + vz;
-#pragma unroll
+#pragma unroll 1
             for (int ps = 0; ps < 2; ++ps) {
-                float v[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) v[i] = 0.f;
+                taco_f4 xs[G::NJD][4];
 #pragma unroll
                 for (int j = 0; j < G::NJD; ++j) {
                     const int g = tlz + 128 * j, k = 4 * min(g, G::K4D - 1);
-                    const int xbase = k < 1024 ? p.att_h_o[po] + k : k < 1024 + M_ ? p.ctx_o + (k - 1024) : p.dec_h_o[pi] + (k - 1024 - M_);
-                    const int xstride = k >= 1024 && k < 1024 + M_ ? M_ : 1024;
+                    const int gk = k >> 2, kc = k - 1024, cgx = kc / G::MC;
+                    const bool rec = k >= 1024 + M_;                                      // the recurrent part comes from the previous step
+                    const float* xsrc = rec ? prv : cur;
+                    const int xbase = k < 1024 ? TR_ATT + gk * 32 : !rec ? TR_CTX + cgx * 32 + (kc - cgx * G::MC) : TR_DEC + (gk - (1024 + M_) / 4) * 32;
+                    const int xstride = k >= 1024 && !rec ? 1024 : 4;
 #pragma unroll
-                    for (int bq = 0; bq < 4; ++bq) {
-                        float4 xv;
-                        XLD4(xv, xbase + min(4 * ps + bq, B - 1) * xstride)
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r * 4 + bq] = taco_dot4(wd[r][j], xv, v[r * 4 + bq]);   // wd is zero past K4D
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int bq = 0; bq < 4; ++bq) xs[j][bq] = *reinterpret_cast<const taco_f4*>(xsrc + xbase + min(4 * ps + bq, B - 1) * xstride);
                 }
+                taco_f2 vv[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) vv[i] = taco_f2{0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < G::NJD; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        taco_f4 w;                                                         // zero past K4D
+                        TACO_ACC_GET(w.x, wd[r][j][0]);
+                        TACO_ACC_GET(w.y, wd[r][j][1]);
+                        TACO_ACC_GET(w.z, wd[r][j][2]);
+                        TACO_ACC_GET(w.w, wd[r][j][3]);
+#pragma unroll
+                        for (int bq = 0; bq < 4; ++bq) vv[r * 4 + bq] = taco_pk_dot4(w, xs[j][bq], vv[r * 4 + bq]);
+                    }
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = vv[i].x + vv[i].y;
                 const float tot = taco_butterfly32(v, lane);
                 if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
             }
@@ -1041,11 +1108,13 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;
                 const float gi = gp[0] + bd[0], gf = gp[8] + bd[1], gg = gp[16] + bd[2], go = gp[24] + bd[3];
                 c_dec = sigmoidf_(gf) * c_dec + sigmoidf_(gi) * tanhf(gg);
-                if (bb < B) XST(p.dec_h_o[po] + bb * 1024 + u0 + uu, sigmoidf_(go) * tanhf(c_dec));
+                if (bb < B) XST(TR_DEC + bid * 32 + bb * 4 + uu, sigmoidf_(go) * tanhf(c_dec));
             }
         }
 #endif
+        TP_STAMP()
         if (!taco_grid_barrier(slots, ++epoch, err)) return;
+        TP_STAMP()
 #if !(TP_SKIP & 16)
         // ---------------- S6: mel / gate row bid (< 81) and prenet layer-1 unit bid (folded) from [dec_h | ctx]
         {
@@ -1058,12 +1127,13 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int g = tidz + 256 * j, k = 4 * min(g, G::K4P - 1);
-                const int xbase = k < 1024 ? p.dec_h_o[po] + k : p.ctx_o + (k - 1024);
-                const int xstride = k < 1024 ? 1024 : M_;
+                const int kc = k - 1024, cgx = kc / G::MC;
+                const int xbase = k < 1024 ? TR_DEC + (k >> 2) * 32 : TR_CTX + cgx * 32 + (kc - cgx * G::MC);
+                const int xstride = k < 1024 ? 4 : 1024;
 #pragma unroll
                 for (int bb = 0; bb < 8; ++bb) {
                     float4 xv;
-                    XLD4(xv, xbase + min(bb, B - 1) * xstride)
+                    XLD4(xv, cur + xbase + min(bb, B - 1) * xstride)
                     acc[bb] = taco_dot4(wpA[j], xv, acc[bb]);                    // weights are zero past K4P
                     acc[8 + bb] = taco_dot4(wpB[j], xv, acc[8 + bb]);
                 }
@@ -1081,7 +1151,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 const int bb = tid;
                 float a = fmaxf(gates[bb] + biasA, 0.f);
                 if (p.seed >= 0) a *= taco_keep((unsigned)p.seed, 0u, (unsigned)(s + 1), (unsigned)bb, (unsigned)bid);
-                XST(p.h0_o + bb * 256 + bid, a);
+                XST(TR_H0 + bid * 32 + bb, a);
                 const float m = gates[8 + bb] + biasB;
                 if (bid < p.n_mels) {
                     p.mel_out[((int64_t)bb * p.n_mels + bid) * p.Tcap + s] = m;
@@ -1089,54 +1159,74 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                     if (!fin) mlen += 1;
                     if (sigmoidf_(m) > p.thr) fin = 1;
                     p.mel_lens[bb] = mlen;
-                    XST(p.fin_o + bb, __builtin_bit_cast(float, fin));
+                    XST(R_FIN + bb, __builtin_bit_cast(float, fin));
                 }
             }
         }
 #endif
+        TP_STAMP()
         if (!taco_grid_barrier(slots, ++epoch, err)) return;
+        TP_STAMP()
         {
             int all = 1;
-            for (int b = 0; b < B; ++b) all &= __builtin_bit_cast(int, XLD(p.fin_o + b)) != 0;
+            for (int b = 0; b < B; ++b) all &= __builtin_bit_cast(int, cur[R_FIN + b]) != 0;
             if (all) { steps = s + 1; break; }
         }
-        // ---------------- S7: prenet layer 2, unit bid (input of the next step's attention cell)
-        {
-            float pp[8];
+        // ---------------- S7: prenet layer 2, units 4 bid .. 4 bid + 3 on blocks 0..63 (input of the next step's attention cell)
+        if (bid < 64) {
+            float v[32];
+            float4 xa, xb;                                            // h0[utterance 0..7][unit tid]
+            XLD4(xa, cur + TR_H0 + tid * 32)
+            XLD4(xb, cur + TR_H0 + tid * 32 + 4)
+            const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) pp[bb] = w1 * XLD(p.h0_o + min(bb, B - 1) * 256 + tid);
+            for (int r = 0; r < 4; ++r) {
+                const float wr = p.pre1[(int64_t)(4 * bid + r) * 256 + tid];
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                float a = pp[bb];
-                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-                if (lane == 0) part[wid * 8 + bb] = a;
+                for (int bb = 0; bb < 8; ++bb) v[r * 8 + bb] = wr * xs[bb];
             }
+            const float tot = taco_butterfly32(v, lane);
+            if (!(lane & 1)) part[wid * 32 + (lane >> 1)] = tot;
             __syncthreads();
-            if (tid < 8 && tid < B) {
-                float a = fmaxf(part[tid] + part[8 + tid] + part[16 + tid] + part[24 + tid], 0.f);
-                if (p.seed >= 0) a *= taco_keep((unsigned)p.seed, 1u, (unsigned)(s + 1), (unsigned)tid, (unsigned)bid);
-                XST(p.pre_o + tid * 256 + bid, a);
+            if (tid < 32) {
+                const int r = tid >> 3, bb = tid & 7;
+                float a = fmaxf(part[tid] + part[32 + tid] + part[64 + tid] + part[96 + tid], 0.f);
+                if (p.seed >= 0) a *= taco_keep((unsigned)p.seed, 1u, (unsigned)(s + 1), (unsigned)bb, (unsigned)(4 * bid + r));
+                if (bb < B) XST(TR_PRE + bid * 32 + bb * 4 + r, a);
             }
         }
+        TP_STAMP()
         if (!taco_grid_barrier(slots, ++epoch, err)) return;
+        TP_STAMP()
+#ifdef TP_TIMING
+        if (tid == 0)
+            for (int i = 0; i < 13; ++i) curw[TR_H0 + bid * 32 + 8 + i] = __builtin_bit_cast(float, tstamp[i]);
+#endif
     }
-    if (bid == 0 && tid == 0) *reinterpret_cast<int32_t*>(p.xch + p.steps_o) = steps;
+    if (bid == 0 && tid == 0) *reinterpret_cast<int32_t*>(p.xch + p.tail_o + 320) = steps;
 }
-#undef XLD
 #undef XST
+#undef TACO_ACC_PUT
+#undef TACO_ACC_GET
 #undef XLD4
 
 // ------------------------------------------------------------------------------------ host
+
+// TTSAMD_TACO_PERSISTENT=1 selects the persistent decoder (opt-in: on the 8-XCD part its six grid barriers per step cost what
+// the seven kernel boundaries of the graph path cost); read per call
+static bool taco_persistent_wanted() {
+    const char* e = getenv("TTSAMD_TACO_PERSISTENT");
+    return e && e[0] == '1';
+}
 
 struct TWs {
     float *x0, *x1, *xproj, *memory, *pm, *pre, *pq, *energy, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
     float *post0, *post1;
     int32_t *finished, *step;
-    // the decoder state lives in ONE block (xch) so that the persistent decoder can address all of it through one buffer
-    // resource with cache-bypassing accesses; *_o are float offsets into it
+    // persistent decoder: exchange arena of (Tcap + 1) per-step regions + tail (barrier slots, error flag, step count)
     float* xch;
-    int64_t xch_floats;
-    int pre_o, h0_o, att_h_o[2], dec_h_o[2], ctx_o, aw_o, cum_o, epart_o, fin_o, slots_o, err_o, steps_o;
+    int64_t xch_floats, tail_o;
+    int step_floats, Lp, PTp;
 };
 
 static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
@@ -1152,34 +1242,22 @@ static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
     w.att_c = a.take<float>((int64_t)B * c.attention_rnn_dim);
     w.dec_c = a.take<float>((int64_t)B * c.decoder_rnn_dim);
     w.dec_in = a.take<float>((int64_t)B * c.n_mels);
-    {
-        int64_t o = 0;
-        auto sub = [&](int64_t n) { const int64_t r = o; o += align_up(n, 64); return (int)r; };
-        w.pre_o = sub((int64_t)B * c.prenet_dim);
-        w.h0_o = sub((int64_t)B * c.prenet_dim);
-        for (int i = 0; i < 2; ++i) w.att_h_o[i] = sub((int64_t)B * c.attention_rnn_dim);
-        for (int i = 0; i < 2; ++i) w.dec_h_o[i] = sub((int64_t)B * c.decoder_rnn_dim);
-        w.ctx_o = sub((int64_t)B * M);
-        w.aw_o = sub((int64_t)B * L);
-        w.cum_o = sub((int64_t)B * L);
-        w.epart_o = sub((int64_t)16 * B * L);
-        w.fin_o = sub(B);
-        w.slots_o = sub(256);
-        w.err_o = sub(1);
-        w.steps_o = sub(1);
-        w.xch_floats = o;
-        w.xch = a.take<float>(o);
-        float* x = w.xch;
-        w.pre = x ? x + w.pre_o : nullptr;
-        for (int i = 0; i < 2; ++i) w.att_h[i] = x ? x + w.att_h_o[i] : nullptr;
-        for (int i = 0; i < 2; ++i) w.dec_h[i] = x ? x + w.dec_h_o[i] : nullptr;
-        w.ctx = x ? x + w.ctx_o : nullptr;
-        w.aw = x ? x + w.aw_o : nullptr;
-        w.aw_cum = x ? x + w.cum_o : nullptr;
-    }
+    w.pre = a.take<float>((int64_t)B * c.prenet_dim);
+    for (int i = 0; i < 2; ++i) w.att_h[i] = a.take<float>((int64_t)B * c.attention_rnn_dim);
+    for (int i = 0; i < 2; ++i) w.dec_h[i] = a.take<float>((int64_t)B * c.decoder_rnn_dim);
+    w.aw = a.take<float>((int64_t)B * L);
+    w.aw_cum = a.take<float>((int64_t)B * L);
+    w.ctx = a.take<float>((int64_t)B * M);
+    w.finished = a.take<int32_t>(B);
+    w.Lp = (int)align_up(L, 32);
+    w.PTp = (int)align_up(((int64_t)std::min(B, 8) * L + 15) / 16, 32);
+    w.step_floats = taco_region_floats(w.Lp, w.PTp);
+    const bool persist_geo = taco_persistent_wanted() && B <= 8 && L <= 256;   // (taco_decoder_persistent's residency plan; else no arena)
+    w.tail_o = persist_geo ? (int64_t)(Tcap + 1) * w.step_floats : 0;
+    w.xch_floats = w.tail_o + 384;
+    w.xch = a.take<float>(w.xch_floats);
     w.post0 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
     w.post1 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
-    w.finished = w.xch ? reinterpret_cast<int32_t*>(w.xch + w.fin_o) : nullptr;
     w.step = a.take<int32_t>(1);
 }
 
@@ -1265,7 +1343,12 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     hipLaunchKernelGGL(taco_pm_kernel, dim3(L, B), dim3(128), 0, s, w.memory, W + h->wmT, L, M, w.pm);
     TTS_CHECK_HIP(hipGetLastError());
     // ---- decoder state
-    TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0, (size_t)w.xch_floats * sizeof(float), s));   // h, ctx, alignment weights, prenet, stop flags, barrier slots
+    TTS_CHECK_HIP(hipMemsetAsync(w.att_h[0], 0, (size_t)B * A * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.dec_h[0], 0, (size_t)B * D * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.aw, 0, (size_t)B * L * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.aw_cum, 0, (size_t)B * L * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.ctx, 0, (size_t)B * M * sizeof(float), s));
+    TTS_CHECK_HIP(hipMemsetAsync(w.finished, 0, (size_t)B * sizeof(int32_t), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.att_c, 0, (size_t)B * A * sizeof(float), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.dec_c, 0, (size_t)B * D * sizeof(float), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.dec_in, 0, (size_t)B * c.n_mels * sizeof(float), s));
@@ -1277,8 +1360,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     bool done = false;
     // ---- the persistent decoder (one cooperative launch for the whole loop) when the geometry fits its residency plan
     {
-        const char* e = getenv("TTSAMD_TACO_PERSISTENT");
-        const bool want = e && e[0] == '1';      // opt-in while the exchange still bypasses L2 (65 us per step vs 57 on the graph path)
+        const bool want = taco_persistent_wanted();
         const int KS = c.attention_location_kernel_size, half = (KS - 1) / 2, PT = (B * L + 15) / 16;
         const int MC = M / 32, NS = MC ? 256 / MC : 0, K4A = (P + M + A) / 4;
         const size_t lds = (size_t)16 * K4A * 16 +
@@ -1288,11 +1370,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev_id);
         const bool fits = want && B <= 8 && L <= 256 && (M == 512 || M == 640) && A == 1024 && D == 1024 && P == 256 && KS % 2 == 1 &&
-                          lds <= 160 * 1024 && n_cu >= 256 && coop && w.xch_floats * 4 < (int64_t)1 << 31;
-        if (e && e[0] == '1' && !fits) {
-            set_error("tacotron2_infer: TTSAMD_TACO_PERSISTENT=1 but batch %d / tokens %d / memory dim %d / %d CUs do not fit the persistent decoder", B, L, M, n_cu);
-            return TTSAMD_EINVAL;
-        }
+                          lds <= 160 * 1024 && n_cu >= 256 && coop && w.tail_o > 0;
         if (fits) {
             TacoPersist q;
             q.pre1 = W + h->pre1;
@@ -1302,23 +1380,21 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             q.pm = w.pm; q.memory = w.memory;
             q.projx_w = W + h->projx_w; q.projx_b = W + h->projx_b;
             q.lens = lengths;
-            q.xch = w.xch; q.xch_bytes = (int)(w.xch_floats * 4);
-            q.pre_o = w.pre_o; q.h0_o = w.h0_o;
-            for (int i = 0; i < 2; ++i) { q.att_h_o[i] = w.att_h_o[i]; q.dec_h_o[i] = w.dec_h_o[i]; }
-            q.ctx_o = w.ctx_o; q.aw_o = w.aw_o; q.cum_o = w.cum_o; q.epart_o = w.epart_o; q.fin_o = w.fin_o;
-            q.slots_o = w.slots_o; q.err_o = w.err_o; q.steps_o = w.steps_o;
+            q.xch = w.xch; q.tail_o = w.tail_o; q.step_floats = w.step_floats; q.Lp = w.Lp; q.PTp = w.PTp;
             q.mel_out = mel_raw; q.align_out = alignments; q.mel_lens = mel_lens;
             q.B = B; q.L = L; q.KS = KS; q.Tcap = Tcap; q.max_step = max_step; q.n_mels = c.n_mels;
             q.thr = c.gate_threshold; q.seed = (long long)dropout_seed;
             const void* fn = M == 512 ? (const void*)taco_decoder_persistent<512> : (const void*)taco_decoder_persistent<640>;
             std::lock_guard<std::mutex> lock(h->mu);
+            TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0, (size_t)w.step_floats * sizeof(float), s));                 // region 0: the zero initial state
+            TTS_CHECK_HIP(hipMemsetAsync(w.xch + w.tail_o, 0, 384 * sizeof(float), s));                        // barrier slots, error flag, step count
             TTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             void* args[] = {&q};
             const double t0 = now_us();
             TTS_CHECK_HIP(hipLaunchCooperativeKernel(fn, dim3(256), dim3(256), args, (unsigned)lds, s));
             int32_t tail[2] = {0, 0};                                   // err_o and steps_o are 64 floats apart: two copies
-            TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.err_o, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            TTS_CHECK_HIP(hipMemcpyAsync(&tail[1], w.xch + w.steps_o, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.tail_o + 256, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            TTS_CHECK_HIP(hipMemcpyAsync(&tail[1], w.xch + w.tail_o + 320, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             TTS_CHECK_HIP(hipStreamSynchronize(s));
             if (dbg) fprintf(stderr, "[taco] persistent decoder: %.0f us for %d steps (%zu B of LDS per block)\n", now_us() - t0, (int)tail[1], lds);
             if (tail[0] != 0) {
@@ -1327,12 +1403,11 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             }
             steps = tail[1];
             done = true;
-            if (const char* dump = getenv("TTSAMD_TACO_DUMP")) {        // debugging aid: the decoder state after the loop
-                std::vector<float> hx((size_t)w.xch_floats);
-                TTS_CHECK_HIP(hipMemcpy(hx.data(), w.xch, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
+            if (const char* dump = getenv("TTSAMD_TACO_DUMP")) {        // debugging aid: the region the last step produced
+                std::vector<float> hx((size_t)w.step_floats);
+                TTS_CHECK_HIP(hipMemcpy(hx.data(), w.xch + (int64_t)steps * w.step_floats, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
                 if (FILE* f = fopen(dump, "wb")) {
-                    const int32_t hdr[16] = {B, L, M, steps, w.pre_o, w.h0_o, w.att_h_o[0], w.att_h_o[1], w.dec_h_o[0], w.dec_h_o[1],
-                                             w.ctx_o, w.aw_o, w.cum_o, w.epart_o, w.fin_o, (int32_t)w.xch_floats};
+                    const int32_t hdr[8] = {B, L, M, steps, w.Lp, w.PTp, w.step_floats, 0};
                     fwrite(hdr, sizeof(hdr), 1, f);
                     fwrite(hx.data(), sizeof(float), hx.size(), f);
                     fclose(f);
