@@ -26,10 +26,11 @@ def main():
     raw = open('/tmp/taco_dump.bin', 'rb').read()
     x = np.frombuffer(raw[32:], dtype=np.uint32)
     st = x[26624:26624 + 8192].reshape(256, 32)[:, 8:21].astype(np.int64)
+    cyc = x[26624:26624 + 8192].reshape(256, 32)[:, 21].astype(np.int64)
     names = ['S1 att-lstm', 'bar1', 'S2/3 energies', 'bar2', 'S4 softmax+ctx', 'bar3', 'S5 dec-lstm', 'bar4', 'S6 proj', 'bar5', 'S7 prenet2', 'bar6']
     d = np.diff(st, axis=1) * 0.01           # us
     t0 = st[:, 0].min()
-    print('step length (block 0): %.2f us' % ((st[0, 12] - st[0, 0]) * 0.01))
+    print('step length (block 0): %.2f us, %d shader cycles -> %.0f MHz' % ((st[0, 12] - st[0, 0]) * 0.01, cyc[0], cyc[0] / ((st[0, 12] - st[0, 0]) * 0.01)))
     for i, n in enumerate(names):
         print(f'{n:16s} mean {d[:, i].mean():6.2f}  min {d[:, i].min():6.2f}  max {d[:, i].max():6.2f} us   (phase end spread over blocks: {(st[:, i + 1].max() - st[:, i + 1].min()) * 0.01:.2f} us)')
 

@@ -887,6 +887,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #ifdef TP_TIMING
         unsigned tstamp[13];
         int tsi = 0;
+        const unsigned long long tp_c0 = clock64();
 #define TP_STAMP() tstamp[tsi++] = (unsigned)wall_clock64();
 #else
 #define TP_STAMP()
@@ -1200,7 +1201,10 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         TP_STAMP()
 #ifdef TP_TIMING
         if (tid == 0)
+        {
             for (int i = 0; i < 13; ++i) curw[TR_H0 + bid * 32 + 8 + i] = __builtin_bit_cast(float, tstamp[i]);
+            curw[TR_H0 + bid * 32 + 21] = __builtin_bit_cast(float, (unsigned)(clock64() - tp_c0));      // shader-clock cycles of this step
+        }
 #endif
     }
     if (bid == 0 && tid == 0) *reinterpret_cast<int32_t*>(p.xch + p.tail_o + 320) = steps;
