@@ -2,7 +2,7 @@
 `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small`, with the calibration factors MEASURED in the conv
 engine's own access patterns (profiles/traffic_calib.py, tools/traffic_calib.hip; MI355X_MICROARCH.md's factor 2.0 for
 FETCH_SIZE is for 16 B/lane streaming reads), next to the ALGORITHMIC bytes of every launch
-    4 * (Cin * L + Cout * L * (1 + has_residual + accumulate))         (fused ResBlock pair: 4 * 32 * L * (2 + accumulate))
+    4 * (Cin * L + Cout * L * (1 + has_residual + accumulate))         (fused ResBlock pair: 4 * C * L * (2 + accumulate))
 taken from the library's own launch log (TTSAMD_CONV_LOG, launch order = dispatch order).
 usage: python profiles/traffic_from_pmc.py <fetch_dir> <write_dir> <conv_log.csv> <frames> [calib.json] > profiles/rN/traffic.json"""
 import csv
@@ -57,7 +57,7 @@ def main():
             K, cin, cout, nout, batch, has_res, mode, len_mul, ragged, n_phase = map(int, log[i][1:])
             L = frames * len_mul if ragged else nout * batch          # valid positions summed over the batch
             if kind == 'fused_pair':
-                alg = 4.0 * 32 * L * (2 + (mode != 0))
+                alg = 4.0 * cin * L * (2 + (mode != 0))
             else:
                 alg = 4.0 * (cin * L + cout * L * n_phase * (1 + has_res + (mode != 0)))
         key = f'{name} grid{grid}'

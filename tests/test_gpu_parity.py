@@ -648,7 +648,7 @@ def test_denoiser_rejects_utterances_of_at_most_512_samples(dev, hifigan_engine)
 
 def test_fused_pair_and_all_phase_convt_match_the_generic_engine(dev, synth_weights, hifigan_engine, monkeypatch):
     """Round-2 kernels against the generic MFMA conv engine they replace, same weights, ragged batch with a 1-frame and a
-    2-tile utterance: `resblock_pair_c32` (c1 -> c2 of the C = 32 stage in one launch, intermediate in LDS, halo recompute)
+    2-tile utterance: `resblock_pair<K, C>` (c1 -> c2 of the C = 32 stage, and of the C = 64 stage at k = 3, in one launch, intermediate in LDS, halo recompute)
     and `convt_mfma_f32` (all output phases of a transposed conv per wave).  Only the summation order differs (bias first,
     residual in the accumulator), so the waves agree far inside the waveform tolerance; each schedule is bit-reproducible."""
     rng = np.random.default_rng(21)

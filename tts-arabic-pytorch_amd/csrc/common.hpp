@@ -113,9 +113,9 @@ bool convt_supported(const ConvParams& p);
 int32_t launch_convt(const ConvParams& p, hipStream_t stream);
 // One launch for a c1 -> c2 pair of a C = 32 ResBlock1 with the intermediate in LDS (resblock_fused.hip); x != y.
 bool fused_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y);
-int32_t launch_fused_pair_c32(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
-                              int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
-                              int32_t mode, float div, float slope, hipStream_t stream);
+int32_t launch_fused_pair(int32_t channels, const float* x, float* y, const float* w1, const float* b1, const float* w2,
+                          const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
+                          int32_t mode, float div, float slope, hipStream_t stream);
 // Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]
 void pack_conv_weight(const float* w, int cout, int cin, int k, float* out);
 // torch ConvTranspose1d [Cin][Cout][Kt] (Kt = 2u, stride u, padding p) -> [u][Cin][2][CoutP]

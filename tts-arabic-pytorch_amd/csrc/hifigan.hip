@@ -366,19 +366,19 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
             for (int m = 0; m < cfg.n_dilations; ++m) {
                 const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
                 const int d = cfg.resblock_dilations[j][m];
-                // C = 32 stage, fp32: the c1 -> c2 pair in one launch with the intermediate in LDS (resblock_fused.hip);
+                // C = 32 stage (and k = 3 of the C = 64 stage), fp32: the c1 -> c2 pair in one launch with the intermediate in LDS (resblock_fused.hip);
                 // x and y must differ (halo reads), so the pair outputs alternate between R and the unused c1 buffer
                 {
                     const bool last = m + 1 == cfg.n_dilations;
                     float* dst = last ? cur : (src == R ? Tb : R);
                     const ConvW &w1 = h->c1[li], &w2 = h->c2[li];
-                    if (fused_ok && w1.cin == 32 && w1.cout == 32 && w2.cin == 32 && w2.cout == 32 && w1.k == w2.k &&
-                        fused_pair_supported(32, w1.k, d, L, src, dst)) {
+                    if (fused_ok && w1.cin == w1.cout && w2.cin == w1.cin && w2.cout == w1.cin && w1.k == w2.k &&
+                        fused_pair_supported(w1.cin, w1.k, d, L, src, dst)) {
                         const int mode = !last ? 0 : (cfg.n_kernels == 1 ? 0 : (j == 0 ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2)));
                         if (multi && last && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
-                        const double fl = 2.0 * (2.0 * 32 * 32 * w1.k) * mul;
+                        const double fl = 2.0 * (2.0 * w1.cin * w1.cin * w1.k) * mul;
                         if (in_section) prof_add(fl); else prof_begin(st, fl);
-                        const int32_t frc = launch_fused_pair_c32(src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
+                        const int32_t frc = launch_fused_pair(w1.cin, src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
                                                                   h->dev + w2.b_off, w1.k, d, lens, mul, L, B, mode,
                                                                   (float)cfg.n_kernels, 0.1f, st);
                         if (!in_section) prof_end(st);
