@@ -109,7 +109,8 @@ def _self_launch(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    for ln in out0.decode().splitlines():                       # stdout carries the ONE json line; library chatter (gloo) goes to stderr
+        print(ln, file=sys.stdout if ln.startswith('{') else sys.stderr)
     sys.stdout.flush()
     if any(rcs):
         print(f'bench.py: rank exit codes {rcs}', file=sys.stderr)
@@ -332,7 +333,7 @@ def main():
                                    f'{world}xMI355X', 'batch_per_gpu': B, 'n_tokens': Lt,
                        'frames_per_step_rank0': frames, 'parallelism': par, 'dp_transport': transport},
             'roofline': {'bound': 'mfma' if args.precision == 'f32' else 'hbm (fp32 activations; MFMA figures for reference)',
-                         'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair_c32 + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
+                         'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
                          'kernel_time_basis': 'HIP events on the launch stream: one pair per launch, one pair per fork..join section of the three-stream ResBlock schedule (wall time of the section)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
