@@ -50,7 +50,11 @@ struct FusedGeo {
     static constexpr int LDS4 = XT4 + 2 * WCH4;
     // prefetch distance in chunks (weights: register sets in flight; input octets): a k = 3 chunk is 24 MFMAs = 0.64 us,
     // shorter than one L2 / HBM round trip
+#ifdef TTS_FUSED_PF64
+    static constexpr int PFW = C > 32 ? TTS_FUSED_PF64 : (K <= 3 ? 3 : (K <= 7 ? 2 : 1));
+#else
     static constexpr int PFW = C > 32 ? (K <= 3 ? 2 : 1) : (K <= 3 ? 3 : (K <= 7 ? 2 : 1));
+#endif
     static constexpr int PFX = PFW;
     static_assert(C * 64 <= XT4, "the epilogue's [C][256] transposition buffer must fit in the input window");
 };
