@@ -255,11 +255,13 @@ def test_inference_cli_both_models(dev, taco_ckpt, tmp_path, synth_weights):
         inference.main(['--cpu'])
 
 
+@pytest.mark.parametrize('mode', ['1', '2'])
 @pytest.mark.parametrize('num_speakers,B,L,steps,seed', [(40, 3, 23, 20, -1), (1, 8, 64, 24, 7), (40, 1, 7, 9, 0)])
-def test_tacotron2_persistent_decoder_matches_oracle(dev, monkeypatch, num_speakers, B, L, steps, seed):
-    """TTSAMD_TACO_PERSISTENT=1: the whole decoder loop as one cooperative kernel (weights resident in LDS / registers, six
-    fence-free grid barriers per step, stop test on the device) against the oracle at the same tolerances as the graph
-    path, for both memory dims (640 multi-speaker, 512 single-speaker), with dropout on and off."""
+def test_tacotron2_persistent_decoder_matches_oracle(dev, monkeypatch, num_speakers, B, L, steps, seed, mode):
+    """TTSAMD_TACO_PERSISTENT=1 / 2: the whole decoder loop as one cooperative kernel (weights resident in LDS / registers,
+    stop test on the device) — 1: six fence-free grid barriers per step, 2: no barriers, consumers poll the words they need
+    (sentinel-filled arena) and the cells' big operands are folded in ahead — against the oracle at the same tolerances as
+    the graph path, for both memory dims (640 multi-speaker, 512 single-speaker), with dropout on and off."""
     import taco_oracle as T
     from ttsamd.engine import Tacotron2Engine
     cfg, sd = _weights(gate_bias=-20.0, num_speakers=num_speakers)
@@ -267,7 +269,7 @@ def test_tacotron2_persistent_decoder_matches_oracle(dev, monkeypatch, num_speak
     sids = torch.arange(B) % num_speakers if num_speakers > 1 else None
     mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=steps, seed=seed)
     eng = Tacotron2Engine(sd, cfg, device=dev)
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '1')
+    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
     monkeypatch.setenv('TTSAMD_TACO_DEBUG', '1')
     mel, mel_lens, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)
     assert mel_lens.cpu().tolist() == np.asarray(lens_ref).tolist() == [steps] * B
@@ -278,7 +280,8 @@ def test_tacotron2_persistent_decoder_matches_oracle(dev, monkeypatch, num_speak
     assert maxabs(mel, mel_g) < MEL_TOL and maxabs(al, al_g) < ALIGN_TOL
 
 
-def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch):
+@pytest.mark.parametrize('mode', ['1', '2'])
+def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch, mode):
     """the persistent decoder's device-side stop test: utterances finish at different steps, the loop ends with the last"""
     import taco_oracle as T
     from ttsamd.engine import Tacotron2Engine
@@ -288,7 +291,7 @@ def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch):
     stops = [12, 27, 5, 21]
     sd = _gate_for_stops(cfg, sd, tok, sids, lens, stops, max_step=40, seed=4)
     mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=40, seed=4)
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '1')
+    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
     mel, mel_lens, al = Tacotron2Engine(sd, cfg, device=dev).infer(tok, sids, lens, max_step=40, dropout_seed=4)
     assert mel_lens.cpu().tolist() == stops and mel.shape == mel_ref.shape
     assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL

@@ -789,7 +789,7 @@ __device__ __forceinline__ bool taco_grid_barrier(unsigned* slots, unsigned epoc
     return ok;
 }
 
-template <int M_>
+template <int M_, bool FLOW>
 __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist p) {
     using G = PGeo<M_>;
     extern __shared__ float4 taco_smem4[];
@@ -880,6 +880,484 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
     const int n4 = b4 < B ? min((int)p.lens[b4], L) : 0;
     __syncthreads();
 
+    if constexpr (FLOW) {
+    // ================= dataflow schedule: no grid barriers =================
+    // The arena is pre-filled with a sentinel bit pattern no arithmetic produces (0xFFFFFFFF); consumers poll the very words
+    // they need with device-coherent loads until none is the sentinel, so a hand-off costs one store -> visible -> load
+    // chain instead of barrier + fetch.  Only SMALL fresh inputs are ever polled on the critical path: the big operands of the
+    // two cells (previous h, context) were validated by this block in an earlier phase and their share of the gate sums is
+    // computed ahead, while the fresh input is still on its way ("early" / "late" halves of a cell).
+    constexpr unsigned SENT = 0xFFFFFFFFu;
+    constexpr int POLL_LIM = 1 << 15;
+#ifndef TACO_POLL_SLEEP
+#define TACO_POLL_SLEEP 8
+#endif
+#define TACO_BACKOFF __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);   /* between polls: the fabric carries everybody's polls AND the stores they wait for */
+    bool bad = false;
+#define TACO_OK4(v) (__builtin_bit_cast(unsigned, (v).x) != SENT && __builtin_bit_cast(unsigned, (v).y) != SENT && \
+                     __builtin_bit_cast(unsigned, (v).z) != SENT && __builtin_bit_cast(unsigned, (v).w) != SENT)
+#define TACO_RSRC(rs_, base_) { const unsigned long long a_ = (unsigned long long)(base_); rs_.x = (int)(unsigned)a_; \
+                                rs_.y = (int)(unsigned)(a_ >> 32); rs_.z = p.step_floats * 4; rs_.w = 0x00020000; }
+#define TACO_LD4(rs_, foff_) taco_buffer_load_f4(rs_, (foff_) * 4, 0, 16)
+#define TACO_LD1(rs_, foff_) taco_buffer_load_f1(rs_, (foff_) * 4, 0, 16)
+    float* gE1 = sf;  sf += 128;                                     // early halves of the two cells' gate sums [half][unit][gate][batch]
+    float* gE5 = sf;  sf += 128;
+
+    // early half of the attention cell for the step that reads region `rq` as its "previous" state: [ctx | att_h] columns
+#define TACO_S1_EARLY(rq)                                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                                                      \
+        int vp = 0;                                                                                                         \
+        asm volatile("" : "+v"(vp));                                                                                        \
+        const int tlz = tl + vp;                                                                                            \
+        taco_f4 xs[G::NJA][4];                                                                                              \
+        for (int spin = 0;; ++spin) {                                                                                       \
+            bool okv = true;                                                                                                \
+            _Pragma("unroll") for (int j = 0; j < G::NJA; ++j) {                                                            \
+                const int g = tlz + 128 * j, gc = min(g, G::K4A - 1), k = 4 * gc;                                           \
+                const int kc = k - 256, cgx = kc / G::MC;                                                                   \
+                const int xbase = k < 256 + M_ ? TR_CTX + cgx * 32 + (kc - cgx * G::MC) : TR_ATT + (gc - (256 + M_) / 4) * 32; \
+                const int xstride = k < 256 + M_ ? 1024 : 4;                                                                \
+                const bool use = g >= 64 && g < G::K4A;                           /* groups 0..63 are the prenet columns */ \
+                _Pragma("unroll") for (int bq = 0; bq < 4; ++bq) {                                                          \
+                    xs[j][bq] = TACO_LD4(rq, use ? xbase + min(4 * ps + bq, B - 1) * xstride : TR_CTX);                     \
+                    okv = okv && (!use || TACO_OK4(xs[j][bq]));                                                             \
+                    if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};                                                      \
+                }                                                                                                           \
+            }                                                                                                               \
+            if (okv) break;                                                                                                 \
+            if (spin > POLL_LIM) { bad = true; break; }                                                                     \
+            TACO_BACKOFF                                                                                                    \
+        }                                                                                                                   \
+        taco_f2 vv[32];                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 32; ++i) vv[i] = taco_f2{0.f, 0.f};                                           \
+        _Pragma("unroll") for (int j = 0; j < G::NJA; ++j) {                                                                \
+            const int gc = min(tlz + 128 * j, G::K4A - 1);                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                                 \
+                const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(8 * hf + r) * G::K4A + gc]);                     \
+                _Pragma("unroll") for (int bq = 0; bq < 4; ++bq) vv[r * 4 + bq] = taco_pk_dot4(wa, xs[j][bq], vv[r * 4 + bq]); \
+            }                                                                                                               \
+        }                                                                                                                   \
+        float v[32];                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 32; ++i) v[i] = vv[i].x + vv[i].y;                                            \
+        const float tot = taco_butterfly32(v, lane);                                                                        \
+        if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;                               \
+    }                                                                                                                       \
+    __syncthreads();                                                                                                        \
+    if (tid < 128) gE1[tid] = part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)];               \
+    __syncthreads();
+
+    taco_i4 rs0;
+    TACO_RSRC(rs0, p.xch)
+    TACO_S1_EARLY(rs0)                                               // step 0: zero state
+    for (int s = 0; s < p.max_step; ++s) {
+        float* curw = p.xch + (int64_t)(s + 1) * p.step_floats;
+        taco_i4 rs, rq;                                              // this step's region (stores, fresh reads); the previous step's
+        TACO_RSRC(rs, curw)
+        TACO_RSRC(rq, p.xch + (int64_t)s * p.step_floats)
+        // ---------------- stop test of the previous step (the gate block's flags travel with its prenet hand-off)
+        if (s > 0) {
+            int all = 1;
+            for (int spin = 0;; ++spin) {
+                bool okv = true;
+                all = 1;
+                for (int b = 0; b < B; ++b) {
+                    const unsigned f = __builtin_bit_cast(unsigned, TACO_LD1(rq, R_FIN + b));
+                    okv = okv && f != SENT;
+                    all &= f != 0u;
+                }
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; all = 0; break; }
+                TACO_BACKOFF
+            }
+            if (all) { steps = s; break; }
+        }
+        // ---------------- S1 late: the prenet columns of the attention cell, gates, new att_h
+        {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                int vp = 0;
+                asm volatile("" : "+v"(vp));             // opaque zero: keeps this phase's address arithmetic out of the step loop's preheader
+                const int tl = (tid & 127) + vp;
+                taco_f4 xp[4];
+                const bool use = tl < 64;
+                for (int spin = 0;; ++spin) {
+                    bool okv = true;
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        xp[bq] = TACO_LD4(rq, TR_PRE + (use ? tl : 0) * 32 + min(4 * ps + bq, B - 1) * 4);
+                        okv = okv && (!use || TACO_OK4(xp[bq]));
+                    }
+                    if (okv) break;
+                    if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+                }
+                float v[32];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float4 wa = sWa[(8 * hf + r) * G::K4A + (tl & 63)];
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        const float4 xv = use ? make_float4(xp[bq].x, xp[bq].y, xp[bq].z, xp[bq].w) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[r * 4 + bq] = taco_dot4(wa, xv, 0.f);
+                    }
+                }
+                const float tot = taco_butterfly32(v, lane);
+                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+            }
+            __syncthreads();
+            if (tid < 128) gates[tid] = gE1[tid] + (part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)]);
+            __syncthreads();
+            if (tid < 32) {
+                const int uu = tid >> 3, bb = tid & 7;
+                const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;
+                const float gi = gp[0] + ba[0], gf = gp[8] + ba[1], gg = gp[16] + ba[2], go = gp[24] + ba[3];
+                c_att = sigmoidf_(gf) * c_att + sigmoidf_(gi) * tanhf(gg);
+                if (bb < B) XST(TR_ATT + bid * 32 + bb * 4 + uu, sigmoidf_(go) * tanhf(c_att));
+            }
+        }
+        // ---------------- S2+S3: query rows of this block, partial energies of its tile
+        {
+            int vp = 0;
+            asm volatile("" : "+v"(vp));
+            const int tid = (int)threadIdx.x + vp;
+            taco_f4 xa[8];
+            for (int spin = 0;; ++spin) {
+                bool okv = true;
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    xa[bb] = TACO_LD4(rs, TR_ATT + tid * 32 + min(bb, B - 1) * 4);
+                    okv = okv && TACO_OK4(xa[bb]);
+                }
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+            }
+            float4 wq[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) wq[r] = *reinterpret_cast<const float4*>(p.wq + (int64_t)(8 * g16 + r) * 1024 + 4 * tid);
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                float v[32];
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) {
+                    const taco_f4 xv = xa[4 * ps + bq];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r * 4 + bq] = fmaf(wq[r].x, xv.x, fmaf(wq[r].y, xv.y, fmaf(wq[r].z, xv.z, wq[r].w * xv.w)));
+                }
+                const float tot = taco_butterfly32(v, lane);
+                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+            }
+            const int nw = (p1 - p0) + 2 * half;
+            for (int i = tid; i < nw; i += 256) {
+                const int fp = p0 - half + i;
+                const bool ok = fp >= 0 && fp < BL;
+                const int fb = ok ? fp / L : 0, fo = fb * Lp + (ok ? fp - fb * L : 0);
+                float a = 0.f, c = 0.f;
+                for (int spin = 0;; ++spin) {
+                    a = TACO_LD1(rq, TR_AW + fo);
+                    c = TACO_LD1(rq, R_CUM + fo);
+                    if (__builtin_bit_cast(unsigned, a) != SENT && __builtin_bit_cast(unsigned, c) != SENT) break;
+                    if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+                }
+                sAw[i] = ok ? a : 0.f;
+                sCum[i] = ok ? c : 0.f;
+            }
+            __syncthreads();
+            if (tid < 64) sPq[tid] = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
+            __syncthreads();
+            for (int it = tid; it < (p1 - p0) * 8; it += 256) {
+                const int pair = it >> 3, d = it & 7, pp = p0 + pair, b = pp / L, t = pp - b * L;
+                const float* gd = sG + d * 2 * KS;
+                float loc = 0.f;
+                for (int k = 0; k < KS; ++k) {
+                    const int tt = t + k - half;
+                    const bool ok = tt >= 0 && tt < L;
+                    loc = fmaf(gd[k], ok ? sAw[pair + k] : 0.f, loc);
+                    loc = fmaf(gd[KS + k], ok ? sCum[pair + k] : 0.f, loc);
+                }
+                float val = sV[d] * tanhf(sPq[d * 8 + b] + loc + sPm[pair * 8 + d]);
+                val += __shfl_xor(val, 1);
+                val += __shfl_xor(val, 2);
+                val += __shfl_xor(val, 4);
+                if (d == 0) XST(R_EP + (g16 * 16 + tile) * PTp + pair, val);
+            }
+        }
+        // ---------------- S5 early: [att_h | dec_h] columns of the decoder cell (both already complete in memory)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            int vp = 0;
+            asm volatile("" : "+v"(vp));
+            const int tlz = tl + vp;
+            taco_f4 xs[G::NJD][4];
+            for (int spin = 0;; ++spin) {
+                bool okv = true;
+#pragma unroll
+                for (int j = 0; j < G::NJD; ++j) {
+                    const int g = tlz + 128 * j, k = 4 * min(g, G::K4D - 1), gk = k >> 2;
+                    const bool isctx = k >= 1024 && k < 1024 + M_, rec = k >= 1024 + M_;
+                    const bool use = !isctx && g < G::K4D;
+                    const int xbase = rec ? TR_DEC + (gk - (1024 + M_) / 4) * 32 : TR_ATT + min(gk, 255) * 32;
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        const int off = xbase + min(4 * ps + bq, B - 1) * 4;
+                        xs[j][bq] = rec ? TACO_LD4(rq, off) : TACO_LD4(rs, off);
+                        okv = okv && (!use || TACO_OK4(xs[j][bq]));
+                        if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+            }
+            taco_f2 vv[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) vv[i] = taco_f2{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < G::NJD; ++j)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    taco_f4 w;
+                    TACO_ACC_GET(w.x, wd[r][j][0]);
+                    TACO_ACC_GET(w.y, wd[r][j][1]);
+                    TACO_ACC_GET(w.z, wd[r][j][2]);
+                    TACO_ACC_GET(w.w, wd[r][j][3]);
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) vv[r * 4 + bq] = taco_pk_dot4(w, xs[j][bq], vv[r * 4 + bq]);
+                }
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = vv[i].x + vv[i].y;
+            const float tot = taco_butterfly32(v, lane);
+            if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+        }
+        __syncthreads();
+        if (tid < 128) gE5[tid] = part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)];
+        __syncthreads();
+        // ---------------- S4: masked softmax over the tokens of utterance b4, context columns cg MC .. +MC
+        if (b4 < B) {
+            const int t = tid;
+            float e = -INFINITY;
+            if (t < n4) {
+                const int pp = b4 * L + t, tp = pp / PT;
+                const int eo = R_EP + tp * PTp + (pp - tp * PT);
+                float ev[16];
+                for (int spin = 0;; ++spin) {
+                    bool okv = true;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        ev[g] = TACO_LD1(rs, eo + g * 16 * PTp);
+                        okv = okv && __builtin_bit_cast(unsigned, ev[g]) != SENT;
+                    }
+                    if (okv) break;
+                    if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+                }
+                e = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) e += ev[g];
+            }
+            float mx = e;
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0) red[wid] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const float pr = t < n4 ? expf(e - mx) : 0.f;
+            float sm = pr;
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            if (lane == 0) red[4 + wid] = sm;
+            __syncthreads();
+            const float w = pr * (1.0f / (red[4] + red[5] + red[6] + red[7]));
+            sW[t] = w;
+            if (cg == 0 && t < L) {
+                cum += w;
+                XST(TR_AW + b4 * Lp + t, w);
+                XST(R_CUM + b4 * Lp + t, cum);
+                if (s < p.Tcap) p.align_out[((int64_t)b4 * p.Tcap + s) * L + t] = w;
+            }
+            __syncthreads();
+            if (tid < G::MC * G::NS) {
+                const int col = tid % G::MC, sl = tid / G::MC;
+                float a = 0.f;
+                for (int t2 = sl; t2 < n4; t2 += G::NS) a = fmaf(sW[t2], sMem[t2 * G::MC + col], a);
+                sRed[sl * G::MC + col] = a;
+            }
+            __syncthreads();
+            if (tid < G::MC) {
+                float a = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < G::NS; ++sl) a += sRed[sl * G::MC + tid];
+                XST(TR_CTX + (b4 * 32 + cg) * 32 + tid, a);
+            }
+        }
+        __syncthreads();
+        // ---------------- S5 late: the context columns of the decoder cell, gates, new dec_h
+        {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                int vp = 0;
+                asm volatile("" : "+v"(vp));
+                const int tl = (tid & 127) + vp;
+                taco_f4 xs[G::NJD][4];
+                for (int spin = 0;; ++spin) {
+                    bool okv = true;
+#pragma unroll
+                    for (int j = 0; j < G::NJD; ++j) {
+                        const int g = tl + 128 * j, k = 4 * min(g, G::K4D - 1), kc = k - 1024, cgx = kc / G::MC;
+                        const bool use = k >= 1024 && k < 1024 + M_ && g < G::K4D;
+                        if ((128 * j + 127) * 4 < 1024 || 128 * j * 4 >= 1024 + M_) continue;          // no context column in this group set
+#pragma unroll
+                        for (int bq = 0; bq < 4; ++bq) {
+                            xs[j][bq] = TACO_LD4(rs, use ? TR_CTX + cgx * 32 + (kc - cgx * G::MC) + min(4 * ps + bq, B - 1) * 1024 : TR_CTX);
+                            okv = okv && (!use || TACO_OK4(xs[j][bq]));
+                            if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                    if (okv) break;
+                    if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+                }
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < G::NJD; ++j) {
+                    if ((128 * j + 127) * 4 < 1024 || 128 * j * 4 >= 1024 + M_) continue;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float4 w;
+                        TACO_ACC_GET(w.x, wd[r][j][0]);
+                        TACO_ACC_GET(w.y, wd[r][j][1]);
+                        TACO_ACC_GET(w.z, wd[r][j][2]);
+                        TACO_ACC_GET(w.w, wd[r][j][3]);
+#pragma unroll
+                        for (int bq = 0; bq < 4; ++bq)
+                            v[r * 4 + bq] = taco_dot4(w, make_float4(xs[j][bq].x, xs[j][bq].y, xs[j][bq].z, xs[j][bq].w), v[r * 4 + bq]);
+                    }
+                }
+                const float tot = taco_butterfly32(v, lane);
+                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+            }
+            __syncthreads();
+            if (tid < 128) gates[tid] = gE5[tid] + (part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)]);
+            __syncthreads();
+            if (tid < 32) {
+                const int uu = tid >> 3, bb = tid & 7;
+                const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;
+                const float gi = gp[0] + bd[0], gf = gp[8] + bd[1], gg = gp[16] + bd[2], go = gp[24] + bd[3];
+                c_dec = sigmoidf_(gf) * c_dec + sigmoidf_(gi) * tanhf(gg);
+                if (bb < B) XST(TR_DEC + bid * 32 + bb * 4 + uu, sigmoidf_(go) * tanhf(c_dec));
+            }
+        }
+        __syncthreads();
+        // ---------------- S6: mel / gate row bid (< 81) and prenet layer-1 unit bid (folded) from [dec_h | ctx]
+        {
+            int vp = 0;
+            asm volatile("" : "+v"(vp));
+            const int tid = (int)threadIdx.x + vp;
+            taco_f4 xs[2][8];
+            for (int spin = 0;; ++spin) {
+                bool okv = true;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int g = tid + 256 * j, k = 4 * min(g, G::K4P - 1), kc = k - 1024, cgx = kc / G::MC;
+                    const int xbase = k < 1024 ? TR_DEC + (k >> 2) * 32 : TR_CTX + cgx * 32 + (kc - cgx * G::MC);
+                    const int xstride = k < 1024 ? 4 : 1024;
+#pragma unroll
+                    for (int bb = 0; bb < 8; ++bb) {
+                        xs[j][bb] = TACO_LD4(rs, xbase + min(bb, B - 1) * xstride);
+                        okv = okv && TACO_OK4(xs[j][bb]);
+                    }
+                }
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+            }
+            float acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const float4 xv = make_float4(xs[j][bb].x, xs[j][bb].y, xs[j][bb].z, xs[j][bb].w);
+                    acc[bb] = taco_dot4(wpA[j], xv, acc[bb]);                    // weights are zero past K4P
+                    acc[8 + bb] = taco_dot4(wpB[j], xv, acc[8 + bb]);
+                }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float a = acc[i];
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                if (lane == 0) part[wid * 16 + i] = a;
+            }
+            __syncthreads();
+            if (tid < 16) gates[tid] = part[tid] + part[16 + tid] + part[32 + tid] + part[48 + tid];
+            __syncthreads();
+            if (tid < 8 && tid < B) {
+                const int bb = tid;
+                float a = fmaxf(gates[bb] + biasA, 0.f);
+                if (p.seed >= 0) a *= taco_keep((unsigned)p.seed, 0u, (unsigned)(s + 1), (unsigned)bb, (unsigned)bid);
+                XST(TR_H0 + bid * 32 + bb, a);
+                const float m = gates[8 + bb] + biasB;
+                if (bid < p.n_mels) {
+                    p.mel_out[((int64_t)bb * p.n_mels + bid) * p.Tcap + s] = m;
+                } else if (bid == p.n_mels) {
+                    if (!fin) mlen += 1;
+                    if (sigmoidf_(m) > p.thr) fin = 1;
+                    p.mel_lens[bb] = mlen;
+                    XST(R_FIN + bb, __builtin_bit_cast(float, fin));
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- S7: prenet layer 2, units 4 bid .. 4 bid + 3 on blocks 0..63
+        if (bid < 64) {
+            int vp = 0;
+            asm volatile("" : "+v"(vp));
+            const int tid = (int)threadIdx.x + vp;
+            taco_f4 xa, xb;
+            for (int spin = 0;; ++spin) {
+                xa = TACO_LD4(rs, TR_H0 + tid * 32);
+                xb = TACO_LD4(rs, TR_H0 + tid * 32 + 4);
+                bool okv = true;                                      // (utterances >= B of a line are never written)
+                const float xs8[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) okv = okv && (bb >= B || __builtin_bit_cast(unsigned, xs8[bb]) != SENT);
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+            }
+            const float xs8[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            float v[32];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float wr = p.pre1[(int64_t)(4 * bid + r) * 256 + tid];
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) v[r * 8 + bb] = wr * xs8[min(bb, B - 1)];
+            }
+            const float tot = taco_butterfly32(v, lane);
+            if (!(lane & 1)) part[wid * 32 + (lane >> 1)] = tot;
+            __syncthreads();
+            if (tid < 32) {
+                const int r = tid >> 3, bb = tid & 7;
+                float a = fmaxf(part[tid] + part[32 + tid] + part[64 + tid] + part[96 + tid], 0.f);
+                if (p.seed >= 0) a *= taco_keep((unsigned)p.seed, 1u, (unsigned)(s + 1), (unsigned)bb, (unsigned)(4 * bid + r));
+                if (bb < B) XST(TR_PRE + bid * 32 + bb * 4 + r, a);
+            }
+        }
+        // ---------------- S1 early of the next step (context and att_h of this step are complete in memory)
+        TACO_S1_EARLY(rs)
+        if (__syncthreads_or(bad)) {
+            if (tid == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+#undef TACO_S1_EARLY
+#undef TACO_OK4
+#undef TACO_RSRC
+#undef TACO_LD4
+#undef TACO_LD1
+    } else {
     for (int s = 0; s < p.max_step; ++s) {
         const float* prv = p.xch + (int64_t)s * p.step_floats;      // what step s - 1 left (region 0: zeros)
         float* curw = p.xch + (int64_t)(s + 1) * p.step_floats;     // what this step produces
@@ -1207,6 +1685,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         }
 #endif
     }
+    }   // barrier schedule
     if (bid == 0 && tid == 0) *reinterpret_cast<int32_t*>(p.xch + p.tail_o + 320) = steps;
 }
 #undef XST
@@ -1218,10 +1697,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 
 // TTSAMD_TACO_PERSISTENT=1 selects the persistent decoder (opt-in: on the 8-XCD part its six grid barriers per step cost what
 // the seven kernel boundaries of the graph path cost); read per call
-static bool taco_persistent_wanted() {
+static int taco_persistent_mode() {          // 0 graph path, 1 persistent kernel with grid barriers, 2 persistent kernel, dataflow hand-offs
     const char* e = getenv("TTSAMD_TACO_PERSISTENT");
-    return e && e[0] == '1';
+    return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
 }
+static bool taco_persistent_wanted() { return taco_persistent_mode() != 0; }
 
 struct TWs {
     float *x0, *x1, *xproj, *memory, *pm, *pre, *pq, *energy, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
@@ -1368,7 +1848,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         const int KS = c.attention_location_kernel_size, half = (KS - 1) / 2, PT = (B * L + 15) / 16;
         const int MC = M / 32, NS = MC ? 256 / MC : 0, K4A = (P + M + A) / 4;
         const size_t lds = (size_t)16 * K4A * 16 +
-                           sizeof(float) * ((size_t)L * MC + (size_t)PT * 8 + 16 * KS + 2 * (PT + 2 * half) + 256 + 128 + 64 + 256 + NS * MC + 16);
+                           sizeof(float) * ((size_t)L * MC + (size_t)PT * 8 + 16 * KS + 2 * (PT + 2 * half) + 256 + 128 + 64 + 256 + NS * MC + 16 + 256);
         int dev_id = 0, n_cu = 0, coop = 0;
         (void)hipGetDevice(&dev_id);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
@@ -1388,8 +1868,12 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             q.mel_out = mel_raw; q.align_out = alignments; q.mel_lens = mel_lens;
             q.B = B; q.L = L; q.KS = KS; q.Tcap = Tcap; q.max_step = max_step; q.n_mels = c.n_mels;
             q.thr = c.gate_threshold; q.seed = (long long)dropout_seed;
-            const void* fn = M == 512 ? (const void*)taco_decoder_persistent<512> : (const void*)taco_decoder_persistent<640>;
+            const bool flow = taco_persistent_mode() == 2;
+            const void* fn = flow ? (M == 512 ? (const void*)taco_decoder_persistent<512, true> : (const void*)taco_decoder_persistent<640, true>)
+                                  : (M == 512 ? (const void*)taco_decoder_persistent<512, false> : (const void*)taco_decoder_persistent<640, false>);
             std::lock_guard<std::mutex> lock(h->mu);
+            if (flow)    // every word a consumer may poll starts as the sentinel 0xFFFFFFFF
+                TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0xFF, (size_t)w.tail_o * sizeof(float), s));
             TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0, (size_t)w.step_floats * sizeof(float), s));                 // region 0: the zero initial state
             TTS_CHECK_HIP(hipMemsetAsync(w.xch + w.tail_o, 0, 384 * sizeof(float), s));                        // barrier slots, error flag, step count
             TTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1402,7 +1886,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             TTS_CHECK_HIP(hipStreamSynchronize(s));
             if (dbg) fprintf(stderr, "[taco] persistent decoder: %.0f us for %d steps (%zu B of LDS per block)\n", now_us() - t0, (int)tail[1], lds);
             if (tail[0] != 0) {
-                set_error("tacotron2_infer: the persistent decoder's grid barrier timed out (are 256 CUs free for it?)");
+                set_error("tacotron2_infer: the persistent decoder timed out waiting for another block (are 256 CUs free for it?)");
                 return TTSAMD_EHIP;
             }
             steps = tail[1];
