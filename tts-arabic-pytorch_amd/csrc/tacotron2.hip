@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
     float* gE5 = sf;  sf += 128;
 
     // early half of the attention cell for the step that reads region `rq` as its "previous" state: [ctx | att_h] columns
-#define TACO_S1_EARLY(rq)                                                                                                   \
+#define TACO_S1_EARLY(rq, pq)                                                                                                 \
     _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                                                      \
         int vp = 0;                                                                                                         \
         asm volatile("" : "+v"(vp));                                                                                        \
@@ -919,7 +919,8 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 const int xstride = k < 256 + M_ ? 1024 : 4;                                                                \
                 const bool use = g >= 64 && g < G::K4A;                           /* groups 0..63 are the prenet columns */ \
                 _Pragma("unroll") for (int bq = 0; bq < 4; ++bq) {                                                          \
-                    xs[j][bq] = TACO_LD4(rq, use ? xbase + min(4 * ps + bq, B - 1) * xstride : TR_CTX);                     \
+                    const int off_ = use ? xbase + min(4 * ps + bq, B - 1) * xstride : TR_CTX;                              \
+                    xs[j][bq] = spin == 0 ? *reinterpret_cast<const taco_f4*>((pq) + off_) : TACO_LD4(rq, off_);            \
                     okv = okv && (!use || TACO_OK4(xs[j][bq]));                                                             \
                     if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};                                                      \
                 }                                                                                                           \
@@ -948,12 +949,20 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 
     taco_i4 rs0;
     TACO_RSRC(rs0, p.xch)
-    TACO_S1_EARLY(rs0)                                               // step 0: zero state
+    TACO_S1_EARLY(rs0, p.xch)                                        // step 0: zero state
     for (int s = 0; s < p.max_step; ++s) {
         float* curw = p.xch + (int64_t)(s + 1) * p.step_floats;
         taco_i4 rs, rq;                                              // this step's region (stores, fresh reads); the previous step's
         TACO_RSRC(rs, curw)
         TACO_RSRC(rq, p.xch + (int64_t)s * p.step_floats)
+#ifdef TP_TIMING
+        unsigned fst[20];
+        int fsi = 0;
+#define TF_STAMP() fst[fsi++] = (unsigned)wall_clock64();
+#else
+#define TF_STAMP()
+#endif
+        TF_STAMP()   /* 0 top */
         // ---------------- stop test of the previous step (the gate block's flags travel with its prenet hand-off)
         if (s > 0) {
             int all = 1;
@@ -971,6 +980,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             }
             if (all) { steps = s; break; }
         }
+        TF_STAMP()   /* 1 stop flags in */
         // ---------------- S1 late: the prenet columns of the attention cell, gates, new att_h
         {
 #pragma unroll
@@ -1015,6 +1025,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 if (bb < B) XST(TR_ATT + bid * 32 + bb * 4 + uu, sigmoidf_(go) * tanhf(c_att));
             }
         }
+        TF_STAMP()   /* 2 S1 late done (pre polled, att_h stored) */
         // ---------------- S2+S3: query rows of this block, partial energies of its tile
         {
             int vp = 0;
@@ -1032,6 +1043,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 if (spin > POLL_LIM) { bad = true; break; }
                     TACO_BACKOFF
             }
+            TF_STAMP()   /* 3 att_h in */
             float4 wq[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) wq[r] = *reinterpret_cast<const float4*>(p.wq + (int64_t)(8 * g16 + r) * 1024 + 4 * tid);
@@ -1083,6 +1095,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 if (d == 0) XST(R_EP + (g16 * 16 + tile) * PTp + pair, val);
             }
         }
+        TF_STAMP()   /* 4 energies stored */
         // ---------------- S5 early: [att_h | dec_h] columns of the decoder cell (both already complete in memory)
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
@@ -1101,7 +1114,10 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #pragma unroll
                     for (int bq = 0; bq < 4; ++bq) {
                         const int off = xbase + min(4 * ps + bq, B - 1) * 4;
-                        xs[j][bq] = rec ? TACO_LD4(rq, off) : TACO_LD4(rs, off);
+                        // first attempt through L2 (these words were complete in memory before this block's previous phase
+                        // ended; 256 blocks re-reading them past L2 costs 13 us); any sentinel sends the pass to the coherent path
+                        if (spin == 0) xs[j][bq] = *reinterpret_cast<const taco_f4*>((rec ? curw - p.step_floats : curw) + off);
+                        else xs[j][bq] = rec ? TACO_LD4(rq, off) : TACO_LD4(rs, off);
                         okv = okv && (!use || TACO_OK4(xs[j][bq]));
                         if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -1134,6 +1150,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         __syncthreads();
         if (tid < 128) gE5[tid] = part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)];
         __syncthreads();
+        TF_STAMP()   /* 5 S5 early done */
         // ---------------- S4: masked softmax over the tokens of utterance b4, context columns cg MC .. +MC
         if (b4 < B) {
             const int t = tid;
@@ -1191,6 +1208,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             }
         }
         __syncthreads();
+        TF_STAMP()   /* 6 S4 done (epart polled, ctx stored) */
         // ---------------- S5 late: the context columns of the decoder cell, gates, new dec_h
         {
 #pragma unroll
@@ -1250,6 +1268,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             }
         }
         __syncthreads();
+        TF_STAMP()   /* 7 S5 late done (ctx polled, dec_h stored) */
         // ---------------- S6: mel / gate row bid (< 81) and prenet layer-1 unit bid (folded) from [dec_h | ctx]
         {
             int vp = 0;
@@ -1310,6 +1329,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             }
         }
         __syncthreads();
+        TF_STAMP()   /* 8 S6 done (dec_h polled, h0 stored) */
         // ---------------- S7: prenet layer 2, units 4 bid .. 4 bid + 3 on blocks 0..63
         if (bid < 64) {
             int vp = 0;
@@ -1345,8 +1365,14 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 if (bb < B) XST(TR_PRE + bid * 32 + bb * 4 + r, a);
             }
         }
+        TF_STAMP()   /* 9 S7 done */
         // ---------------- S1 early of the next step (context and att_h of this step are complete in memory)
-        TACO_S1_EARLY(rs)
+        TACO_S1_EARLY(rs, curw)
+        TF_STAMP()   /* 10 S1 early done */
+#ifdef TP_TIMING
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 11; ++i) curw[TR_H0 + bid * 32 + 8 + i] = __builtin_bit_cast(float, fst[i]);
+#endif
         if (__syncthreads_or(bad)) {
             if (tid == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
