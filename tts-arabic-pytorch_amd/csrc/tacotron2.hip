@@ -816,17 +816,42 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 
     // ---------------- residency set-up (constant data: ordinary loads)
     const int u0 = bid * 4;                                          // hidden units of both cells
+    if constexpr (FLOW) {
+        // MFMA operand order (v_mfma_f32_16x16x4_f32, A = 16 gate rows x 4 k): entry (super-step i = 16 k values, lane l) holds
+        // W[row l & 15][16 i + 4 (l >> 4) .. + 3], row r16 = (unit r16 >> 2, gate r16 & 3): component m feeds the m-th MFMA of the
+        // super-step, whose B operand is component m of the lane's x float4 (same four consecutive k)
+        for (int idx = tid; idx < G::KA * 4; idx += 256) {
+            const int i = idx >> 6, l = idx & 63, r16 = l & 15, k = 16 * i + 4 * (l >> 4);
+            const int64_t row = (int64_t)(r16 & 3) * 1024 + u0 + (r16 >> 2);
+            sWa[idx] = *reinterpret_cast<const float4*>(k < 256 + M_ ? p.att_wih + row * (256 + M_) + k : p.att_whh + row * 1024 + (k - 256 - M_));
+        }
+    } else {
     for (int i = tid; i < 16 * G::K4A; i += 256) {
         const int r = i / G::K4A, g = i - r * G::K4A, k = 4 * g;
         const int64_t row = (int64_t)(r & 3) * 1024 + u0 + (r >> 2);  // row r = (unit r >> 2, gate r & 3)
         sWa[i] = *reinterpret_cast<const float4*>(k < 256 + M_ ? p.att_wih + row * (256 + M_) + k : p.att_whh + row * 1024 + (k - 256 - M_));
     }
+    }
     const int hf = wid >> 1, tl = tid & 127;                         // wave pair hf owns gate rows 8 hf .. 8 hf + 7
     // decoder-cell weights: 8 rows x NJD float4 column groups per thread, parked in ACCUMULATION registers (the "a" constraint)
     // and moved to a VGPR where they are used -- left to the register allocator they compete with the x operands in flight
     float wd[8][G::NJD][4];
+    constexpr int NSWA = G::KA / 64, NSWD = G::KD / 64;              // MFMA super-steps (16 k) per wave: attention / decoder cell
+    float wm[NSWD][4];                                               // (dataflow schedule) decoder-cell weights in MFMA operand order
 #define TACO_ACC_PUT(dst, val) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(val))
 #define TACO_ACC_GET(dst, src) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dst) : "a"(src))
+    if constexpr (FLOW) {
+#pragma unroll
+        for (int n = 0; n < NSWD; ++n) {
+            const int r16 = lane & 15, k = 16 * (wid + 4 * n) + 4 * (lane >> 4);
+            const int64_t row = (int64_t)(r16 & 3) * 1024 + u0 + (r16 >> 2);
+            const float4 wv = *reinterpret_cast<const float4*>(k < 1024 + M_ ? p.dec_wih + row * (1024 + M_) + k : p.dec_whh + row * 1024 + (k - 1024 - M_));
+            TACO_ACC_PUT(wm[n][0], wv.x);
+            TACO_ACC_PUT(wm[n][1], wv.y);
+            TACO_ACC_PUT(wm[n][2], wv.z);
+            TACO_ACC_PUT(wm[n][3], wv.w);
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int R = 8 * hf + r;
@@ -841,6 +866,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             TACO_ACC_PUT(wd[r][j][2], wv.z);
             TACO_ACC_PUT(wd[r][j][3], wv.w);
         }
+    }
     }
     const int g16 = bid & 15, tile = bid >> 4;                       // attention dims 8 g16 .. +7, energy tile
     for (int i = tid; i < 8 * 2 * KS; i += 256) sG[i] = p.loc_fold[(int64_t)8 * g16 * 2 * KS + i];
@@ -866,7 +892,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
     const float biasA = p.projx_b[p.n_mels + 1 + bid], biasB = p.projx_b[min(bid, p.n_mels)];
     float ba[4], bd[4];                                              // gate biases of this thread's unit (threads < 32)
     {
-        const int uu = (tid >> 3) & 3;
+        const int uu = FLOW ? (lane >> 4) : ((tid >> 3) & 3);    // (dataflow: lane (unit l >> 4, utterance l & 15) of wave 0 applies the gates)
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) {
             ba[gt] = p.att_b[gt * 1024 + u0 + uu];
@@ -900,56 +926,57 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                                 rs_.y = (int)(unsigned)(a_ >> 32); rs_.z = p.step_floats * 4; rs_.w = 0x00020000; }
 #define TACO_LD4(rs_, foff_) taco_buffer_load_f4(rs_, (foff_) * 4, 0, 16)
 #define TACO_LD1(rs_, foff_) taco_buffer_load_f1(rs_, (foff_) * 4, 0, 16)
-    float* gE1 = sf;  sf += 128;                                     // early halves of the two cells' gate sums [half][unit][gate][batch]
-    float* gE5 = sf;  sf += 128;
-
-    // early half of the attention cell for the step that reads region `rq` as its "previous" state: [ctx | att_h] columns
-#define TACO_S1_EARLY(rq, pq)                                                                                                 \
-    _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                                                      \
+    float* cred = sf;  sf += 1024;                                   // [wave][lane][4]: the four waves' partial gate tiles
+    // The two LSTMCells run on the matrix pipe: one v_mfma_f32_16x16x4_f32 = 16 gate rows (4 units x 4 gates of this block) x
+    // 16 columns (8 utterances, duplicated) x 4 k.  A "super-step" is 16 k = four MFMAs fed by ONE float4 of weights and ONE
+    // float4 of x per lane (lane = (row or utterance l & 15, k quarter l >> 4)); wave w owns super-steps w, w + 4, ...  The
+    // result tile has unit l >> 4's four gates for utterance l & 15 in the lane's four registers: exactly the pointwise update.
+    // (Exact fp32 FMA chains, as on the vector pipe; at one wave per SIMD the vector version took 9.7 us per cell half.)
+    const int c16 = lane & 15, kq = lane >> 4, bl = min(c16 & 7, B - 1);
+    taco_f4 accA0 = {0.f, 0.f, 0.f, 0.f}, accA1 = accA0, accD0 = accA0, accD1 = accA0;
+#define TACO_MFMA4(a0_, a1_, w_, x_)                                             \
+    a0_ = __builtin_amdgcn_mfma_f32_16x16x4f32((w_).x, (x_).x, a0_, 0, 0, 0);    \
+    a1_ = __builtin_amdgcn_mfma_f32_16x16x4f32((w_).y, (x_).y, a1_, 0, 0, 0);    \
+    a0_ = __builtin_amdgcn_mfma_f32_16x16x4f32((w_).z, (x_).z, a0_, 0, 0, 0);    \
+    a1_ = __builtin_amdgcn_mfma_f32_16x16x4f32((w_).w, (x_).w, a1_, 0, 0, 0);
+    // x float4 of the attention cell's super-step i for this lane: [pre | ctx | att_h] column 16 i + 4 kq, utterance bl
+#define TACO_ATT_XOFF(i_) ({ const int k_ = 16 * (i_) + 4 * kq, kc_ = k_ - 256, cg_ = kc_ / G::MC;                              \
+        k_ < 256 ? TR_PRE + (k_ >> 2) * 32 + bl * 4 : k_ < 256 + M_ ? TR_CTX + (bl * 32 + cg_) * 32 + (kc_ - cg_ * G::MC)      \
+                                                     : TR_ATT + ((k_ - 256 - M_) >> 2) * 32 + bl * 4; })
+#define TACO_DEC_XOFF(i_) ({ const int k_ = 16 * (i_) + 4 * kq, kc_ = k_ - 1024, cg_ = kc_ / G::MC;                             \
+        k_ < 1024 ? TR_ATT + (k_ >> 2) * 32 + bl * 4 : k_ < 1024 + M_ ? TR_CTX + (bl * 32 + cg_) * 32 + (kc_ - cg_ * G::MC)    \
+                                                      : TR_DEC + ((k_ - 1024 - M_) >> 2) * 32 + bl * 4; })
+    // early half of the attention cell for the step that reads region (rq, pq) as its previous state: the [ctx | att_h] super-steps
+    // (n >= 4: super-steps 0..15 are the prenet columns).  First attempt through L2, any sentinel sends the lane to the coherent path.
+    constexpr int NEA = NSWA - 4;
+#define TACO_ATT_EARLY(rq, pq)                                                                                              \
+    {                                                                                                                       \
         int vp = 0;                                                                                                         \
         asm volatile("" : "+v"(vp));                                                                                        \
-        const int tlz = tl + vp;                                                                                            \
-        taco_f4 xs[G::NJA][4];                                                                                              \
+        const int wz = wid + vp;                                                                                            \
+        taco_f4 xs[NEA];                                                                                                    \
         for (int spin = 0;; ++spin) {                                                                                       \
             bool okv = true;                                                                                                \
-            _Pragma("unroll") for (int j = 0; j < G::NJA; ++j) {                                                            \
-                const int g = tlz + 128 * j, gc = min(g, G::K4A - 1), k = 4 * gc;                                           \
-                const int kc = k - 256, cgx = kc / G::MC;                                                                   \
-                const int xbase = k < 256 + M_ ? TR_CTX + cgx * 32 + (kc - cgx * G::MC) : TR_ATT + (gc - (256 + M_) / 4) * 32; \
-                const int xstride = k < 256 + M_ ? 1024 : 4;                                                                \
-                const bool use = g >= 64 && g < G::K4A;                           /* groups 0..63 are the prenet columns */ \
-                _Pragma("unroll") for (int bq = 0; bq < 4; ++bq) {                                                          \
-                    const int off_ = use ? xbase + min(4 * ps + bq, B - 1) * xstride : TR_CTX;                              \
-                    xs[j][bq] = spin == 0 ? *reinterpret_cast<const taco_f4*>((pq) + off_) : TACO_LD4(rq, off_);            \
-                    okv = okv && (!use || TACO_OK4(xs[j][bq]));                                                             \
-                    if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};                                                      \
-                }                                                                                                           \
+            _Pragma("unroll") for (int n = 0; n < NEA; ++n) {                                                               \
+                const int off_ = TACO_ATT_XOFF(wz + 4 * (n + 4));                                                           \
+                xs[n] = spin == 0 ? *reinterpret_cast<const taco_f4*>((pq) + off_) : TACO_LD4(rq, off_);                    \
+                okv = okv && TACO_OK4(xs[n]);                                                                               \
             }                                                                                                               \
             if (okv) break;                                                                                                 \
             if (spin > POLL_LIM) { bad = true; break; }                                                                     \
             TACO_BACKOFF                                                                                                    \
         }                                                                                                                   \
-        taco_f2 vv[32];                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 32; ++i) vv[i] = taco_f2{0.f, 0.f};                                           \
-        _Pragma("unroll") for (int j = 0; j < G::NJA; ++j) {                                                                \
-            const int gc = min(tlz + 128 * j, G::K4A - 1);                                                                  \
-            _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                                 \
-                const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(8 * hf + r) * G::K4A + gc]);                     \
-                _Pragma("unroll") for (int bq = 0; bq < 4; ++bq) vv[r * 4 + bq] = taco_pk_dot4(wa, xs[j][bq], vv[r * 4 + bq]); \
-            }                                                                                                               \
+        accA0 = taco_f4{0.f, 0.f, 0.f, 0.f};                                                                                \
+        accA1 = accA0;                                                                                                      \
+        _Pragma("unroll") for (int n = 0; n < NEA; ++n) {                                                                   \
+            const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * (n + 4)) * 64 + lane]);                     \
+            TACO_MFMA4(accA0, accA1, wa, xs[n])                                                                             \
         }                                                                                                                   \
-        float v[32];                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 32; ++i) v[i] = vv[i].x + vv[i].y;                                            \
-        const float tot = taco_butterfly32(v, lane);                                                                        \
-        if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;                               \
-    }                                                                                                                       \
-    __syncthreads();                                                                                                        \
-    if (tid < 128) gE1[tid] = part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)];               \
-    __syncthreads();
+    }
 
     taco_i4 rs0;
     TACO_RSRC(rs0, p.xch)
-    TACO_S1_EARLY(rs0, p.xch)                                        // step 0: zero state
+    TACO_ATT_EARLY(rs0, p.xch)                                       // step 0: zero state
     for (int s = 0; s < p.max_step; ++s) {
         float* curw = p.xch + (int64_t)(s + 1) * p.step_floats;
         taco_i4 rs, rq;                                              // this step's region (stores, fresh reads); the previous step's
@@ -981,49 +1008,39 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             if (all) { steps = s; break; }
         }
         TF_STAMP()   /* 1 stop flags in */
-        // ---------------- S1 late: the prenet columns of the attention cell, gates, new att_h
+        // ---------------- S1 late: the prenet super-steps of the attention cell, gates, new att_h
         {
+            int vp = 0;
+            asm volatile("" : "+v"(vp));
+            const int wz = wid + vp;
+            taco_f4 xp[4];
+            for (int spin = 0;; ++spin) {
+                bool okv = true;
 #pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                int vp = 0;
-                asm volatile("" : "+v"(vp));             // opaque zero: keeps this phase's address arithmetic out of the step loop's preheader
-                const int tl = (tid & 127) + vp;
-                taco_f4 xp[4];
-                const bool use = tl < 64;
-                for (int spin = 0;; ++spin) {
-                    bool okv = true;
-#pragma unroll
-                    for (int bq = 0; bq < 4; ++bq) {
-                        xp[bq] = TACO_LD4(rq, TR_PRE + (use ? tl : 0) * 32 + min(4 * ps + bq, B - 1) * 4);
-                        okv = okv && (!use || TACO_OK4(xp[bq]));
-                    }
-                    if (okv) break;
-                    if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
+                for (int n = 0; n < 4; ++n) {
+                    xp[n] = TACO_LD4(rq, TACO_ATT_XOFF(wz + 4 * n));
+                    okv = okv && TACO_OK4(xp[n]);
                 }
-                float v[32];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float4 wa = sWa[(8 * hf + r) * G::K4A + (tl & 63)];
-#pragma unroll
-                    for (int bq = 0; bq < 4; ++bq) {
-                        const float4 xv = use ? make_float4(xp[bq].x, xp[bq].y, xp[bq].z, xp[bq].w) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        v[r * 4 + bq] = taco_dot4(wa, xv, 0.f);
-                    }
-                }
-                const float tot = taco_butterfly32(v, lane);
-                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; break; }
+                TACO_BACKOFF
             }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * n) * 64 + lane]);
+                TACO_MFMA4(accA0, accA1, wa, xp[n])
+            }
+            const taco_f4 tile = accA0 + accA1;
+            *reinterpret_cast<taco_f4*>(cred + (wid * 64 + lane) * 4) = tile;
             __syncthreads();
-            if (tid < 128) gates[tid] = gE1[tid] + (part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)]);
-            __syncthreads();
-            if (tid < 32) {
-                const int uu = tid >> 3, bb = tid & 7;
-                const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;
-                const float gi = gp[0] + ba[0], gf = gp[8] + ba[1], gg = gp[16] + ba[2], go = gp[24] + ba[3];
+            if (wid == 0 && c16 < 8) {                                    // lane = (unit kq, utterance c16): its four gates
+                const taco_f4 g4 = *reinterpret_cast<const taco_f4*>(cred + lane * 4) + *reinterpret_cast<const taco_f4*>(cred + (64 + lane) * 4) +
+                                   *reinterpret_cast<const taco_f4*>(cred + (128 + lane) * 4) + *reinterpret_cast<const taco_f4*>(cred + (192 + lane) * 4);
+                const float gi = g4.x + ba[0], gf = g4.y + ba[1], gg = g4.z + ba[2], go = g4.w + ba[3];
                 c_att = sigmoidf_(gf) * c_att + sigmoidf_(gi) * tanhf(gg);
-                if (bb < B) XST(TR_ATT + bid * 32 + bb * 4 + uu, sigmoidf_(go) * tanhf(c_att));
+                if (c16 < B) XST(TR_ATT + bid * 32 + c16 * 4 + kq, sigmoidf_(go) * tanhf(c_att));
             }
+            __syncthreads();
         }
         TF_STAMP()   /* 2 S1 late done (pre polled, att_h stored) */
         // ---------------- S2+S3: query rows of this block, partial energies of its tile
@@ -1096,60 +1113,42 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             }
         }
         TF_STAMP()   /* 4 energies stored */
-        // ---------------- S5 early: [att_h | dec_h] columns of the decoder cell (both already complete in memory)
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+        // ---------------- S5 early: the [att_h | dec_h] super-steps of the decoder cell (both already complete in memory)
+        {
             int vp = 0;
             asm volatile("" : "+v"(vp));
-            const int tlz = tl + vp;
-            taco_f4 xs[G::NJD][4];
+            const int wz = wid + vp;
+            constexpr int NC = M_ / 64, NED = NSWD - NC;                  // context super-steps per wave (n = 16 .. 16 + NC - 1); the others
+            taco_f4 xs[NED];
+            const float* prvp = curw - p.step_floats;
             for (int spin = 0;; ++spin) {
                 bool okv = true;
 #pragma unroll
-                for (int j = 0; j < G::NJD; ++j) {
-                    const int g = tlz + 128 * j, k = 4 * min(g, G::K4D - 1), gk = k >> 2;
-                    const bool isctx = k >= 1024 && k < 1024 + M_, rec = k >= 1024 + M_;
-                    const bool use = !isctx && g < G::K4D;
-                    const int xbase = rec ? TR_DEC + (gk - (1024 + M_) / 4) * 32 : TR_ATT + min(gk, 255) * 32;
-#pragma unroll
-                    for (int bq = 0; bq < 4; ++bq) {
-                        const int off = xbase + min(4 * ps + bq, B - 1) * 4;
-                        // first attempt through L2 (these words were complete in memory before this block's previous phase
-                        // ended; 256 blocks re-reading them past L2 costs 13 us); any sentinel sends the pass to the coherent path
-                        if (spin == 0) xs[j][bq] = *reinterpret_cast<const taco_f4*>((rec ? curw - p.step_floats : curw) + off);
-                        else xs[j][bq] = rec ? TACO_LD4(rq, off) : TACO_LD4(rs, off);
-                        okv = okv && (!use || TACO_OK4(xs[j][bq]));
-                        if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};
-                    }
+                for (int e = 0; e < NED; ++e) {
+                    const int n = e < 16 ? e : e + NC;
+                    const int off = TACO_DEC_XOFF(wz + 4 * n);
+                    if (spin == 0) xs[e] = *reinterpret_cast<const taco_f4*>((e < 16 ? curw : prvp) + off);
+                    else xs[e] = e < 16 ? TACO_LD4(rs, off) : TACO_LD4(rq, off);
+                    okv = okv && TACO_OK4(xs[e]);
                 }
                 if (okv) break;
                 if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
+                TACO_BACKOFF
             }
-            taco_f2 vv[32];
+            accD0 = taco_f4{0.f, 0.f, 0.f, 0.f};
+            accD1 = accD0;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) vv[i] = taco_f2{0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < G::NJD; ++j)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    taco_f4 w;
-                    TACO_ACC_GET(w.x, wd[r][j][0]);
-                    TACO_ACC_GET(w.y, wd[r][j][1]);
-                    TACO_ACC_GET(w.z, wd[r][j][2]);
-                    TACO_ACC_GET(w.w, wd[r][j][3]);
-#pragma unroll
-                    for (int bq = 0; bq < 4; ++bq) vv[r * 4 + bq] = taco_pk_dot4(w, xs[j][bq], vv[r * 4 + bq]);
-                }
-            float v[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = vv[i].x + vv[i].y;
-            const float tot = taco_butterfly32(v, lane);
-            if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+            for (int e = 0; e < NED; ++e) {
+                const int n = e < 16 ? e : e + NC;
+                taco_f4 w;                                        // (a plain use: the compiler feeds the MFMA from the AGPR itself -- behind
+                                                                  //  an inline-asm v_accvgpr_read it does not see the VALU -> MFMA hazard)
+                w.x = wm[n][0];
+                w.y = wm[n][1];
+                w.z = wm[n][2];
+                w.w = wm[n][3];
+                TACO_MFMA4(accD0, accD1, w, xs[e])
+            }
         }
-        __syncthreads();
-        if (tid < 128) gE5[tid] = part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)];
-        __syncthreads();
         TF_STAMP()   /* 5 S5 early done */
         // ---------------- S4: masked softmax over the tokens of utterance b4, context columns cg MC .. +MC
         if (b4 < B) {
@@ -1209,62 +1208,42 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         }
         __syncthreads();
         TF_STAMP()   /* 6 S4 done (epart polled, ctx stored) */
-        // ---------------- S5 late: the context columns of the decoder cell, gates, new dec_h
+        // ---------------- S5 late: the context super-steps of the decoder cell, gates, new dec_h
         {
+            int vp = 0;
+            asm volatile("" : "+v"(vp));
+            const int wz = wid + vp;
+            constexpr int NC = M_ / 64;
+            taco_f4 xc[NC];
+            for (int spin = 0;; ++spin) {
+                bool okv = true;
 #pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                int vp = 0;
-                asm volatile("" : "+v"(vp));
-                const int tl = (tid & 127) + vp;
-                taco_f4 xs[G::NJD][4];
-                for (int spin = 0;; ++spin) {
-                    bool okv = true;
-#pragma unroll
-                    for (int j = 0; j < G::NJD; ++j) {
-                        const int g = tl + 128 * j, k = 4 * min(g, G::K4D - 1), kc = k - 1024, cgx = kc / G::MC;
-                        const bool use = k >= 1024 && k < 1024 + M_ && g < G::K4D;
-                        if ((128 * j + 127) * 4 < 1024 || 128 * j * 4 >= 1024 + M_) continue;          // no context column in this group set
-#pragma unroll
-                        for (int bq = 0; bq < 4; ++bq) {
-                            xs[j][bq] = TACO_LD4(rs, use ? TR_CTX + cgx * 32 + (kc - cgx * G::MC) + min(4 * ps + bq, B - 1) * 1024 : TR_CTX);
-                            okv = okv && (!use || TACO_OK4(xs[j][bq]));
-                            if (!use) xs[j][bq] = taco_f4{0.f, 0.f, 0.f, 0.f};
-                        }
-                    }
-                    if (okv) break;
-                    if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
+                for (int e = 0; e < NC; ++e) {
+                    xc[e] = TACO_LD4(rs, TACO_DEC_XOFF(wz + 4 * (16 + e)));
+                    okv = okv && TACO_OK4(xc[e]);
                 }
-                float v[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) v[i] = 0.f;
-#pragma unroll
-                for (int j = 0; j < G::NJD; ++j) {
-                    if ((128 * j + 127) * 4 < 1024 || 128 * j * 4 >= 1024 + M_) continue;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float4 w;
-                        TACO_ACC_GET(w.x, wd[r][j][0]);
-                        TACO_ACC_GET(w.y, wd[r][j][1]);
-                        TACO_ACC_GET(w.z, wd[r][j][2]);
-                        TACO_ACC_GET(w.w, wd[r][j][3]);
-#pragma unroll
-                        for (int bq = 0; bq < 4; ++bq)
-                            v[r * 4 + bq] = taco_dot4(w, make_float4(xs[j][bq].x, xs[j][bq].y, xs[j][bq].z, xs[j][bq].w), v[r * 4 + bq]);
-                    }
-                }
-                const float tot = taco_butterfly32(v, lane);
-                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; break; }
+                TACO_BACKOFF
             }
+#pragma unroll
+            for (int e = 0; e < NC; ++e) {
+                taco_f4 w;
+                w.x = wm[16 + e][0];
+                w.y = wm[16 + e][1];
+                w.z = wm[16 + e][2];
+                w.w = wm[16 + e][3];
+                TACO_MFMA4(accD0, accD1, w, xc[e])
+            }
+            const taco_f4 tile = accD0 + accD1;
+            *reinterpret_cast<taco_f4*>(cred + (wid * 64 + lane) * 4) = tile;
             __syncthreads();
-            if (tid < 128) gates[tid] = gE5[tid] + (part[(tid >> 6) * 128 + (tid & 63)] + part[(tid >> 6) * 128 + 64 + (tid & 63)]);
-            __syncthreads();
-            if (tid < 32) {
-                const int uu = tid >> 3, bb = tid & 7;
-                const float* gp = gates + (uu >> 1) * 64 + (uu & 1) * 32 + bb;
-                const float gi = gp[0] + bd[0], gf = gp[8] + bd[1], gg = gp[16] + bd[2], go = gp[24] + bd[3];
+            if (wid == 0 && c16 < 8) {
+                const taco_f4 g4 = *reinterpret_cast<const taco_f4*>(cred + lane * 4) + *reinterpret_cast<const taco_f4*>(cred + (64 + lane) * 4) +
+                                   *reinterpret_cast<const taco_f4*>(cred + (128 + lane) * 4) + *reinterpret_cast<const taco_f4*>(cred + (192 + lane) * 4);
+                const float gi = g4.x + bd[0], gf = g4.y + bd[1], gg = g4.z + bd[2], go = g4.w + bd[3];
                 c_dec = sigmoidf_(gf) * c_dec + sigmoidf_(gi) * tanhf(gg);
-                if (bb < B) XST(TR_DEC + bid * 32 + bb * 4 + uu, sigmoidf_(go) * tanhf(c_dec));
+                if (c16 < B) XST(TR_DEC + bid * 32 + c16 * 4 + kq, sigmoidf_(go) * tanhf(c_dec));
             }
         }
         __syncthreads();
@@ -1367,7 +1346,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         }
         TF_STAMP()   /* 9 S7 done */
         // ---------------- S1 early of the next step (context and att_h of this step are complete in memory)
-        TACO_S1_EARLY(rs, curw)
+        TACO_ATT_EARLY(rs, curw)
         TF_STAMP()   /* 10 S1 early done */
 #ifdef TP_TIMING
         if (threadIdx.x == 0)
@@ -1378,7 +1357,10 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             return;
         }
     }
-#undef TACO_S1_EARLY
+#undef TACO_ATT_EARLY
+#undef TACO_MFMA4
+#undef TACO_ATT_XOFF
+#undef TACO_DEC_XOFF
 #undef TACO_OK4
 #undef TACO_RSRC
 #undef TACO_LD4
@@ -1874,7 +1856,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         const int KS = c.attention_location_kernel_size, half = (KS - 1) / 2, PT = (B * L + 15) / 16;
         const int MC = M / 32, NS = MC ? 256 / MC : 0, K4A = (P + M + A) / 4;
         const size_t lds = (size_t)16 * K4A * 16 +
-                           sizeof(float) * ((size_t)L * MC + (size_t)PT * 8 + 16 * KS + 2 * (PT + 2 * half) + 256 + 128 + 64 + 256 + NS * MC + 16 + 256);
+                           sizeof(float) * ((size_t)L * MC + (size_t)PT * 8 + 16 * KS + 2 * (PT + 2 * half) + 256 + 128 + 64 + 256 + NS * MC + 16 + 1024);
         int dev_id = 0, n_cu = 0, coop = 0;
         (void)hipGetDevice(&dev_id);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
