@@ -990,23 +990,6 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #define TF_STAMP()
 #endif
         TF_STAMP()   /* 0 top */
-        // ---------------- stop test of the previous step (the gate block's flags travel with its prenet hand-off)
-        if (s > 0) {
-            int all = 1;
-            for (int spin = 0;; ++spin) {
-                bool okv = true;
-                all = 1;
-                for (int b = 0; b < B; ++b) {
-                    const unsigned f = __builtin_bit_cast(unsigned, TACO_LD1(rq, R_FIN + b));
-                    okv = okv && f != SENT;
-                    all &= f != 0u;
-                }
-                if (okv) break;
-                if (spin > POLL_LIM) { bad = true; all = 0; break; }
-                TACO_BACKOFF
-            }
-            if (all) { steps = s; break; }
-        }
         TF_STAMP()   /* 1 stop flags in */
         // ---------------- S1 late: the prenet super-steps of the attention cell, gates, new att_h
         {
@@ -1014,6 +997,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             asm volatile("" : "+v"(vp));
             const int wz = wid + vp;
             taco_f4 xp[4];
+            int all_fin = 0;                                              // the gate block's stop flags of the previous step ride in the same poll
             for (int spin = 0;; ++spin) {
                 bool okv = true;
 #pragma unroll
@@ -1021,10 +1005,17 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                     xp[n] = TACO_LD4(rq, TACO_ATT_XOFF(wz + 4 * n));
                     okv = okv && TACO_OK4(xp[n]);
                 }
-                if (okv) break;
+                if (s > 0) {
+                    const unsigned fv = __builtin_bit_cast(unsigned, TACO_LD1(rq, R_FIN + (lane & 7)));
+                    const unsigned long long bm = __ballot(fv != 0u || (lane & 7) >= B), vm = __ballot(fv != SENT || (lane & 7) >= B);
+                    okv = okv && vm == ~0ull;
+                    all_fin = bm == ~0ull;
+                }
+                if (__all(okv)) break;                                    // wave-uniform exit: the ballots above need every lane in the loop
                 if (spin > POLL_LIM) { bad = true; break; }
                 TACO_BACKOFF
             }
+            if (__syncthreads_or(all_fin)) { steps = s; break; }          // (every wave sees the same flags once they are valid)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * n) * 64 + lane]);
@@ -1048,34 +1039,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             int vp = 0;
             asm volatile("" : "+v"(vp));
             const int tid = (int)threadIdx.x + vp;
-            taco_f4 xa[8];
-            for (int spin = 0;; ++spin) {
-                bool okv = true;
-#pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    xa[bb] = TACO_LD4(rs, TR_ATT + tid * 32 + min(bb, B - 1) * 4);
-                    okv = okv && TACO_OK4(xa[bb]);
-                }
-                if (okv) break;
-                if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
-            }
-            TF_STAMP()   /* 3 att_h in */
-            float4 wq[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) wq[r] = *reinterpret_cast<const float4*>(p.wq + (int64_t)(8 * g16 + r) * 1024 + 4 * tid);
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                float v[32];
-#pragma unroll
-                for (int bq = 0; bq < 4; ++bq) {
-                    const taco_f4 xv = xa[4 * ps + bq];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r * 4 + bq] = fmaf(wq[r].x, xv.x, fmaf(wq[r].y, xv.y, fmaf(wq[r].z, xv.z, wq[r].w * xv.w)));
-                }
-                const float tot = taco_butterfly32(v, lane);
-                if (!(lane & 1)) part[wid * 64 + (lane >> 3) * 8 + 4 * ps + ((lane >> 1) & 3)] = tot;
-            }
+            // the previous step's alignment weights first: they have been in memory since its softmax phase
             const int nw = (p1 - p0) + 2 * half;
             for (int i = tid; i < nw; i += 256) {
                 const int fp = p0 - half + i;
@@ -1092,8 +1056,35 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 sAw[i] = ok ? a : 0.f;
                 sCum[i] = ok ? c : 0.f;
             }
+            // query rows on the matrix pipe: rows 8 g16 .. + 7 (duplicated into the tile's rows 8..15), 64 super-steps over K = 1024,
+            // 16 per wave; the weights are constants: fetched before the wait for att_h
+            taco_f4 wqm[16], xa[16];
+#pragma unroll
+            for (int n = 0; n < 16; ++n)
+                wqm[n] = *reinterpret_cast<const taco_f4*>(p.wq + (int64_t)(8 * g16 + (c16 & 7)) * 1024 + 16 * (wid + 4 * n + vp) + 4 * kq);
+            for (int spin = 0;; ++spin) {
+                bool okv = true;
+#pragma unroll
+                for (int n = 0; n < 16; ++n) {
+                    xa[n] = TACO_LD4(rs, TR_ATT + (4 * (wid + 4 * n + vp) + kq) * 32 + bl * 4);
+                    okv = okv && TACO_OK4(xa[n]);
+                }
+                if (okv) break;
+                if (spin > POLL_LIM) { bad = true; break; }
+                TACO_BACKOFF
+            }
+            TF_STAMP()   /* 3 att_h in */
+            {
+                taco_f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+#pragma unroll
+                for (int n = 0; n < 16; ++n) { TACO_MFMA4(q0, q1, wqm[n], xa[n]) }
+                *reinterpret_cast<taco_f4*>(cred + (wid * 64 + lane) * 4) = q0 + q1;
+            }
             __syncthreads();
-            if (tid < 64) sPq[tid] = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
+            if (tid < 64) {                                              // sPq[dim][utterance]: tile row = dim, lane = (dim >> 2, utterance), reg dim & 3
+                const int d = tid >> 3, ub = tid & 7, src = ((d >> 2) * 16 + ub) * 4 + (d & 3);
+                sPq[tid] = cred[src] + cred[256 + src] + cred[512 + src] + cred[768 + src];
+            }
             __syncthreads();
             for (int it = tid; it < (p1 - p0) * 8; it += 256) {
                 const int pair = it >> 3, d = it & 7, pp = p0 + pair, b = pp / L, t = pp - b * L;
@@ -1703,11 +1694,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 
 // ------------------------------------------------------------------------------------ host
 
-// TTSAMD_TACO_PERSISTENT=1 selects the persistent decoder (opt-in: on the 8-XCD part its six grid barriers per step cost what
-// the seven kernel boundaries of the graph path cost); read per call
-static int taco_persistent_mode() {          // 0 graph path, 1 persistent kernel with grid barriers, 2 persistent kernel, dataflow hand-offs
-    const char* e = getenv("TTSAMD_TACO_PERSISTENT");
-    return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
+// TTSAMD_TACO_PERSISTENT (read per call): see taco_persistent_mode()
+static int taco_persistent_mode() {          // 0 graph path (8-step hipGraph replay), 1 persistent kernel with grid barriers, 2 persistent kernel with
+    const char* e = getenv("TTSAMD_TACO_PERSISTENT");   // dataflow hand-offs and MFMA cells (default where it fits: 47.5 vs 57.5 us per step)
+    if (!e || !e[0]) return 2;
+    return (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
 }
 static bool taco_persistent_wanted() { return taco_persistent_mode() != 0; }
 
@@ -1894,12 +1885,20 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             TTS_CHECK_HIP(hipStreamSynchronize(s));
             if (dbg) fprintf(stderr, "[taco] persistent decoder: %.0f us for %d steps (%zu B of LDS per block)\n", now_us() - t0, (int)tail[1], lds);
             if (tail[0] != 0) {
-                set_error("tacotron2_infer: the persistent decoder timed out waiting for another block (are 256 CUs free for it?)");
-                return TTSAMD_EHIP;
+                // a block waited > 80 ms for another one: the 256 blocks were not all resident (CUs held by other streams).  The
+                // graph path below recomputes the whole loop from the same state; only an explicit request is an error.
+                const char* e = getenv("TTSAMD_TACO_PERSISTENT");
+                if (e && (e[0] == '1' || e[0] == '2')) {
+                    set_error("tacotron2_infer: the persistent decoder timed out waiting for another block (are 256 CUs free for it?)");
+                    return TTSAMD_EHIP;
+                }
+                fprintf(stderr, "ttsamd: tacotron2 persistent decoder timed out, using the graph path\n");
+                TTS_CHECK_HIP(hipMemsetAsync(mel_lens, 0, (size_t)B * sizeof(int32_t), s));     // (the kernel had started counting)
+            } else {
+                steps = tail[1];
+                done = true;
             }
-            steps = tail[1];
-            done = true;
-            if (const char* dump = getenv("TTSAMD_TACO_DUMP")) {        // debugging aid: the region the last step produced
+            if (const char* dump = done ? getenv("TTSAMD_TACO_DUMP") : nullptr) {   // debugging aid: the region the last step produced
                 std::vector<float> hx((size_t)w.step_floats);
                 TTS_CHECK_HIP(hipMemcpy(hx.data(), w.xch + (int64_t)steps * w.step_floats, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
                 if (FILE* f = fopen(dump, "wb")) {
