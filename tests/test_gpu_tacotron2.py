@@ -295,3 +295,23 @@ def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch, mode):
     mel, mel_lens, al = Tacotron2Engine(sd, cfg, device=dev).infer(tok, sids, lens, max_step=40, dropout_seed=4)
     assert mel_lens.cpu().tolist() == stops and mel.shape == mel_ref.shape
     assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL
+
+
+def test_tacotron2_persistent_decoder_geometries(dev, monkeypatch):
+    """The default (persistent, dataflow) decoder against the graph path over the corners of its residency plan: the largest
+    token count (256: LDS 155-159 KB per block), both memory dims, odd batch sizes, one step, and back-to-back calls of
+    different shapes on one engine (the exchange arena is re-filled with the sentinel per call)."""
+    from ttsamd.engine import Tacotron2Engine
+    for num_speakers in (40, 1):
+        cfg, sd = _weights(gate_bias=-20.0, num_speakers=num_speakers)
+        eng = Tacotron2Engine(sd, cfg, device=dev)
+        for B, L, steps, seed in ((8, 256, 3, 3), (5, 100, 6, -1), (2, 33, 5, 1), (8, 256, 1, -1), (1, 1, 4, 2)):
+            tok, lens = _tokens(B, L, 7 * B + L)
+            sids = torch.arange(B) % num_speakers if num_speakers > 1 else None
+            monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '2')          # explicit: a geometry that did not fit or a time-out would raise
+            mel, mel_lens, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)
+            monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '0')
+            mel_g, lens_g, al_g = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)
+            assert mel_lens.cpu().tolist() == lens_g.cpu().tolist() == [steps] * B
+            assert bool(torch.isfinite(mel).all())
+            assert maxabs(mel, mel_g) < MEL_TOL and maxabs(al, al_g) < ALIGN_TOL, (num_speakers, B, L, steps)
