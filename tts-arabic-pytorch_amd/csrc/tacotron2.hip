@@ -1239,48 +1239,56 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         }
         __syncthreads();
         TF_STAMP()   /* 7 S5 late done (ctx polled, dec_h stored) */
-        // ---------------- S6: mel / gate row bid (< 81) and prenet layer-1 unit bid (folded) from [dec_h | ctx]
+        // ---------------- S6: mel / gate row bid (< 81) and prenet layer-1 unit bid (folded) from [dec_h | ctx], on the matrix pipe:
+        // tile rows alternate (row 81 + bid, row bid); the context super-steps are folded in before the wait for dec_h
         {
             int vp = 0;
             asm volatile("" : "+v"(vp));
-            const int tid = (int)threadIdx.x + vp;
-            taco_f4 xs[2][8];
+            const int wz = wid + vp;
+            const float* wrow = p.projx_w + (int64_t)((c16 & 1) ? min(bid, p.n_mels) : p.n_mels + 1 + bid) * G::KP + 4 * kq;
+            constexpr int NC = M_ / 64;
+            taco_f4 pj0 = {0.f, 0.f, 0.f, 0.f}, pj1 = pj0;
+            {
+                taco_f4 wc[NC], xc[NC];
+#pragma unroll
+                for (int e = 0; e < NC; ++e) wc[e] = *reinterpret_cast<const taco_f4*>(wrow + 16 * (64 + wz + 4 * e));
+                for (int spin = 0;; ++spin) {                             // (complete since this block's S5 late: one pass)
+                    bool okv = true;
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) {
+                        const int kc = 16 * (wz + 4 * e) + 4 * kq, cgx = kc / G::MC;
+                        xc[e] = TACO_LD4(rs, TR_CTX + (bl * 32 + cgx) * 32 + (kc - cgx * G::MC));
+                        okv = okv && TACO_OK4(xc[e]);
+                    }
+                    if (okv) break;
+                    if (spin > POLL_LIM) { bad = true; break; }
+                    TACO_BACKOFF
+                }
+#pragma unroll
+                for (int e = 0; e < NC; ++e) { TACO_MFMA4(pj0, pj1, wc[e], xc[e]) }
+            }
+            taco_f4 wp[16], xd[16];
+#pragma unroll
+            for (int n = 0; n < 16; ++n) wp[n] = *reinterpret_cast<const taco_f4*>(wrow + 16 * (wz + 4 * n));
             for (int spin = 0;; ++spin) {
                 bool okv = true;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int g = tid + 256 * j, k = 4 * min(g, G::K4P - 1), kc = k - 1024, cgx = kc / G::MC;
-                    const int xbase = k < 1024 ? TR_DEC + (k >> 2) * 32 : TR_CTX + cgx * 32 + (kc - cgx * G::MC);
-                    const int xstride = k < 1024 ? 4 : 1024;
-#pragma unroll
-                    for (int bb = 0; bb < 8; ++bb) {
-                        xs[j][bb] = TACO_LD4(rs, xbase + min(bb, B - 1) * xstride);
-                        okv = okv && TACO_OK4(xs[j][bb]);
-                    }
+                for (int n = 0; n < 16; ++n) {
+                    xd[n] = TACO_LD4(rs, TR_DEC + (4 * (wz + 4 * n) + kq) * 32 + bl * 4);
+                    okv = okv && TACO_OK4(xd[n]);
                 }
                 if (okv) break;
                 if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
+                TACO_BACKOFF
             }
-            float acc[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    const float4 xv = make_float4(xs[j][bb].x, xs[j][bb].y, xs[j][bb].z, xs[j][bb].w);
-                    acc[bb] = taco_dot4(wpA[j], xv, acc[bb]);                    // weights are zero past K4P
-                    acc[8 + bb] = taco_dot4(wpB[j], xv, acc[8 + bb]);
-                }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float a = acc[i];
-                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-                if (lane == 0) part[wid * 16 + i] = a;
-            }
+            for (int n = 0; n < 16; ++n) { TACO_MFMA4(pj0, pj1, wp[n], xd[n]) }
+            *reinterpret_cast<taco_f4*>(cred + (wid * 64 + lane) * 4) = pj0 + pj1;
             __syncthreads();
-            if (tid < 16) gates[tid] = part[tid] + part[16 + tid] + part[32 + tid] + part[48 + tid];
+            if (tid < 16) {                                               // gates[0..7]: row 81 + bid (tile row 0), [8..15]: row bid (tile row 1), per utterance
+                const int src = (tid & 7) * 4 + (tid >> 3);
+                gates[tid] = cred[src] + cred[256 + src] + cred[512 + src] + cred[768 + src];
+            }
             __syncthreads();
             if (tid < 8 && tid < B) {
                 const int bb = tid;
