@@ -918,6 +918,9 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #ifndef TACO_POLL_SLEEP
 #define TACO_POLL_SLEEP 8
 #endif
+#ifndef TACO_POLL_GAP
+#define TACO_POLL_GAP 0                     /* s_sleep units between the first two polls: swept 0...64 on the box, 0 is best (tools/taco_gap_sweep.sh) */
+#endif
 #define TACO_BACKOFF __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);   /* between polls: the fabric carries everybody's polls AND the stores they wait for */
     bool bad = false;
 #define TACO_OK4(v) (__builtin_bit_cast(unsigned, (v).x) != SENT && __builtin_bit_cast(unsigned, (v).y) != SENT && \
@@ -998,22 +1001,29 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             const int wz = wid + vp;
             taco_f4 xp[4];
             int all_fin = 0;                                              // the gate block's stop flags of the previous step ride in the same poll
+            taco_f4 xq[4];
+            unsigned fv = 0u, fn = 0u;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) xp[n] = TACO_LD4(rq, TACO_ATT_XOFF(wz + 4 * n));
+            if (s > 0) fv = __builtin_bit_cast(unsigned, TACO_LD1(rq, R_FIN + (lane & 7)));
+            // (no gap here: the prenet output has usually landed while this block did the early half of the cell)
             for (int spin = 0;; ++spin) {
                 bool okv = true;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    xp[n] = TACO_LD4(rq, TACO_ATT_XOFF(wz + 4 * n));
-                    okv = okv && TACO_OK4(xp[n]);
-                }
+                for (int n = 0; n < 4; ++n) xq[n] = TACO_LD4(rq, TACO_ATT_XOFF(wz + 4 * n));
+                if (s > 0) fn = __builtin_bit_cast(unsigned, TACO_LD1(rq, R_FIN + (lane & 7)));
+#pragma unroll
+                for (int n = 0; n < 4; ++n) okv = okv && TACO_OK4(xp[n]);
                 if (s > 0) {
-                    const unsigned fv = __builtin_bit_cast(unsigned, TACO_LD1(rq, R_FIN + (lane & 7)));
                     const unsigned long long bm = __ballot(fv != 0u || (lane & 7) >= B), vm = __ballot(fv != SENT || (lane & 7) >= B);
                     okv = okv && vm == ~0ull;
                     all_fin = bm == ~0ull;
                 }
                 if (__all(okv)) break;                                    // wave-uniform exit: the ballots above need every lane in the loop
                 if (spin > POLL_LIM) { bad = true; break; }
-                TACO_BACKOFF
+#pragma unroll
+                for (int n = 0; n < 4; ++n) xp[n] = xq[n];
+                fv = fn;
             }
             if (__syncthreads_or(all_fin)) { steps = s; break; }          // (every wave sees the same flags once they are valid)
 #pragma unroll
@@ -1062,16 +1072,22 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #pragma unroll
             for (int n = 0; n < 16; ++n)
                 wqm[n] = *reinterpret_cast<const taco_f4*>(p.wq + (int64_t)(8 * g16 + (c16 & 7)) * 1024 + 16 * (wid + 4 * n + vp) + 4 * kq);
-            for (int spin = 0;; ++spin) {
-                bool okv = true;
+            {                                                             // two polls in flight, half a round trip apart
+                taco_f4 xn[16];
 #pragma unroll
-                for (int n = 0; n < 16; ++n) {
-                    xa[n] = TACO_LD4(rs, TR_ATT + (4 * (wid + 4 * n + vp) + kq) * 32 + bl * 4);
-                    okv = okv && TACO_OK4(xa[n]);
+                for (int n = 0; n < 16; ++n) xa[n] = TACO_LD4(rs, TR_ATT + (4 * (wid + 4 * n + vp) + kq) * 32 + bl * 4);
+                __builtin_amdgcn_s_sleep(TACO_POLL_GAP);
+                for (int spin = 0;; ++spin) {
+                    bool okv = true;
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) xn[n] = TACO_LD4(rs, TR_ATT + (4 * (wid + 4 * n + vp) + kq) * 32 + bl * 4);
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) okv = okv && TACO_OK4(xa[n]);
+                    if (okv) break;
+                    if (spin > POLL_LIM) { bad = true; break; }
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) xa[n] = xn[n];
                 }
-                if (okv) break;
-                if (spin > POLL_LIM) { bad = true; break; }
-                TACO_BACKOFF
             }
             TF_STAMP()   /* 3 att_h in */
             {
@@ -1148,17 +1164,20 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             if (t < n4) {
                 const int pp = b4 * L + t, tp = pp / PT;
                 const int eo = R_EP + tp * PTp + (pp - tp * PT);
-                float ev[16];
+                float ev[16], en[16];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) ev[g] = TACO_LD1(rs, eo + g * 16 * PTp);
+                __builtin_amdgcn_s_sleep(TACO_POLL_GAP);
                 for (int spin = 0;; ++spin) {
                     bool okv = true;
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        ev[g] = TACO_LD1(rs, eo + g * 16 * PTp);
-                        okv = okv && __builtin_bit_cast(unsigned, ev[g]) != SENT;
-                    }
+                    for (int g = 0; g < 16; ++g) en[g] = TACO_LD1(rs, eo + g * 16 * PTp);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) okv = okv && __builtin_bit_cast(unsigned, ev[g]) != SENT;
                     if (okv) break;
                     if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) ev[g] = en[g];
                 }
                 e = 0.f;
 #pragma unroll
@@ -1205,17 +1224,21 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             asm volatile("" : "+v"(vp));
             const int wz = wid + vp;
             constexpr int NC = M_ / 64;
-            taco_f4 xc[NC];
+            // two polls in flight, half a round trip apart: the expected wait after the data lands is a quarter round trip, not half
+            taco_f4 xc[NC], xn[NC];
+#pragma unroll
+            for (int e = 0; e < NC; ++e) xc[e] = TACO_LD4(rs, TACO_DEC_XOFF(wz + 4 * (16 + e)));
+            __builtin_amdgcn_s_sleep(TACO_POLL_GAP);
             for (int spin = 0;; ++spin) {
                 bool okv = true;
 #pragma unroll
-                for (int e = 0; e < NC; ++e) {
-                    xc[e] = TACO_LD4(rs, TACO_DEC_XOFF(wz + 4 * (16 + e)));
-                    okv = okv && TACO_OK4(xc[e]);
-                }
+                for (int e = 0; e < NC; ++e) xn[e] = TACO_LD4(rs, TACO_DEC_XOFF(wz + 4 * (16 + e)));
+#pragma unroll
+                for (int e = 0; e < NC; ++e) okv = okv && TACO_OK4(xc[e]);
                 if (okv) break;
                 if (spin > POLL_LIM) { bad = true; break; }
-                TACO_BACKOFF
+#pragma unroll
+                for (int e = 0; e < NC; ++e) xc[e] = xn[e];
             }
 #pragma unroll
             for (int e = 0; e < NC; ++e) {
@@ -1270,16 +1293,22 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             taco_f4 wp[16], xd[16];
 #pragma unroll
             for (int n = 0; n < 16; ++n) wp[n] = *reinterpret_cast<const taco_f4*>(wrow + 16 * (wz + 4 * n));
-            for (int spin = 0;; ++spin) {
-                bool okv = true;
+            {
+                taco_f4 xn[16];
 #pragma unroll
-                for (int n = 0; n < 16; ++n) {
-                    xd[n] = TACO_LD4(rs, TR_DEC + (4 * (wz + 4 * n) + kq) * 32 + bl * 4);
-                    okv = okv && TACO_OK4(xd[n]);
+                for (int n = 0; n < 16; ++n) xd[n] = TACO_LD4(rs, TR_DEC + (4 * (wz + 4 * n) + kq) * 32 + bl * 4);
+                __builtin_amdgcn_s_sleep(TACO_POLL_GAP);
+                for (int spin = 0;; ++spin) {
+                    bool okv = true;
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) xn[n] = TACO_LD4(rs, TR_DEC + (4 * (wz + 4 * n) + kq) * 32 + bl * 4);
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) okv = okv && TACO_OK4(xd[n]);
+                    if (okv) break;
+                    if (spin > POLL_LIM) { bad = true; break; }
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) xd[n] = xn[n];
                 }
-                if (okv) break;
-                if (spin > POLL_LIM) { bad = true; break; }
-                TACO_BACKOFF
             }
 #pragma unroll
             for (int n = 0; n < 16; ++n) { TACO_MFMA4(pj0, pj1, wp[n], xd[n]) }
@@ -1313,17 +1342,18 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             int vp = 0;
             asm volatile("" : "+v"(vp));
             const int tid = (int)threadIdx.x + vp;
-            taco_f4 xa, xb;
+            taco_f4 xa = TACO_LD4(rs, TR_H0 + tid * 32), xb = TACO_LD4(rs, TR_H0 + tid * 32 + 4);
+            __builtin_amdgcn_s_sleep(TACO_POLL_GAP);
             for (int spin = 0;; ++spin) {
-                xa = TACO_LD4(rs, TR_H0 + tid * 32);
-                xb = TACO_LD4(rs, TR_H0 + tid * 32 + 4);
+                const taco_f4 na = TACO_LD4(rs, TR_H0 + tid * 32), nb = TACO_LD4(rs, TR_H0 + tid * 32 + 4);
                 bool okv = true;                                      // (utterances >= B of a line are never written)
                 const float xs8[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
                 for (int bb = 0; bb < 8; ++bb) okv = okv && (bb >= B || __builtin_bit_cast(unsigned, xs8[bb]) != SENT);
                 if (okv) break;
                 if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
+                xa = na;
+                xb = nb;
             }
             const float xs8[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
             float v[32];
