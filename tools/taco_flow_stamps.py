@@ -28,7 +28,7 @@ def main():
     x = np.frombuffer(raw[32:], dtype=np.uint32)
     st = x[26624:26624 + 8192].reshape(256, 32)[:, 8:19].astype(np.int64)
     names = ['stop flags in', 'S1 late (poll pre, gates, store att_h)', 'poll att_h', 'query + energies + store', 'S5 early', 'S4 (poll epart, softmax, ctx)',
-             'S5 late (poll ctx, gates, store dec_h)', 'S6 (poll dec_h, proj, store h0)', 'S7 (poll h0, prenet 2)', 'S1 early']
+             'S5 late (poll ctx, gates, store dec_h)', 'S6 (poll dec_h, proj, store h0)', 'S1 early (next step)', 'S7 (poll h0, prenet 2)']
     d = np.diff(st, axis=1) * 0.01
     print('step length (block 0): %.2f us' % ((st[0, 10] - st[0, 0]) * 0.01))
     for i, n in enumerate(names):

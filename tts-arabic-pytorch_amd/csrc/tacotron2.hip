@@ -1337,6 +1337,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         }
         __syncthreads();
         TF_STAMP()   /* 8 S6 done (dec_h polled, h0 stored) */
+        // ---------------- S1 early of the next step (context and att_h of this step are complete in memory); on the 64 prenet
+        // blocks it runs while h0 is on its way, so that they are not 4 us behind the others when the prenet output lands
+        TACO_ATT_EARLY(rs, curw)
+        __syncthreads();
+        TF_STAMP()   /* 9 S1 early done */
         // ---------------- S7: prenet layer 2, units 4 bid .. 4 bid + 3 on blocks 0..63
         if (bid < 64) {
             int vp = 0;
@@ -1373,10 +1378,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 if (bb < B) XST(TR_PRE + bid * 32 + bb * 4 + r, a);
             }
         }
-        TF_STAMP()   /* 9 S7 done */
-        // ---------------- S1 early of the next step (context and att_h of this step are complete in memory)
-        TACO_ATT_EARLY(rs, curw)
-        TF_STAMP()   /* 10 S1 early done */
+        TF_STAMP()   /* 10 S7 done */
 #ifdef TP_TIMING
         if (threadIdx.x == 0)
             for (int i = 0; i < 11; ++i) curw[TR_H0 + bid * 32 + 8 + i] = __builtin_bit_cast(float, fst[i]);
