@@ -1066,6 +1066,26 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 sAw[i] = ok ? a : 0.f;
                 sCum[i] = ok ? c : 0.f;
             }
+            __syncthreads();
+            // the location term of this tile's energies depends on the previous alignment only: computed now, while att_h is on its way
+            float locv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = tid + 256 * u;
+                locv[u] = 0.f;
+                if (it < (p1 - p0) * 8) {
+                    const int pair = it >> 3, d = it & 7, pp = p0 + pair, b = pp / L, t = pp - b * L;
+                    const float* gd = sG + d * 2 * KS;
+                    float loc = 0.f;
+                    for (int k = 0; k < KS; ++k) {
+                        const int tt = t + k - half;
+                        const bool ok = tt >= 0 && tt < L;
+                        loc = fmaf(gd[k], ok ? sAw[pair + k] : 0.f, loc);
+                        loc = fmaf(gd[KS + k], ok ? sCum[pair + k] : 0.f, loc);
+                    }
+                    locv[u] = loc;
+                }
+            }
             // query rows on the matrix pipe: rows 8 g16 .. + 7 (duplicated into the tile's rows 8..15), 64 super-steps over K = 1024,
             // 16 per wave; the weights are constants: fetched before the wait for att_h
             taco_f4 wqm[16], xa[16];
@@ -1102,21 +1122,17 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 sPq[tid] = cred[src] + cred[256 + src] + cred[512 + src] + cred[768 + src];
             }
             __syncthreads();
-            for (int it = tid; it < (p1 - p0) * 8; it += 256) {
-                const int pair = it >> 3, d = it & 7, pp = p0 + pair, b = pp / L, t = pp - b * L;
-                const float* gd = sG + d * 2 * KS;
-                float loc = 0.f;
-                for (int k = 0; k < KS; ++k) {
-                    const int tt = t + k - half;
-                    const bool ok = tt >= 0 && tt < L;
-                    loc = fmaf(gd[k], ok ? sAw[pair + k] : 0.f, loc);
-                    loc = fmaf(gd[KS + k], ok ? sCum[pair + k] : 0.f, loc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = tid + 256 * u;
+                if (it < (p1 - p0) * 8) {                                 // (whole groups of 8 lanes are in or out together)
+                    const int pair = it >> 3, d = it & 7, pp = p0 + pair, b = pp / L;
+                    float val = sV[d] * tanhf(sPq[d * 8 + b] + locv[u] + sPm[pair * 8 + d]);
+                    val += __shfl_xor(val, 1);
+                    val += __shfl_xor(val, 2);
+                    val += __shfl_xor(val, 4);
+                    if (d == 0) XST(R_EP + (g16 * 16 + tile) * PTp + pair, val);
                 }
-                float val = sV[d] * tanhf(sPq[d * 8 + b] + loc + sPm[pair * 8 + d]);
-                val += __shfl_xor(val, 1);
-                val += __shfl_xor(val, 2);
-                val += __shfl_xor(val, 4);
-                if (d == 0) XST(R_EP + (g16 * 16 + tile) * PTp + pair, val);
             }
         }
         TF_STAMP()   /* 4 energies stored */
