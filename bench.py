@@ -142,6 +142,9 @@ def main():
     ap.add_argument('--tokens', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-small', action='store_true', help='skip the batch 1 / batch 8 sub-results (N=1 only)')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='two HIP streams (ttsamd.pipeline): FastPitch of step i+1 under HiFi-GAN of step i; measured +1.3 %% at '
+                         'B=32 (the conv engine is busy either way), so the default stays the one-stream schedule')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16x3'],
                     help='MFMA operand precision of the conv/linear GEMMs (f32 = BASELINE config 2; bf16 = config 3; '
                          'bf16x3 = split bf16, fp32-class accuracy)')
@@ -211,8 +214,19 @@ def main():
     dur = torch.from_numpy(dur_all[rank * B:(rank + 1) * B]).to(dev)
     hop = hg.hop
 
+    # --pipeline: two HIP streams (ttsamd.pipeline), the acoustic model of step i + 1 (150 short launches) under the vocoder of
+    # step i.  Same work per step, same results; 79.4 -> 78.4 ms per step at B=32 (only FastPitch's non-conv kernels find idle CUs).
+    from ttsamd.pipeline import FastPitchHifiGan
+    pipe = FastPitchHifiGan(fp, hg, dev) if args.pipeline else None
+
     def make_step(ids_, dur_):
         if world == 1:
+            if pipe is not None:
+                def step():
+                    _, dec_lens, wave = pipe.submit(ids_, dur_tgt=dur_)
+                    return wave, dec_lens
+                return step
+
             def step():
                 mel, dec_lens, *_ = fp.infer(ids_, dur_tgt=dur_)
                 return hg.forward(mel, dec_lens), dec_lens
@@ -223,13 +237,19 @@ def main():
             state['all'] = dpx.exchange_lens(dec_lens, ids_.shape[0])
             return state['all'][rank, 1:1 + ids_.shape[0]]
 
-        def step():
-            mel, dec_lens, *_ = fp.infer(ids_, dur_tgt=dur_, lens_hook=hook)
+        def vocode(mel, dec_lens):
             wave = hg.forward(mel, dec_lens)
             all_samples = state['all'].copy()
             all_samples[:, 1:] *= hop
             dpx.gather_flat(wave, dec_lens * hop, all_lens=all_samples)     # C2: audio fan-in to rank 0
-            return wave, dec_lens
+            return wave
+
+        def step():
+            if pipe is not None:
+                _, dec_lens, wave = pipe.submit(ids_, vocode=vocode, dur_tgt=dur_, lens_hook=hook)
+                return wave, dec_lens
+            mel, dec_lens, *_ = fp.infer(ids_, dur_tgt=dur_, lens_hook=hook)
+            return vocode(mel, dec_lens), dec_lens
         return step
 
     step = make_step(ids, dur)
@@ -331,10 +351,12 @@ def main():
             'rtf': elapsed / (samples / SAMPLE_RATE),
             'config': {'workload': f'FastPitch+HiFi-GAN, synthetic {Lt}-phoneme x batch{B} per GPU, {prec_name}, '
                                    f'{world}xMI355X', 'batch_per_gpu': B, 'n_tokens': Lt,
-                       'frames_per_step_rank0': frames, 'parallelism': par, 'dp_transport': transport},
+                       'frames_per_step_rank0': frames, 'parallelism': par, 'dp_transport': transport,
+                       'schedule': ('two HIP streams: FastPitch of step i+1 under HiFi-GAN of step i (ttsamd.pipeline)' if args.pipeline else
+                                    'one stream per step')},
             'roofline': {'bound': 'mfma' if args.precision == 'f32' else 'hbm (fp32 activations; MFMA figures for reference)',
                          'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
-                         'kernel_time_basis': 'HIP events on the launch stream: one pair per launch, one pair per fork..join section of the three-stream ResBlock schedule (wall time of the section)',
+                         'kernel_time_basis': 'HIP events on the launch stream: one pair per launch, one pair per fork..join section of the three-stream ResBlock schedule (wall time of the section); kernel time = length of the UNION of these intervals (the two pipeline streams overlap)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
                          'launches': int(n_launch), 'avg_launch_ms': conv_ms / max(1.0, n_launch),

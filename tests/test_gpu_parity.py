@@ -669,3 +669,22 @@ def test_fused_pair_and_all_phase_convt_match_the_generic_engine(dev, synth_weig
     monkeypatch.delenv('TTSAMD_FUSED_PAIR')
     monkeypatch.delenv('TTSAMD_CONVT')
     assert torch.equal(hifigan_engine.forward(mel, lens), out)          # both are the default
+
+
+def test_two_stream_pipeline_bit_identical(dev, synth_weights, fastpitch_engine, hifigan_engine):
+    """ttsamd.pipeline.FastPitchHifiGan: FastPitch of batch i + 1 on its own stream under HiFi-GAN of batch i gives the same
+    waves, bit for bit, as issuing the two stages of each batch on one stream."""
+    from ttsamd import synth
+    from ttsamd.pipeline import FastPitchHifiGan
+    ids = torch.from_numpy(synth.synth_ids(6, 20)).to(dev)
+    dur = torch.from_numpy(synth.synth_durations(6, 20)).to(dev)
+    ref = []
+    for i in range(3):
+        mel, dl, *_ = fastpitch_engine.infer(ids[2 * i:2 * i + 2], dur_tgt=dur[2 * i:2 * i + 2])
+        ref.append((hifigan_engine.forward(mel, dl).clone(), dl.clone()))
+    pipe = FastPitchHifiGan(fastpitch_engine, hifigan_engine, dev)
+    got = [pipe.submit(ids[2 * i:2 * i + 2], dur_tgt=dur[2 * i:2 * i + 2]) for i in range(3)]
+    pipe.join()
+    torch.cuda.synchronize()
+    for (w_ref, dl_ref), (_, dl, w) in zip(ref, got):
+        assert torch.equal(dl, dl_ref) and torch.equal(w, w_ref)

@@ -1,6 +1,7 @@
 // extern "C" surface of libttsamd.so (include/ttsamd.h): argument checks, error strings,
 // the launch-timing hooks used by bench.py, and thin forwards into the model code.
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -368,13 +369,30 @@ int32_t ttsamd_profile_enable(int32_t on) {
 int32_t ttsamd_profile_read(double* out3) {
     TTS_REQUIRE(out3, "profile_read: null argument");
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    double ms = 0.0;
+    // busy time of the conv engine = length of the UNION of the sections' intervals: on one stream the sections follow each
+    // other (union = sum); with the acoustic model of batch i + 1 on a second stream under the vocoder of batch i
+    // (ttsamd.pipeline) they overlap, and a sum would count the shared time twice
+    std::vector<std::pair<float, float>> iv;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         TTS_CHECK_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
-        float t = 0.f;
-        TTS_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
-        ms += t;
+        float t0 = 0.f, t1 = 0.f;
+        if (i > 0) TTS_CHECK_HIP(hipEventElapsedTime(&t0, g_prof.ev[0], g_prof.ev[i]));
+        TTS_CHECK_HIP(hipEventElapsedTime(&t1, g_prof.ev[0], g_prof.ev[i + 1]));
+        iv.emplace_back(t0, std::max(t0, t1));
     }
+    std::sort(iv.begin(), iv.end());
+    double ms = 0.0;
+    float lo = 0.f, hi = -1.f;
+    for (const auto& v : iv) {
+        if (hi < lo || v.first > hi) {
+            if (hi >= lo) ms += hi - lo;
+            lo = v.first;
+            hi = v.second;
+        } else {
+            hi = std::max(hi, v.second);
+        }
+    }
+    if (hi >= lo) ms += hi - lo;
     out3[0] = ms;
     out3[1] = (double)g_prof.launches;
     out3[2] = g_prof.flops_per_frame;
