@@ -688,3 +688,27 @@ def test_two_stream_pipeline_bit_identical(dev, synth_weights, fastpitch_engine,
     torch.cuda.synchronize()
     for (w_ref, dl_ref), (_, dl, w) in zip(ref, got):
         assert torch.equal(dl, dl_ref) and torch.equal(w, w_ref)
+
+
+def test_dropin_tts_list_pipeline_bit_identical(dev, golden, checkpoints, monkeypatch, capsys):
+    """`FastPitch2Wave.tts(list)` over several chunks runs as a three-stream pipeline (FastPitch of chunk k + 1 under the
+    vocoder of chunk k, D2H on a third stream): same waves, bit for bit, as the one-stream loop, for batch_size 1 (tts_single
+    per line) and 2 (tts_batch), denoiser on; prints both timings."""
+    import time
+    from models.fastpitch import FastPitch2Wave
+    lines = _lines(golden, range(24))
+    model = FastPitch2Wave(checkpoints[0], vocoder_sd=checkpoints[1], vocoder_config=checkpoints[2]).to(dev)
+    for bs in (1, 2, 5):
+        res = {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('TTSAMD_TTS_PIPELINE', mode)
+            model.tts(lines[:4], batch_size=bs)                              # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res[mode] = (model.tts(lines, batch_size=bs), time.perf_counter() - t0)
+        a, b = res['0'][0], res['1'][0]
+        assert len(a) == len(b) == len(lines)
+        for x, y in zip(a, b):
+            assert x.device.type == 'cpu' and torch.equal(x, y)
+        with capsys.disabled():
+            print(f'\n[tts list, {len(lines)} lines, batch_size {bs}] one stream {res["0"][1] * 1e3:.1f} ms, pipelined {res["1"][1] * 1e3:.1f} ms')

@@ -12,6 +12,7 @@ utterance edge — `vowelizer=` runs the Shakkelha / Shakkala taggers of models/
 from typing import List, Optional, Union
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -231,9 +232,10 @@ class FastPitch2Wave(nn.Module):
         n = (dec_lens * self.vocoder.engine().hop)
         if denoise > 0:
             wave = self.denoiser.forward_batch(wave, n, denoise)
-        wave, n = wave.cpu(), n.tolist()                                 # one D2H for the whole batch
+        n = n.tolist()
+        # one exact-size D2H per utterance (a padded [B, n_max] copy + per-row clones touches every host page twice)
         # NB the reference silently ignores return_mel here (:347-350); so do we
-        return [wave[j, :n[j]].clone() for j in reverse_ids.tolist()]
+        return [wave[j, :n[j]].cpu() for j in reverse_ids.tolist()]
 
     def tts(self, text_input: Union[str, List[str]], speed: float = 1., denoise: float = 0.005, speaker_id: int = 0,
             batch_size: int = 2, vowelizer=None, pitch_mul: float = 1., pitch_add: float = 0.,
@@ -245,9 +247,73 @@ class FastPitch2Wave(nn.Module):
         if isinstance(text_input, str):
             return self.tts_single(text_input, **kw)
         assert isinstance(text_input, list)
+        if (len(text_input) > batch_size and not return_mel and self.device.type == 'cuda'
+                and os.environ.get('TTSAMD_TTS_PIPELINE', '1') != '0'):
+            return self._tts_list_pipelined(text_input, batch_size, **kw)
         if batch_size == 1:
             return [self.tts_single(sample, **kw) for sample in text_input]
         wav_list = []
         for k in range(0, len(text_input), batch_size):
             wav_list += self.tts_batch(text_input[k:k + batch_size], **kw)
         return wav_list
+
+    @torch.inference_mode()
+    def _tts_list_pipelined(self, text_input, batch_size, speed, denoise, speaker_id, vowelizer, pitch_mul, pitch_add,
+                            return_mel=False):
+        """The list path of `tts` over several chunks, as a three-stage pipeline on three HIP streams: tokenisation + FastPitch
+        of chunk k + 1 (host work and ~150 short launches that leave most CUs idle) run under the vocoder + denoiser of chunk
+        k, whose audio is copied to the host on a third stream.  Every chunk goes through exactly the calls of the one-stream
+        loop (`tts_single` for batch_size 1, `tts_batch` otherwise), each engine sees its own calls in order on its own
+        stream: the waves are bit-identical, only the schedule differs (C1, 100 lines at batch 1: see DESIGN.md)."""
+        dev = self.device
+        if getattr(self, '_pipe_streams', None) is None or self._pipe_streams[0].device != dev:
+            self._pipe_streams = tuple(torch.cuda.Stream(dev) for _ in range(3))
+        s_fp, s_hg, s_cp = self._pipe_streams
+        cur = torch.cuda.current_stream(dev)
+        for st in (s_fp, s_hg, s_cp):
+            st.wait_stream(cur)
+        hop = self.vocoder.engine().hop
+        out, pending = [], None
+
+        def flush(item):
+            wave, n, rev, done = item
+            s_cp.wait_event(done)
+            with torch.cuda.stream(s_cp):
+                wave.record_stream(s_cp)
+                if rev is None:
+                    out.append(wave[0].cpu())                            # blocks the host on THIS chunk's audio only
+                else:
+                    out.extend(wave[j, :n[j]].cpu() for j in rev.tolist())
+
+        for k in range(0, len(text_input), batch_size):
+            chunk = text_input[k:k + batch_size]
+            with torch.cuda.stream(s_fp):
+                if batch_size == 1:
+                    mel = self.model.ttmel_single(chunk[0], speed, speaker_id, vowelizer, pitch_mul=pitch_mul, pitch_add=pitch_add)
+                    dec_lens = rev = None
+                else:
+                    mel, dec_lens, rev = self.model._ttmel_batch_padded(chunk, speed, speaker_id, vowelizer, pitch_mul, pitch_add)
+                    n_host = (dec_lens.cpu() * hop).tolist()             # (FastPitch has synchronised on these lengths already)
+            s_hg.wait_stream(s_fp)
+            with torch.cuda.stream(s_hg):
+                mel.record_stream(s_hg)
+                if batch_size == 1:
+                    wave, n = self.vocoder(mel), None
+                    if denoise > 0:
+                        wave = self.denoiser(wave, denoise)
+                else:
+                    dec_lens.record_stream(s_hg)
+                    wave = self.vocoder.engine().forward(mel, dec_lens)
+                    if denoise > 0:
+                        wave = self.denoiser.forward_batch(wave, dec_lens * hop, denoise, nsamples_min=min(n_host))
+                    n = n_host
+                done = torch.cuda.Event()
+                done.record(s_hg)
+            if pending is not None:
+                flush(pending)
+            pending = (wave, n, rev, done)
+        if pending is not None:
+            flush(pending)
+        cur.wait_stream(s_hg)
+        cur.wait_stream(s_cp)
+        return out

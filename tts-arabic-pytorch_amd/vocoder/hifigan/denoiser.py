@@ -39,17 +39,21 @@ class Denoiser(_HipModule):
         """audio [1, n] (or [1,1,n] / [n]) -> denoised audio of the same shape (denoiser.py:66-72)."""
         shape = audio.shape
         wave = audio.float().reshape(1, -1).contiguous().clone()
-        n = torch.tensor([wave.shape[1]], dtype=torch.int64, device=wave.device)
-        out = self.forward_batch(wave, n, strength)
+        n = torch.full((1,), wave.shape[1], dtype=torch.int64, device=wave.device)      # a fill, not a (stream-ordered, host-blocking) H2D copy
+        out = self.forward_batch(wave, n, strength, nsamples_min=wave.shape[1])
         n_out = (wave.shape[1] // 256) * 256
         return out[:, :n_out].reshape(shape[:-1] + (n_out,))
 
     @torch.inference_mode()
-    def forward_batch(self, wave, nsamples, strength):
-        """Ragged batch (extension): wave [B, n_max] float32 on the GPU, nsamples int64 [B]."""
-        if wave.shape[0] and int(nsamples.min()) <= 512:
+    def forward_batch(self, wave, nsamples, strength, nsamples_min=None):
+        """Ragged batch (extension): wave [B, n_max] float32 on the GPU, nsamples int64 [B].  `nsamples_min`: the smallest
+        length if the caller has it on the host already (FastPitch synchronises on the lengths anyway) -- reading it from the
+        device here would stall the host until the vocoder has finished, which is what the pipelined `tts` list path overlaps."""
+        if nsamples_min is None and wave.shape[0]:
+            nsamples_min = int(nsamples.min())
+        if wave.shape[0] and nsamples_min <= 512:
             # the reference's Spectrogram(center=True, pad_mode='reflect') needs more than n_fft/2 samples and raises
             raise ValueError('Denoiser: every utterance needs more than 512 samples (reflect padding of n_fft/2); '
-                             f'shortest has {int(nsamples.min())}')
+                             f'shortest has {nsamples_min}')
         eng = self._engine(lambda d: DenoiserEngine(device=d))
         return eng.denoise(wave.contiguous(), nsamples, self._bias_spec(wave.device), strength)
