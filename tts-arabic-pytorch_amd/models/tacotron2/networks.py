@@ -189,17 +189,18 @@ class Tacotron2Wave(nn.Module):
                   speaker_id: int = 0, vowelizer=None, postprocess_mel: bool = True, return_mel: bool = False):
         mel_list = self.model.ttmel_batch(batch, speaker_id, speed, vowelizer, postprocess_mel)
         eng = self.vocoder.engine()
-        lens = torch.tensor([m.shape[-1] for m in mel_list], dtype=torch.int64, device=mel_list[0].device)
-        mel = torch.zeros(len(mel_list), mel_list[0].shape[0], int(lens.max()), device=lens.device)
+        lens_host = [m.shape[-1] for m in mel_list]
+        lens = torch.tensor(lens_host, dtype=torch.int64, device=mel_list[0].device)
+        mel = torch.zeros(len(mel_list), mel_list[0].shape[0], max(lens_host), device=lens.device)
         for i, m in enumerate(mel_list):
             mel[i, :, :m.shape[-1]] = m
         wave = eng.forward(mel, lens)                                    # one ragged batched launch sequence
-        n = lens * eng.hop
+        n = [t * eng.hop for t in lens_host]
         if denoise > 0:
-            wave = self.denoiser.forward_batch(wave, n, denoise)
-        wave, n = wave.cpu(), n.tolist()
+            wave = self.denoiser.forward_batch(wave, lens * eng.hop, denoise, nsamples_min=min(n))
+        # one exact-size D2H per utterance (a padded [B, n_max] copy + per-row clones touches every host page twice)
         # NB the reference silently ignores return_mel here (:348-351); so do we
-        return [wave[i, :n[i]].clone() for i in range(len(mel_list))]
+        return [wave[i, :n[i]].cpu() for i in range(len(mel_list))]
 
     def tts(self, text_buckw: Union[str, List[str]], speed: Union[int, float, None] = None, denoise: float = 0.005,
             speaker_id: int = 0, batch_size: int = 8, vowelizer=None, postprocess_mel: bool = True,
