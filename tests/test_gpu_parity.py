@@ -712,3 +712,18 @@ def test_dropin_tts_list_pipeline_bit_identical(dev, golden, checkpoints, monkey
             assert x.device.type == 'cpu' and torch.equal(x, y)
         with capsys.disabled():
             print(f'\n[tts list, {len(lines)} lines, batch_size {bs}] one stream {res["0"][1] * 1e3:.1f} ms, pipelined {res["1"][1] * 1e3:.1f} ms')
+
+
+def test_fastpitch_deep_splitk_tiles(dev, fastpitch_engine, monkeypatch):
+    """Batch 8 x 64 tokens (~450 frames each): the second conv-FF conv of the decoder (1536 -> 384) runs as 128 x 64 tiles with K
+    split into slices + a reduce launch; same mel as the un-split 64 x 64 tiles up to the summation order."""
+    from ttsamd import synth
+    ids = torch.from_numpy(synth.synth_ids(8, 64)).to(dev)
+    dur = torch.from_numpy(synth.synth_durations(8, 64)).to(dev)
+    monkeypatch.setenv('TTSAMD_DEEP_SPLITK', '0')
+    mel0, dl0, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
+    monkeypatch.setenv('TTSAMD_DEEP_SPLITK', '1')
+    mel1, dl1, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
+    assert torch.equal(dl0, dl1) and bool(torch.isfinite(mel1).all())
+    assert maxabs(mel0, mel1) < 2e-5
+    assert not torch.equal(mel0, mel1)          # the other schedule did run

@@ -101,6 +101,7 @@ struct ConvParams {
     unsigned long long* timing;   // tools/conv_bench -DTTS_TIMING only: [blocks][8] clock samples (nullptr otherwise)
 };
 constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)
+constexpr int64_t kSplitKFloatsFp = 8 << 20; // FastPitch: 32 MB, the deep conv-FF conv (1536 -> 384) splits K at batch 4..13 too
 
 void conv_log(const char* kind, int K, int cin, int cout, int nout, int batch, int has_res, int mode, int len_mul, int ragged,
               int n_phase);

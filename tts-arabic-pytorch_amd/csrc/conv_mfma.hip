@@ -732,6 +732,13 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
         if (few_long && K >= 7 && blocks(64, 128) >= want) return launch_cfg<K, 1, 2, 2, 2>(p, stream);  //  64 co x 128 t
         if (K < 11 && !tiny && blocks(128, 128) >= want) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
         if (K == 11 && !tiny && blocks(64, 256) >= want) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
+        // deep K, a few hundred tiles (FastPitch's second conv-FF conv, 1536 -> 384, at batch 7..13): 128 x 64 tiles with K split
+        // (launch_cfg: < 320 tiles -> 2..4 slices) instead of twice as many 64 x 64 tiles that each walk all 96 chunks
+        if (p.splitk_ws && p.Cin >= 1024 && !tiny && blocks(128, 64) >= 160 && blocks(128, 64) < 320 &&
+            (int64_t)2 * p.batch * p.Cout * p.Nout <= p.splitk_floats) {
+            const char* e = getenv("TTSAMD_DEEP_SPLITK");                    // read per launch of this (rare) shape: the tests flip it
+            if (!(e && e[0] == '0')) return launch_cfg<K, 1, 2, 4, 1>(p, stream);
+        }
         if (blocks(128, 64) >= want || (tiny && blocks(64, 64) < 2 * want)) return launch_cfg<K, 1, 2, 4, 1>(p, stream);   // 128 co x 64 t
         return launch_cfg<K, 1, 1, 2, 2>(p, stream);                                                    //  64 co x  64 t
     }

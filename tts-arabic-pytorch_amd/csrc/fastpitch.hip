@@ -247,7 +247,7 @@ static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, floa
     p.Cin = c.cin; p.Cout = c.cout; p.CoutP = cout_padded(c.cout); p.K = c.k;
     p.dil = 1; p.pad = c.k / 2;
     p.n_phase = 1; p.in_slope = 1.0f; p.relu_out = relu; p.mode = 0; p.div = 1.f; p.batch = B;
-    p.splitk_ws = t_splitk_ws; p.splitk_floats = t_splitk_ws ? kSplitKFloats : 0;
+    p.splitk_ws = t_splitk_ws; p.splitk_floats = t_splitk_ws ? kSplitKFloatsFp : 0;
     prof_begin(s, 2.0 * c.cout * c.cin * c.k);
     const int32_t rc = launch_conv(p, s);
     prof_end(s);
@@ -305,7 +305,7 @@ static void carve_enc(const FastPitch* h, Arena& a, int B, int L, EncWs& w) {
     w.p1 = a.take<float>((int64_t)B * filt * L);
     w.log_dur = a.take<float>((int64_t)B * L);
     w.lens = a.take<int64_t>(B);
-    w.f.splitk = a.take<float>(kSplitKFloats);
+    w.f.splitk = a.take<float>(kSplitKFloatsFp);
 }
 
 int64_t fastpitch_encode_workspace_bytes(const FastPitch* h, int32_t B, int32_t L) {
@@ -364,7 +364,7 @@ static void carve_dec(const FastPitch* h, Arena& a, int B, int T, FftWs& w) {
     w.a = a.take<float>((int64_t)B * c.out_fft_n_heads * c.out_fft_d_head * T);
     w.y = a.take<float>((int64_t)B * c.d_model * T);
     w.hid = a.take<float>((int64_t)B * c.out_fft_filter * T);
-    w.splitk = a.take<float>(kSplitKFloats);
+    w.splitk = a.take<float>(kSplitKFloatsFp);
 }
 
 int64_t fastpitch_decode_workspace_bytes(const FastPitch* h, int32_t B, int32_t T) {
