@@ -246,9 +246,40 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
                       int32_t lin, float in_slope, int32_t relu_out, float* y, float* packed,
                       void* stream);
 
+/* ---- bf16 octet engine (BASELINE config 3), kernel-level entries used by the parity tests and the roofline bench.
+ *      Activations are [B][C/8][L][8] bf16 ("octet" layout: one 16-byte entry = 8 channels of one position = one lane's B
+ *      operand of v_mfma_f32_32x32x16_bf16), stored PRE-ACTIVATED: a = leaky_relu(x, slope of the consumer).  Replaces
+ *      ResBlock1.forward / Generator.forward's convs (vocoder/hifigan/models.py:46-53, 111-127) when
+ *      ttsamd_set_precision(1) is in force; ttsamd_hifigan_forward routes through it by itself. ------------------------- */
+/* fp32 channel-first [B][C][len] -> octet bf16 with leaky_relu(slope) applied (slope 1 = raw); and back (inverse applied) */
+int32_t ttsamd_bfo_pack(const float* x, int32_t batch, int32_t channels, int32_t len, float slope, void* out, void* stream);
+int32_t ttsamd_bfo_unpack(const void* in, int32_t batch, int32_t channels, int32_t len, float slope, float* out, void* stream);
+/* HOST: torch Conv1d weight [Cout][Cin][K] (up = 1) or ConvTranspose1d weight [Cin][Cout][2*up] (stride up, padding up/2)
+ * -> bf16 [phases][Cin/16][K][2][CoutP][8]; `out` holds ttsamd_bfo_weight_elems(...) uint16 */
+int64_t ttsamd_bfo_weight_elems(int32_t cout, int32_t cin, int32_t k, int32_t up);
+int32_t ttsamd_bfo_pack_weight(const float* w, int32_t cout, int32_t cin, int32_t k, int32_t up, uint16_t* out);
+/* y = act_out(([sum_in +] conv(x) + bias [+ raw(res)]) [/ div]): x, res activated tensors, sum_in raw; mode as below.
+ * up > 1: ConvTranspose1d(stride up), y has len_in * up positions (no res / sum). */
+int32_t ttsamd_bfo_conv1d(const void* x, const void* w_packed, const float* bias, const void* res, const void* sum_in,
+                          const int64_t* lens, int32_t len_mul, int32_t batch, int32_t cin, int32_t cout, int32_t k,
+                          int32_t dilation, int32_t up, int32_t len_in, int32_t mode, float div, float res_slope,
+                          float out_slope, void* y, void* stream);
+/* one c1 -> c2 pair of ResBlock1 (models.py:46-53) in one launch, C in {32, 64, 128}, k in {3, 7, 11}:
+ *   v = raw(x) + conv(lrelu(conv(x, w1, dilation) + b1, mid_slope), w2) + b2
+ *   mode 0: y = act(v)   1: y = act(sum_in + v)   2: y = act((sum_in + v) / div);   act = leaky_relu(out_slope), 1 = raw.
+ * x is stored activated with in_slope; y must not alias x. */
+int32_t ttsamd_bfo_resblock_pair(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                                 const void* sum_in, const int64_t* lens, int32_t len_mul, int32_t batch, int32_t channels,
+                                 int32_t k, int32_t dilation, int32_t len, int32_t mode, float div, float in_slope,
+                                 float mid_slope, float out_slope, void* y, void* stream);
+/* wave[b][t] = tanh(bias + conv7(x)); x = 32-channel octet tensor already activated with slope 0.01 (models.py:123-125) */
+int32_t ttsamd_bfo_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul,
+                             int32_t batch, int32_t channels, int32_t len, float* wave, int64_t wave_stride, void* stream);
+
 /* MFMA operand precision of every conv/linear GEMM launched by the model forwards (process-wide):
  *   0 (default) exact fp32 (v_mfma_f32_32x32x2_f32) — BASELINE config 2;
- *   1 bf16 operands, fp32 accumulate (v_mfma_f32_32x32x8_bf16_1k) — config 3;
+ *   1 bf16 operands, fp32 accumulate — config 3: HiFi-GAN on the octet engine above (v_mfma_f32_32x32x16_bf16, bf16
+ *     activations in HBM), the other models on v_mfma_f32_32x32x8_bf16_1k with fp32 activations;
  *   2 split bf16 (x = hi + lo, 3 MFMAs per product): fp32-class accuracy at bf16 MFMA rate.
  * Activations, LayerNorm, softmax, tanh, the DFTs and all integer work stay fp32/int64. */
 int32_t ttsamd_set_precision(int32_t precision);

@@ -1,0 +1,194 @@
+"""GPU parity of the bf16 octet engine (BASELINE config 3), layer by layer through the C ABI (pytest -m gpu).
+
+Checker: the reference's ops (torch conv1d / conv_transpose1d / leaky_relu, vocoder/hifigan/models.py:46-53, 96-99,
+111-127) in float64 on the host, fed the SAME bf16-rounded operands the kernel sees (stored activations, bf16 weights, the
+bf16 c1 -> c2 intermediate), so what is left is fp32-vs-fp64 accumulation plus one bf16 rounding of the output:
+|diff| <= 2^-7 |ref| + 1e-2 (stated tolerance; an indexing bug shows up as O(1)).  The end-to-end bf16 tolerances
+against the fp32 oracle are in tests/test_gpu_fullsize.py / test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    from ttsamd import lib
+    assert lib.load().ttsamd_device_ok() == 1
+    return torch.device('cuda:0')
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def lrelu(x, s):
+    return torch.where(x > 0, x, x * s)
+
+
+def close(got, ref, what):
+    got, ref = got.double(), ref.double()
+    err = (got - ref).abs()
+    tol = ref.abs() * 2.0 ** -7 + 1e-2
+    bad = err > tol
+    assert not bool(bad.any()), f'{what}: {int(bad.sum())} of {bad.numel()} off, worst {float(err.max()):.4f} ' \
+                                f'(ref there {float(ref.flatten()[err.argmax()]):.4f})'
+
+
+def test_pack_unpack_roundtrip(dev):
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 80, 333, generator=g) * 3
+    for slope in (1.0, 0.1, 0.01):
+        t = bfo.pack(x.to(dev), slope)
+        raw = bfo.unpack(t, 1.0).cpu()
+        assert torch.equal(raw.double(), bf(lrelu(x, slope).float()))              # RNE, exactly torch's bf16 cast
+        back = bfo.unpack(t, slope).cpu()
+        assert float((back - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -7
+
+
+def _pair_ref(a, w1, b1, w2, b2, k, dil, n, sum_raw, mode, div, in_slope, out_slope):
+    """a: stored (activated, bf16-valued) input [C, n] float64 of one utterance -> stored output [C, n]."""
+    x_raw = torch.where(a >= 0, a, a / in_slope)
+    t = F.conv1d(a[None], bf(w1), b1.double(), dilation=dil, padding=(k - 1) * dil // 2)[0]
+    t = bf(lrelu(t, 0.1).float())
+    v = x_raw + F.conv1d(t[None], bf(w2), b2.double(), padding=(k - 1) // 2)[0]
+    if mode != 0:
+        v = v + sum_raw
+    if mode == 2:
+        v = v / div
+    return lrelu(v, out_slope)
+
+
+@pytest.mark.parametrize('C,k,dil,L,mode,out_slope', [
+    (128, 3, 1, 700, 0, 0.1), (128, 7, 3, 515, 1, 1.0), (128, 11, 5, 300, 2, 0.01),
+    (64, 3, 5, 1100, 2, 0.1), (64, 7, 1, 600, 0, 0.1), (64, 11, 3, 1000, 1, 1.0),
+    (32, 3, 3, 2100, 1, 1.0), (32, 7, 5, 1030, 2, 0.01), (32, 11, 1, 2500, 0, 0.1),
+])
+def test_resblock_pair(dev, C, k, dil, L, mode, out_slope):
+    """Fused c1 -> c2 pair vs the reference ops; ragged batch incl. an utterance ending inside a tile halo, one ending
+    before the first tile boundary, and the untouched tail past each length."""
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + dil)
+    B = 3
+    x = torch.randn(B, C, L, generator=g) * 1.5
+    w1 = torch.randn(C, C, k, generator=g) / np.sqrt(C * k)
+    w2 = torch.randn(C, C, k, generator=g) / np.sqrt(C * k)
+    b1, b2 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    s_raw = torch.randn(B, C, L, generator=g)
+    ts = {128: 256, 64: 512, 32: 1024}[C] - (k - 1)
+    lens = torch.tensor([L, min(L, ts + 2), max(1, min(L, ts) - 5)], dtype=torch.int64)     # ends 2 columns into tile 1 / inside tile 0
+    xo = bfo.pack(x.to(dev), 0.1)
+    so = bfo.pack(s_raw.to(dev), 1.0)
+    y = torch.full_like(xo, 0x4242)
+    if mode != 0:
+        y.copy_(so)                                                                    # sum_in may alias y
+    bfo.resblock_pair(xo, bfo.pack_weight(w1, device=dev), b1.to(dev), bfo.pack_weight(w2, device=dev), b2.to(dev), k, dil,
+                      lens=lens.to(dev), sum_in=y if mode != 0 else None, mode=mode, div=3.0, out_slope=out_slope, y=y)
+    got = bfo.unpack(y, 1.0).cpu()
+    a_all = bfo.unpack(xo, 1.0).cpu().double()
+    s_all = bfo.unpack(so, 1.0).cpu().double()
+    before = bfo.unpack(so if mode != 0 else torch.full_like(xo, 0x4242), 1.0).cpu()
+    for i in range(B):
+        n = int(lens[i])
+        ref = _pair_ref(a_all[i, :, :n], w1, b1, w2, b2, k, dil, n, s_all[i, :, :n], mode, 3.0, 0.1, out_slope)
+        close(got[i, :, :n], ref, f'utt {i} (len {n})')
+        assert torch.equal(got[i, :, n:], before[i, :, n:]), 'positions past the utterance must stay untouched'
+
+
+@pytest.mark.parametrize('cin,cout,k,dil,L,mode,res', [
+    (256, 256, 3, 1, 600, 0, False), (256, 256, 7, 3, 300, 1, True), (256, 256, 11, 5, 515, 2, True),
+    (80, 512, 7, 1, 90, 0, False), (128, 64, 3, 1, 700, 0, False), (64, 32, 7, 1, 1500, 0, True), (512, 128, 1, 1, 100, 0, False),
+])
+def test_conv1d(dev, cin, cout, k, dil, L, mode, res):
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(cin + cout + k)
+    B = 2
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g) * 0.3
+    r_raw, s_raw = torch.randn(B, cout, L, generator=g), torch.randn(B, cout, L, generator=g)
+    lens = torch.tensor([L, max(1, L - 37)], dtype=torch.int64)
+    xo, ro, so = bfo.pack(x.to(dev), 0.1), bfo.pack(r_raw.to(dev), 0.1), bfo.pack(s_raw.to(dev), 1.0)
+    y = so.clone() if mode != 0 else torch.full_like(so, 0x4242)
+    bfo.conv1d(xo, bfo.pack_weight(w, device=dev), b.to(dev), cout, k, dilation=dil, lens=lens.to(dev), res=ro if res else None,
+               res_slope=0.1, sum_in=y if mode != 0 else None, mode=mode, div=3.0, out_slope=0.1, y=y)
+    got = bfo.unpack(y, 1.0).cpu()
+    a_all, r_all, s_all = (bfo.unpack(t, 1.0).cpu().double() for t in (xo, ro, so))
+    for i in range(B):
+        n = int(lens[i])
+        v = F.conv1d(a_all[i:i + 1, :, :n], bf(w), b.double(), dilation=dil, padding=(k - 1) * dil // 2)[0]
+        if res:
+            rr = r_all[i, :, :n]
+            v = v + torch.where(rr >= 0, rr, rr / 0.1)
+        if mode != 0:
+            v = v + s_all[i, :, :n]
+        if mode == 2:
+            v = v / 3.0
+        close(got[i, :, :n], lrelu(v, 0.1), f'utt {i}')
+
+
+@pytest.mark.parametrize('cin,cout,u,L', [(512, 256, 8, 150), (256, 128, 8, 300), (128, 64, 2, 700), (64, 32, 2, 1100)])
+def test_conv_transpose1d(dev, cin, cout, u, L):
+    """The four HiFi-GAN upsamplers (models.py:96-99): ConvTranspose1d(kernel 2u, stride u, padding u/2)."""
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(cin + u)
+    B = 2
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cin, cout, 2 * u, generator=g) / np.sqrt(cin * 2)
+    b = torch.randn(cout, generator=g) * 0.3
+    lens = torch.tensor([L, max(1, L - 41)], dtype=torch.int64)
+    xo = bfo.pack(x.to(dev), 0.1)
+    y = torch.full((B, cout // 8, L * u, 8), 0x4242, dtype=torch.int16, device=dev)
+    bfo.conv1d(xo, bfo.pack_weight(w, up=u, device=dev), b.to(dev), cout, 2 * u, up=u, lens=lens.to(dev), out_slope=0.1, y=y)
+    got = bfo.unpack(y, 1.0).cpu()
+    a_all = bfo.unpack(xo, 1.0).cpu().double()
+    for i in range(B):
+        n = int(lens[i])
+        v = F.conv_transpose1d(a_all[i:i + 1, :, :n], bf(w), b.double(), stride=u, padding=u // 2)[0]
+        close(got[i, :, :n * u], lrelu(v, 0.1), f'utt {i}')
+        assert bool((got[i, :, n * u:] == got[i, 0, -1]).all()) if n < L else True
+
+
+def test_conv_post(dev):
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(5)
+    B, C, L = 2, 32, 1500
+    x = torch.randn(B, C, L, generator=g)
+    w = torch.randn(1, C, 7, generator=g) / np.sqrt(C * 7)
+    b = torch.randn(1, generator=g) * 0.1
+    lens = torch.tensor([L, L - 300], dtype=torch.int64)
+    xo = bfo.pack(x.to(dev), 0.01)
+    wave = bfo.conv_post(xo, w.reshape(C, 7).contiguous().to(dev), b.to(dev), lens=lens.to(dev)).cpu()
+    a_all = bfo.unpack(xo, 1.0).cpu().double()
+    for i in range(B):
+        n = int(lens[i])
+        ref = torch.tanh(F.conv1d(a_all[i:i + 1, :, :n], w.double(), b.double(), padding=3))[0, 0]
+        assert float((wave[i, :n].double() - ref).abs().max()) < 1e-5
+        assert float(wave[i, n:].abs().max()) == 0.0 if n < L else True
+
+
+@pytest.mark.parametrize('T', [1, 7, 40])
+def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T):
+    """The whole generator on the octet engine vs the real reference's fp32 golden (stated bf16 tolerance), and
+    that the round-2 bf16 engine (TTSAMD_BFO=0) and the octet engine agree to the same tolerance."""
+    import os
+    from ttsamd.engine import HifiGanEngine, set_precision
+    gd = golden(f'hifigan_T{T}')
+    mel = torch.from_numpy(gd['mel']).to(dev)
+    set_precision('bf16')
+    try:
+        hg = HifiGanEngine(synth_weights['hifigan'], device=dev)
+        wave = hg.forward(mel[None] if mel.dim() == 2 else mel).cpu().reshape(-1)
+        os.environ['TTSAMD_BFO'] = '0'
+        wave_old = hg.forward(mel[None] if mel.dim() == 2 else mel).cpu().reshape(-1)
+    finally:
+        os.environ.pop('TTSAMD_BFO', None)
+        set_precision('f32')
+    ref = torch.from_numpy(gd['wave']).reshape(-1)
+    err, err_old = float((wave - ref).abs().max()), float((wave_old - ref).abs().max())
+    print(f'T={T}: octet engine wave max-abs {err:.2e}, round-2 bf16 engine {err_old:.2e}')
+    assert err < 4e-2 and err_old < 4e-2

@@ -1,0 +1,461 @@
+// bf16 octet engine (bfo.hpp): the layers around the fused ResBlock pairs --
+//   bfo_conv1d   Conv1d with a C-in slab loop (conv_pre 80 -> 512 k7; the C = 256 ResBlock convs of HiFi-GAN stage 1)
+//   bfo_convt    ConvTranspose1d(stride u, kernel 2u, padding u/2) as u polyphase 2-tap convs over ONE staged window,
+//                phases interleaved through LDS so that the stores are whole 16-byte entries in position order
+//   bfo_pack / bfo_unpack   fp32 channel-first <-> bf16 octet layout
+//   bfo_conv_post           leaky_relu(0.01) -> Conv1d(C -> 1, k7) -> tanh on an octet tensor
+// and the host-side weight packers.  Reference ops: vocoder/hifigan/models.py:46-53 (ResBlock1), :96-99,114-115
+// (upsamplers), :112 (conv_pre), :123-125 (conv_post).
+#include <cstring>
+#include <vector>
+
+#include "bfo.hpp"
+
+namespace ttsamd {
+
+// =====================================================================================================================
+// Conv1d: block = 4 waves, wave = 32 rows x 256 columns (8 accumulators), WM row slabs x WN column slabs; the input goes
+// through LDS in slabs of SH 16-channel groups (<= 78 KB: two blocks per CU), weights stream from L2 (bfo_mma).
+// =====================================================================================================================
+template <int K, int WM, int WN>
+struct BfoConvGeo {
+    static constexpr int NT = 8;
+    static constexpr int NCOLS = WN * NT * 32;
+    static constexpr int SH = 8 / WN;                        // 16-channel groups per slab
+    static constexpr int WS = NCOLS + (K - 1) * BFO_DMAX;
+    static constexpr int NE = 2 * SH * WS;
+    static constexpr int NXI = (NE + 255) / 256;
+    static constexpr int PH = K <= 3 ? 2 : 1;
+    static constexpr size_t LDS = (size_t)NE * 16;
+};
+
+template <int K, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
+    using G = BfoConvGeo<K, WM, WN>;
+    constexpr int NT = G::NT, WS = G::WS, NXI = G::NXI, SH = G::SH;
+    extern __shared__ __attribute__((aligned(16))) uint4 Xs[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 5, l31 = lane & 31;
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * G::NCOLS;
+    const int co0 = blockIdx.y * (32 * WM) + 32 * wm;       // this wave's first output row
+    const int L = p.Lin;
+    int len = L;
+    if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
+    if (q0 >= len) return;
+    const int dil = p.dil;
+    const int W1 = G::NCOLS + (K - 1) * dil;
+    const int x0 = q0 - (K - 1) * dil / 2;
+    const int NOI = p.Cin / 8, NHT = (p.Cin + 15) / 16, NOO = p.Cout / 8;
+    const int CoutP = (p.Cout + 31) & ~31;
+    const bfo_i4 xrs = bfo_rsrc((const char*)p.x + (int64_t)b * NOI * L * 16, (unsigned)NOI * L * 16);
+    const bfo_i4 wrs = bfo_rsrc(p.w, (unsigned)NHT * K * 2 * CoutP * 16);
+    const int wv = (kk * CoutP + co0 + l31) * 16;
+    const int cw = wn * (NT * 32) + l31;
+    const uint4* sB = Xs + kk * WS + cw;
+
+    bfo_f16 acc[NT];
+    {
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = p.bias ? p.bias[min(co0 + 8 * (r >> 2) + 4 * kk + (r & 3), p.Cout - 1)] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = bv[r];
+    }
+    for (int s0 = 0; s0 < NHT; s0 += SH) {
+        const int nh = min(SH, NHT - s0);
+        if (s0 > 0) __syncthreads();                        // the previous slab has been consumed
+        // staged 8 entries per thread at a time: the accumulators are live here, a whole slab in flight would spill
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));                     // opaque: the per-entry index math must not be hoisted out of the
+                                                            // slab loop (50 VGPRs held across the MFMAs otherwise)
+#pragma unroll
+        for (int i0 = 0; i0 < NXI; i0 += 8) {
+            bfo_i4 xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid_o + 256 * (i0 + i);
+                const int ol = e / WS, col = e - ol * WS;
+                const int o = 2 * s0 + ol, pos = x0 + col;
+                const bool ok = i0 + i < NXI && ol < 2 * nh && o < NOI && col < W1 && pos >= 0 && pos < len;
+                xv[i] = bfo_ld16(xrs, ok ? (o * L + pos) * 16 : BFO_OOB, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid_o + 256 * (i0 + i);
+                if (i0 + i < NXI && e < G::NE) Xs[e] = __builtin_bit_cast(uint4, xv[i]);
+            }
+        }
+        __syncthreads();
+        bfo_mma<K, G::PH, NT>(acc, wrs, wv, 2 * CoutP * 16, sB, nh, 2 * WS, dil, s0);
+    }
+
+    // ---- epilogue: [+ residual] [+ running sum] [/ div], activation of the consumer, 8-byte stores from the C layout
+    if (co0 >= p.Cout) return;
+    int vo[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int q = q0 + cw + 32 * j;
+        vo[j] = q < len ? q * 16 + 8 * kk : BFO_OOB;
+    }
+    const bfo_i4 yrs = bfo_rsrc((char*)p.y + (int64_t)b * NOO * L * 16, (unsigned)NOO * L * 16);
+    const int so0 = (co0 >> 3) * L * 16;
+    const float os = p.out_slope;
+    const float sc = p.mode == 2 ? 1.f / p.div : 1.f;
+    const bool has_res = p.res != nullptr, has_sum = p.mode != 0;
+    const bfo_i4 rrs = bfo_rsrc((const char*)(has_res ? p.res : p.y) + (int64_t)b * NOO * L * 16, (unsigned)NOO * L * 16);
+    const bfo_i4 srs = bfo_rsrc((const char*)(has_sum ? p.sum_in : p.y) + (int64_t)b * NOO * L * 16, (unsigned)NOO * L * 16);
+    const float rinv = has_res ? 1.f / p.res_slope : 1.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        bfo_i2 rv[4], sv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // branch-free: a masked-off buffer load returns 0 without touching memory
+            rv[g] = bfo_ld8(rrs, has_res ? vo[j] : BFO_OOB, so0 + g * L * 16, 0);
+            sv[g] = bfo_ld8(srs, has_sum ? vo[j] : BFO_OOB, so0 + g * L * 16, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+            const float r[4] = {bfo_lo(rv[g].x), bfo_hi(rv[g].x), bfo_lo(rv[g].y), bfo_hi(rv[g].y)};
+            const float s[4] = {bfo_lo(sv[g].x), bfo_hi(sv[g].x), bfo_lo(sv[g].y), bfo_hi(sv[g].y)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bfo_lrelu((v[e] + bfo_lrelu(r[e], rinv) + s[e]) * sc, os);
+            bfo_i2 w;
+            w.x = bfo_pk(v[0], v[1]);
+            w.y = bfo_pk(v[2], v[3]);
+            bfo_st8(w, yrs, vo[j], so0 + g * L * 16, 0);
+        }
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);       // two tiles' loads in flight, not all eight (128 registers)
+    }
+}
+
+template <int K, int WM, int WN>
+static int32_t bfo_launch_conv_cfg(const BfoConvParams& p, hipStream_t stream) {
+    using G = BfoConvGeo<K, WM, WN>;
+    static bool attr_set[16] = {};
+    int dev_id = 0;
+    TTS_CHECK_HIP(hipGetDevice(&dev_id));
+    dev_id &= 15;
+    if (!attr_set[dev_id]) {
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_conv1d<K, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+        attr_set[dev_id] = true;
+    }
+    const int CoutP = (p.Cout + 31) & ~31;
+    dim3 grid((p.Lin + G::NCOLS - 1) / G::NCOLS, (CoutP + 32 * WM - 1) / (32 * WM), p.batch);
+    hipLaunchKernelGGL((bfo_conv1d<K, WM, WN>), grid, dim3(256), G::LDS, stream, p);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int K>
+static int32_t bfo_launch_conv_k(const BfoConvParams& p, hipStream_t stream) {
+    if (p.Cout >= 128) return bfo_launch_conv_cfg<K, 4, 1>(p, stream);
+    if (p.Cout >= 64) return bfo_launch_conv_cfg<K, 2, 2>(p, stream);
+    return bfo_launch_conv_cfg<K, 1, 4>(p, stream);
+}
+
+int32_t bfo_launch_conv(const BfoConvParams& p, hipStream_t stream) {
+    TTS_REQUIRE(p.up == 1, "bfo conv: use bfo_launch_convt for transposed convs");
+    TTS_REQUIRE(p.Cin % 8 == 0 && p.Cout % 32 == 0, "bfo conv: Cin %% 8 and Cout %% 32 must be 0 (Cin=%d, Cout=%d)", p.Cin, p.Cout);
+    TTS_REQUIRE(p.dil >= 1 && p.dil <= BFO_DMAX, "bfo conv: dilation %d outside [1,%d]", p.dil, BFO_DMAX);
+    TTS_REQUIRE((int64_t)std::max(p.Cin, p.Cout) * p.Lin * 2 < ((int64_t)1 << 31), "bfo conv: tensor too large for 32-bit offsets");
+    TTS_REQUIRE(p.mode == 0 || p.sum_in != nullptr, "bfo conv: mode %d needs sum_in", p.mode);
+    if (p.Lin <= 0) return 0;
+    conv_log("bfo", p.K, p.Cin, p.Cout, p.Lin, p.batch, p.res != nullptr, p.mode, p.len_mul, p.lens != nullptr, 1);
+    switch (p.K) {
+        case 1: return bfo_launch_conv_k<1>(p, stream);
+        case 3: return bfo_launch_conv_k<3>(p, stream);
+        case 7: return bfo_launch_conv_k<7>(p, stream);
+        case 11: return bfo_launch_conv_k<11>(p, stream);
+        default:
+            set_error("bfo conv: kernel size %d not instantiated (1,3,7,11)", p.K);
+            return TTSAMD_EINVAL;
+    }
+}
+
+// =====================================================================================================================
+// ConvTranspose1d(stride U, kernel 2U, padding U/2):  y[co][q U + rho] = b[co] + sum_ci W[ci][co][ka] x[ci][q + dl]
+//                                                                               + W[ci][co][ka + U] x[ci][q + dl - 1],
+// ka = (rho + U/2) % U, dl = (rho + U/2) / U  -> per phase rho a 2-tap conv (dil -1) over the same window.
+// Block = (32 RT output rows, NQ = 32 NQT input positions, ALL U phases); the 4 waves split the (phase, row tile, column
+// group) combos, NT column tiles each.  The results leave through LDS: entry (octet, q, rho) in rows of U + 1 entries
+// (the pad entry spreads the 8-byte C-layout writes over the banks), read back in position order -> 16-byte stores,
+// 1 KB contiguous per wave instruction (phase-strided 8-byte stores would write 8 bytes per 128-byte line at U = 8).
+// =====================================================================================================================
+template <int U, int RT, int NQT, int NT>
+__global__ __launch_bounds__(256, 2) void bfo_convt(const BfoConvParams p) {
+    constexpr int NQ = 32 * NQT, CG = NQT / NT, NC = U * RT * CG, NCALL = NC / 4, WSC = NQ + 2;
+    static_assert(NC % 4 == 0 && NQT % NT == 0, "combos must split over 4 waves");
+    extern __shared__ __attribute__((aligned(16))) uint4 Xs[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * NQ;
+    const int co0 = blockIdx.y * (32 * RT);
+    const int L = p.Lin, Lo = L * U;
+    int len = L;
+    if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
+    if (q0 >= len) return;
+    const int NOI = p.Cin / 8, NH = p.Cin / 16, NOO = p.Cout / 8;
+    const int CoutP = (p.Cout + 31) & ~31;
+    const bfo_i4 xrs = bfo_rsrc((const char*)p.x + (int64_t)b * NOI * L * 16, (unsigned)NOI * L * 16);
+
+    // ---- stage the window: column c = input position q0 - 1 + c
+    {
+        const int ne = NOI * WSC;
+        for (int e0 = 0; e0 < ne; e0 += 256 * 8) {
+            bfo_i4 xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + tid + 256 * i;
+                const int o = e / WSC, col = e - o * WSC;
+                const int pos = q0 - 1 + col;
+                const bool ok = e < ne && pos >= 0 && pos < len;
+                xv[i] = bfo_ld16(xrs, ok ? (o * L + pos) * 16 : BFO_OOB, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + tid + 256 * i;
+                if (e < ne) Xs[e] = __builtin_bit_cast(uint4, xv[i]);
+            }
+        }
+    }
+    __syncthreads();
+
+    bfo_f16 acc[NCALL][NT];
+#pragma unroll
+    for (int c = 0; c < NCALL; ++c) {
+        const int cb = wid + 4 * c;
+        const int rho = cb % U, rt = (cb / U) % RT, cg = cb / (U * RT);
+        const int dl = (rho + U / 2) / U;
+        const int row0 = co0 + 32 * rt;
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = p.bias ? p.bias[min(row0 + 8 * (r >> 2) + 4 * kk + (r & 3), p.Cout - 1)] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = bv[r];
+        const bfo_i4 wrs = bfo_rsrc((const char*)p.w + (int64_t)rho * NH * 2 * 2 * CoutP * 16, (unsigned)NH * 2 * 2 * CoutP * 16);
+        const int wv = (kk * CoutP + row0 + l31) * 16;
+        const uint4* sB = Xs + kk * WSC + cg * (NT * 32) + l31 + dl + 1;      // tap 0 reads x[q + dl], tap 1 x[q + dl - 1]
+        bfo_mma<2, 2, NT>(acc[c], wrs, wv, 2 * CoutP * 16, sB, NH, 2 * WSC, -1);
+    }
+    __syncthreads();                                         // the window is dead
+
+    // ---- results -> LDS [octet (4 RT)][q (NQ)][U + 1 entries], activated, bf16
+    {
+        const float os = p.out_slope;
+#pragma unroll
+        for (int c = 0; c < NCALL; ++c) {
+            const int cb = wid + 4 * c;
+            const int rho = cb % U, rt = (cb / U) % RT, cg = cb / (U * RT);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = cg * (NT * 32) + 32 * j + l31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int2 w;
+                    w.x = bfo_pk(bfo_lrelu(acc[c][j][4 * g], os), bfo_lrelu(acc[c][j][4 * g + 1], os));
+                    w.y = bfo_pk(bfo_lrelu(acc[c][j][4 * g + 2], os), bfo_lrelu(acc[c][j][4 * g + 3], os));
+                    *reinterpret_cast<int2*>(reinterpret_cast<char*>(Xs + ((4 * rt + g) * NQ + n) * (U + 1) + rho) + 8 * kk) = w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- position-ordered 16-byte stores
+    {
+        const bfo_i4 yrs = bfo_rsrc((char*)p.y + (int64_t)b * NOO * Lo * 16, (unsigned)NOO * Lo * 16);
+        constexpr int NOUT = 4 * RT * NQ * U;
+#pragma unroll 4
+        for (int i = 0; i < NOUT / 256; ++i) {
+            const int idx = tid + 256 * i;
+            const int og = idx / (NQ * U), r = idx - og * (NQ * U);
+            const int n = r / U, rho = r - n * U;
+            const uint4 v = Xs[(og * NQ + n) * (U + 1) + rho];
+            const int o = (co0 >> 3) + og;
+            const bool ok = q0 + n < len && o < NOO;
+            bfo_st16(__builtin_bit_cast(bfo_i4, v), yrs, ok ? (o * Lo + q0 * U + r) * 16 : BFO_OOB, 0, 0);
+        }
+    }
+}
+
+template <int U, int RT, int NQT, int NT>
+static int32_t bfo_launch_convt_cfg(const BfoConvParams& p, hipStream_t stream) {
+    constexpr int NQ = 32 * NQT;
+    const size_t lds = std::max((size_t)(p.Cin / 8) * (NQ + 2) * 16, (size_t)4 * RT * NQ * (U + 1) * 16);
+    TTS_REQUIRE(lds <= 80 * 1024, "bfo convt: window of %zu bytes does not fit (Cin=%d, u=%d)", lds, p.Cin, U);
+    static size_t attr_lds[16] = {};
+    int dev_id = 0;
+    TTS_CHECK_HIP(hipGetDevice(&dev_id));
+    dev_id &= 15;
+    if (attr_lds[dev_id] < lds) {
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_convt<U, RT, NQT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_lds[dev_id] = 80 * 1024;
+    }
+    dim3 grid((p.Lin + NQ - 1) / NQ, (p.Cout + 32 * RT - 1) / (32 * RT), p.batch);
+    hipLaunchKernelGGL((bfo_convt<U, RT, NQT, NT>), grid, dim3(256), lds, stream, p);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int32_t bfo_launch_convt(const BfoConvParams& p, hipStream_t stream) {
+    TTS_REQUIRE(p.up == 8 || p.up == 2, "bfo convt: stride %d not built (8, 2)", p.up);
+    TTS_REQUIRE(p.Cin % 16 == 0 && p.Cout % 32 == 0, "bfo convt: Cin %% 16 and Cout %% 32 must be 0 (Cin=%d, Cout=%d)", p.Cin, p.Cout);
+    TTS_REQUIRE((int64_t)std::max(p.Cin, p.Cout * p.up) * p.Lin * 2 < ((int64_t)1 << 31), "bfo convt: tensor too large for 32-bit offsets");
+    if (p.Lin <= 0) return 0;
+    conv_log("bfo_convt", 2, p.Cin, p.Cout, p.Lin, p.batch, 0, 0, p.len_mul, p.lens != nullptr, p.up);
+    if (p.up == 8) {
+        if (p.Cin > 256) return bfo_launch_convt_cfg<8, 1, 2, 2>(p, stream);      // ups0: 512 -> 256, 64 positions per block
+        return bfo_launch_convt_cfg<8, 1, 4, 4>(p, stream);                        // ups1: 256 -> 128, 128 positions
+    }
+    if (p.Cout % 64 == 0) return bfo_launch_convt_cfg<2, 2, 4, 4>(p, stream);      // ups2: 128 -> 64
+    return bfo_launch_convt_cfg<2, 1, 8, 4>(p, stream);                            // ups3: 64 -> 32
+}
+
+// =====================================================================================================================
+// layout converters and the HiFi-GAN tail
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void bfo_pack_kernel(const float* __restrict__ x, int C, int L, float slope, uint4* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    if (t >= L) return;
+    const float* xr = x + ((int64_t)b * C + 8 * o) * L + t;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (8 * o + e < C) ? bfo_lrelu(xr[(int64_t)e * L], slope) : 0.f;
+    uint4 w;
+    w.x = (unsigned)bfo_pk(v[0], v[1]); w.y = (unsigned)bfo_pk(v[2], v[3]);
+    w.z = (unsigned)bfo_pk(v[4], v[5]); w.w = (unsigned)bfo_pk(v[6], v[7]);
+    out[((int64_t)b * gridDim.y + o) * L + t] = w;
+}
+
+__global__ __launch_bounds__(256) void bfo_unpack_kernel(const uint4* __restrict__ in, int C, int L, float inv_slope, float* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    if (t >= L) return;
+    const uint4 w = in[((int64_t)b * gridDim.y + o) * L + t];
+    const float v[8] = {bfo_lo((int)w.x), bfo_hi((int)w.x), bfo_lo((int)w.y), bfo_hi((int)w.y),
+                        bfo_lo((int)w.z), bfo_hi((int)w.z), bfo_lo((int)w.w), bfo_hi((int)w.w)};
+    float* yr = out + ((int64_t)b * C + 8 * o) * L + t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (8 * o + e < C) yr[(int64_t)e * L] = bfo_lrelu(v[e], inv_slope);
+}
+
+int32_t bfo_launch_pack(const float* x, int32_t B, int32_t C, int32_t L, float slope, void* out, hipStream_t s) {
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    dim3 grid((L + 255) / 256, (C + 7) / 8, B);
+    hipLaunchKernelGGL(bfo_pack_kernel, grid, dim3(256), 0, s, x, C, L, slope, (uint4*)out);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int32_t bfo_launch_unpack(const void* in, int32_t B, int32_t C, int32_t L, float slope, float* out, hipStream_t s) {
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    dim3 grid((L + 255) / 256, (C + 7) / 8, B);
+    hipLaunchKernelGGL(bfo_unpack_kernel, grid, dim3(256), 0, s, (const uint4*)in, C, L, 1.f / slope, out);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// wave[b][t] = tanh(b0 + sum_{c,k} w[c][k] a[b][c][t + k - 3]); a = the stage sum, stored activated with slope 0.01.
+// HBM-bound (64 B read, 4 B written per sample): 256 samples per block, the (256 + 6) x C/8 entries go through LDS once.
+template <int NO>
+__global__ __launch_bounds__(256) void bfo_conv_post_kernel(const uint4* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const int64_t* __restrict__ lens,
+                                                            int len_mul, int L, float* __restrict__ wave, int64_t wave_bs) {
+    __shared__ uint4 Xs[NO * 262];
+    const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+    int n = L;
+    if (lens) n = min(n, (int)lens[b] * len_mul);
+    if (t0 >= n) return;
+    for (int e = tid; e < NO * 262; e += 256) {
+        const int o = e / 262, col = e - o * 262;
+        const int pos = t0 - 3 + col;
+        Xs[e] = (pos >= 0 && pos < n) ? x[((int64_t)b * NO + o) * L + pos] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const uint4 v = Xs[o * 262 + tid + k];
+            const float a[8] = {bfo_lo((int)v.x), bfo_hi((int)v.x), bfo_lo((int)v.y), bfo_hi((int)v.y),
+                                bfo_lo((int)v.z), bfo_hi((int)v.z), bfo_lo((int)v.w), bfo_hi((int)v.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(w[(8 * o + e) * 7 + k], a[e], acc);
+        }
+    if (t < n) wave[(int64_t)b * wave_bs + t] = tanhf(acc);
+}
+
+int32_t bfo_launch_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul, int32_t B,
+                             int32_t C, int32_t L, float* wave, int64_t wave_bs, hipStream_t s) {
+    TTS_REQUIRE(C == 32, "bfo conv_post: built for 32 input channels (got %d)", C);
+    if (B <= 0 || L <= 0) return 0;
+    dim3 grid((L + 255) / 256, B);
+    hipLaunchKernelGGL(bfo_conv_post_kernel<4>, grid, dim3(256), 0, s, (const uint4*)x, w, bias, lens, len_mul, L, wave, wave_bs);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// =====================================================================================================================
+// host-side weight packers
+// =====================================================================================================================
+static inline uint16_t bfo_host_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+int64_t bfo_packed_conv_elems(int cout, int cin, int k) {
+    return (int64_t)((cin + 15) / 16) * k * 2 * ((cout + 31) & ~31) * 8;
+}
+
+// out[(((h K + t) 2 + kk) CoutP + co) 8 + e] = w[co][16 h + 8 kk + e][t]
+void bfo_pack_conv_weight(const float* w, int cout, int cin, int k, uint16_t* out) {
+    const int cp = (cout + 31) & ~31, nh = (cin + 15) / 16;
+    for (int h = 0; h < nh; ++h)
+        for (int t = 0; t < k; ++t)
+            for (int kk = 0; kk < 2; ++kk) {
+                uint16_t* dst = out + (((int64_t)h * k + t) * 2 + kk) * cp * 8;
+                for (int co = 0; co < cp; ++co)
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 16 * h + 8 * kk + e;
+                        dst[co * 8 + e] = (co < cout && ci < cin) ? bfo_host_bf16(w[((int64_t)co * cin + ci) * k + t]) : 0;
+                    }
+            }
+}
+
+int64_t bfo_packed_convt_elems(int cin, int cout, int u) {
+    return (int64_t)u * (cin / 16) * 2 * 2 * ((cout + 31) & ~31) * 8;
+}
+
+// torch ConvTranspose1d weight [Cin][Cout][2u]: phase rho, tap t2 -> kernel index (rho + u/2) % u + t2 u
+void bfo_pack_convt_weight(const float* w, int cin, int cout, int u, uint16_t* out) {
+    const int cp = (cout + 31) & ~31, nh = cin / 16, kt = 2 * u, pd = u / 2;
+    for (int rho = 0; rho < u; ++rho) {
+        const int ka = (rho + pd) % u;
+        for (int h = 0; h < nh; ++h)
+            for (int t2 = 0; t2 < 2; ++t2)
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint16_t* dst = out + ((((int64_t)rho * nh + h) * 2 + t2) * 2 + kk) * cp * 8;
+                    for (int co = 0; co < cp; ++co)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = 16 * h + 8 * kk + e;
+                            dst[co * 8 + e] = co < cout ? bfo_host_bf16(w[((int64_t)ci * cout + co) * kt + ka + t2 * u]) : 0;
+                        }
+                }
+    }
+}
+
+}  // namespace ttsamd

@@ -11,12 +11,14 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "bfo.hpp"
 
 namespace ttsamd {
 
 struct ConvW {
     int64_t w_off = 0, b_off = 0;  // float offsets into the device weight blob
     int64_t w16_off = 0, w_n = 0;  // bf16 planes (hi, lo) in the uint16 blob; packed element count
+    int64_t wo_off = -1;           // bf16 octet engine (bfo.hpp): [Cin/16][K][2][CoutP][8] in the same uint16 blob (-1: not packed)
     int cin = 0, cout = 0, k = 0;
 };
 
@@ -30,6 +32,7 @@ struct HifiGan {
     std::vector<ConvW> c1, c2;  // [stage*n_kernels + j][m]
     int hop = 1;
     int64_t max_cl = 0;  // max over stages of C * (L / T)
+    bool bfo_ok = false; // every layer fits the bf16 octet engine (config 3 path, hifigan_forward_bfo)
     // small batches: the three ResBlocks of a stage run on three streams (guarded by mu, created on first use)
     mutable std::mutex mu;
     mutable hipStream_t side[2] = {nullptr, nullptr};
@@ -130,6 +133,12 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
     blob.resize(blob.size() + (size_t)cin * k * cout_padded(cout));
     pack_conv_weight(w.data(), cout, cin, k, blob.data() + cw.w_off);
     add_bf16(blob, blob16, cw, (int64_t)cin * k * cout_padded(cout));
+    if (cin % 8 == 0 && cout % 32 == 0) {
+        blob16.resize(align_up((int64_t)blob16.size(), 64));
+        cw.wo_off = (int64_t)blob16.size();
+        blob16.resize(blob16.size() + (size_t)bfo_packed_conv_elems(cout, cin, k));
+        bfo_pack_conv_weight(w.data(), cout, cin, k, blob16.data() + cw.wo_off);
+    }
     blob.resize(align_up((int64_t)blob.size(), 64));
     return get_bias(tm, base, cout, blob, cw.b_off);
 }
@@ -172,6 +181,12 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
         blob.resize(blob.size() + (size_t)u * cin * 2 * cout_padded(cout));
         pack_convt_weight(w.data(), cin, cout, kt, u, (kt - u) / 2, blob.data() + cw.w_off);
         add_bf16(blob, blob16, cw, (int64_t)u * cin * 2 * cout_padded(cout));
+        if (cin % 16 == 0 && cout % 32 == 0 && (u == 8 || u == 2)) {
+            blob16.resize(align_up((int64_t)blob16.size(), 64));
+            cw.wo_off = (int64_t)blob16.size();
+            blob16.resize(blob16.size() + (size_t)bfo_packed_convt_elems(cin, cout, u));
+            bfo_pack_convt_weight(w.data(), cin, cout, u, blob16.data() + cw.wo_off);
+        }
         blob.resize(align_up((int64_t)blob.size(), 64));
         rc = get_bias(tm, "ups." + std::to_string(i), cout, blob, cw.b_off);
         if (rc) break;
@@ -192,6 +207,18 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
         }
     }
     h->hop = mul;
+    if (rc == 0) {
+        // the bf16 octet engine covers this generator if every layer was packed for it
+        bool ok = h->conv_pre.wo_off >= 0 && ch == 32 && cfg->num_mels % 8 == 0;
+        for (const ConvW& cw : h->ups) ok = ok && cw.wo_off >= 0;
+        for (size_t i = 0; i < h->c1.size(); ++i) ok = ok && h->c1[i].wo_off >= 0 && h->c2[i].wo_off >= 0;
+        for (int j = 0; j < cfg->n_kernels; ++j) {
+            const int kk = cfg->resblock_kernel_sizes[j];
+            ok = ok && (kk == 3 || kk == 7 || kk == 11);
+            for (int m = 0; m < cfg->n_dilations; ++m) ok = ok && cfg->resblock_dilations[j][m] >= 1 && cfg->resblock_dilations[j][m] <= BFO_DMAX;
+        }
+        h->bfo_ok = ok;
+    }
     if (rc == 0) {
         // conv_post: [1][C][7] -> plain [C][7]
         std::vector<float> w;
@@ -247,6 +274,7 @@ int64_t hifigan_workspace_bytes(const HifiGan* h, int32_t B, int32_t T) {
     const int nb = use_branch_streams(h, B, T) ? 3 : 1;
     for (int i = 0; i < 2 + 2 * nb; ++i) a.take<float>((int64_t)B * h->max_cl * T);
     for (int i = 0; i < nb; ++i) a.take<float>(kSplitKFloats);
+    a.take<uint16_t>((int64_t)B * align_up(h->cfg.num_mels, 8) * T);   // bf16 octet engine: the mel in its layout
     return a.off;
 }
 
@@ -265,6 +293,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     }
     for (int i = 0; i < nb; ++i) splitks[i] = a.take<float>(kSplitKFloats);
     for (int i = nb; i < 3; ++i) { Tbs[i] = Tbs[0]; Rs[i] = Rs[0]; splitks[i] = splitks[0]; }
+    uint16_t* mel_o = a.take<uint16_t>((int64_t)B * align_up(h->cfg.num_mels, 8) * T);
     if (!ws || !a.ok) {
         set_error("hifigan_forward: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
         return TTSAMD_ENOMEM;
@@ -329,6 +358,104 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
 
 #define HG_TRY(expr) do { int32_t rc_ = (expr); if (rc_ != 0) return fail(rc_); } while (0)
 #define HG_CHECK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return fail(TTSAMD_EHIP); } } while (0)
+    // ---- config 3: plain bf16 runs on the octet engine (bfo.hpp): v_mfma_f32_32x32x16_bf16, bf16 activations in HBM stored
+    // pre-activated for their consumer, fused c1 -> c2 pairs for C <= 128.  TTSAMD_BFO=0 keeps the round-2 bf16 engine.
+    const char* bfo_env = std::getenv("TTSAMD_BFO");
+    if (default_precision() == 1 && h->bfo_ok && !(bfo_env && bfo_env[0] == '0')) {
+        const uint16_t* W16 = h->dev16;
+        void *curo = cur, *upso = ups_out;                 // the fp32-sized buffers hold bf16 tensors of the same element count
+        HG_TRY(bfo_launch_pack(mel, B, cfg.num_mels, T, 1.f, mel_o, s));
+        BfoConvParams cp;
+        std::memset(&cp, 0, sizeof(cp));
+        cp.batch = B; cp.lens = lens; cp.div = 1.f; cp.res_slope = 1.f;
+        // conv_pre (models.py:112); its consumer, the first upsampler, applies leaky_relu(0.1) (models.py:114)
+        cp.x = mel_o; cp.y = curo; cp.w = W16 + h->conv_pre.wo_off; cp.bias = h->dev + h->conv_pre.b_off;
+        cp.len_mul = 1; cp.Lin = T; cp.Cin = h->conv_pre.cin; cp.Cout = h->conv_pre.cout; cp.K = 7; cp.dil = 1; cp.up = 1;
+        cp.mode = 0; cp.out_slope = 0.1f;
+        prof_begin(s, 2.0 * cp.Cout * cp.Cin * 7);
+        int32_t rc = bfo_launch_conv(cp, s);
+        prof_end(s);
+        HG_TRY(rc);
+        int L = T, mul = 1;
+        for (int i = 0; i < cfg.n_ups; ++i) {
+            const int u = cfg.upsample_rates[i];
+            const ConvW& uw = h->ups[i];
+            // ConvTranspose1d on the activated stage input; the ResBlocks read its output through leaky_relu(0.1)
+            cp.x = curo; cp.y = upso; cp.w = W16 + uw.wo_off; cp.bias = h->dev + uw.b_off; cp.res = nullptr; cp.sum_in = nullptr;
+            cp.len_mul = mul; cp.Lin = L; cp.Cin = uw.cin; cp.Cout = uw.cout; cp.K = 2; cp.dil = 1; cp.up = u;
+            cp.mode = 0; cp.out_slope = 0.1f;
+            prof_begin(s, 2.0 * uw.cout * uw.cin * 2 * u * mul);
+            rc = bfo_launch_convt(cp, s);
+            prof_end(s);
+            HG_TRY(rc);
+            L *= u; mul *= u;
+            // what reads the stage sum: the next upsampler through leaky_relu(0.1), conv_post through leaky_relu(0.01)
+            const float next_slope = i + 1 < cfg.n_ups ? 0.1f : 0.01f;
+            if (multi) {
+                prof_section_begin(s);
+                in_section = true;
+                HG_CHECK_HIP(hipEventRecord(h->ev_fork, s));
+            }
+            for (int j = 0; j < cfg.n_kernels; ++j) {
+                hipStream_t st = bs[j % 3];
+                void *Tb = Tbs[j % 3], *R = Rs[j % 3];
+                if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
+                const void* src = upso;
+                for (int m = 0; m < cfg.n_dilations; ++m) {
+                    const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
+                    const int d = cfg.resblock_dilations[j][m];
+                    const bool last = m + 1 == cfg.n_dilations;
+                    const ConvW &w1 = h->c1[li], &w2 = h->c2[li];
+                    void* dst = last ? curo : (src == R ? Tb : R);
+                    // running ResBlock sum in `cur`: raw bf16 until the last branch stores it activated for its consumer
+                    const int mode = !last || cfg.n_kernels == 1 ? 0 : (j == 0 ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2));
+                    const float out_slope = !last ? 0.1f : (j + 1 == cfg.n_kernels ? next_slope : 1.f);
+                    if (multi && last && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
+                    const double fl = 2.0 * (2.0 * w1.cin * w1.cin * w1.k) * mul;
+                    if (bfo_pair_supported(w1.cin, w1.k, d, L)) {
+                        BfoPairParams pp;
+                        std::memset(&pp, 0, sizeof(pp));
+                        pp.x = src; pp.y = dst; pp.sum_in = curo;
+                        pp.w1 = W16 + w1.wo_off; pp.w2 = W16 + w2.wo_off; pp.b1 = h->dev + w1.b_off; pp.b2 = h->dev + w2.b_off;
+                        pp.lens = lens; pp.len_mul = mul; pp.L = L; pp.dil = d; pp.batch = B;
+                        pp.mode = mode; pp.div = (float)cfg.n_kernels; pp.in_slope = 0.1f; pp.mid_slope = 0.1f; pp.out_slope = out_slope;
+                        if (in_section) prof_add(fl); else prof_begin(st, fl);
+                        rc = bfo_launch_pair(w1.cin, w1.k, pp, st);
+                        if (!in_section) prof_end(st);
+                        HG_TRY(rc);
+                    } else {
+                        // C = 256 (stage 1): c1 and c2 as two launches, the intermediate stored activated for c2.  c2 reads its
+                        // residual only at its own output positions, so it may run in place (dst == src == R)
+                        void* t1 = Tb;
+                        if (!last) dst = R;
+                        cp.x = src; cp.y = t1; cp.w = W16 + w1.wo_off; cp.bias = h->dev + w1.b_off; cp.res = nullptr; cp.sum_in = nullptr;
+                        cp.len_mul = mul; cp.Lin = L; cp.Cin = w1.cin; cp.Cout = w1.cout; cp.K = w1.k; cp.dil = d; cp.up = 1;
+                        cp.mode = 0; cp.out_slope = 0.1f; cp.res_slope = 1.f;
+                        if (in_section) prof_add(fl); else prof_begin(st, fl);
+                        rc = bfo_launch_conv(cp, st);
+                        if (rc == 0) {
+                            cp.x = t1; cp.y = dst; cp.w = W16 + w2.wo_off; cp.bias = h->dev + w2.b_off; cp.res = src; cp.sum_in = curo;
+                            cp.dil = 1; cp.mode = mode; cp.div = (float)cfg.n_kernels; cp.out_slope = out_slope; cp.res_slope = 0.1f;
+                            rc = bfo_launch_conv(cp, st);
+                        }
+                        if (!in_section) prof_end(st);
+                        HG_TRY(rc);
+                    }
+                    if (multi && last) HG_CHECK_HIP(hipEventRecord(h->ev_done[j], st));
+                    src = dst;
+                }
+            }
+            if (multi) {
+                HG_CHECK_HIP(hipStreamWaitEvent(s, h->ev_done[cfg.n_kernels - 1], 0));
+                in_section = false;
+                prof_section_end(s);
+            }
+        }
+        HG_TRY(bfo_launch_conv_post(curo, h->dev + h->conv_post.w_off, h->dev + h->conv_post.b_off, lens, mul, B, h->conv_post.cin,
+                                    L, wave, (int64_t)L, s));
+        return 0;
+    }
+
     // conv_pre (models.py:112)
     HG_TRY(conv(h->conv_pre, mel, s, cur, nullptr, T, 1, 1, 1.0f, 0, 1.f));
     int L = T, mul = 1;
