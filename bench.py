@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E, spec
 SAMPLE_RATE = 22050
 
 
@@ -66,7 +67,7 @@ def cpu_baseline(fp_sd, hg_sd, tokens, seconds_budget=25.0):
             el = time.perf_counter() - t0
             if el > seconds_budget * 0.4:
                 break
-    out = {'value': n_samples / el, 'unit': 'audio samples/s', 'cores': torch.get_num_threads(),
+    out = {'value': n_samples / el, 'unit': 'audio samples/s', 'cores': torch.get_num_threads(), 'host_cpus': os.cpu_count(),
            'kind': 'port', 'sample': f'{n_utts} utterances x {tokens} tokens (batch {b}, forced durations), '
                                      f'{el:.1f} s of torch-CPU fp32 on {os.cpu_count()} host cpus',
            'rtf': el / (n_samples / SAMPLE_RATE),
@@ -90,31 +91,77 @@ def _self_launch(args):
     """`python bench.py --gpus N` typed as is (no torch.distributed.run around it): start N ranks as child
     processes BEFORE anything in this process touches the GPU, relay rank 0's JSON line, fail if any child fails.
     With fewer than N GPUs on the box (the 1-GPU dev box) the ranks share device 0 and talk over gloo
-    (TTSAMD_BENCH_ONE_DEVICE=1): a functional check of the N>1 path, labelled as such in the line."""
+    (TTSAMD_BENCH_ONE_DEVICE=1): a functional check of the N>1 path, labelled as such in the line.
+
+    This process never touches the GPU, so it is the WATCHDOG of the ranks: if rank 0 has not printed its line
+    within the budget (TTSAMD_BENCH_WATCHDOG_S, default 300 s + 2 s per step: a cold `import torch` alone can take
+    two minutes on a fresh box), or any rank dies, every child is killed (exact PIDs) and FRESH children are started
+    once more with TTSAMD_DP_TRANSPORT=torch (the exchanges through torch.distributed's own RCCL process group
+    instead of the ttsamd_dp_* communicator); the line then says which transport produced it and why.  A hang of
+    a collective between ranks (the one failure a try/except inside a rank cannot see) therefore costs the budget
+    once, never the caller's whole time-out."""
     import socket
     import subprocess
     n_dev = torch.cuda.device_count()          # counts devices without initialising the HIP runtime
-    env = dict(os.environ)
+    base_env = dict(os.environ)
     if n_dev < args.gpus:
-        env['TTSAMD_BENCH_ONE_DEVICE'] = '1'
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus))
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    procs = []
-    for r in range(args.gpus):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for ln in out0.decode().splitlines():                       # stdout carries the ONE json line; library chatter (gloo) goes to stderr
+        base_env['TTSAMD_BENCH_ONE_DEVICE'] = '1'
+    base_env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    budget = float(os.environ.get('TTSAMD_BENCH_WATCHDOG_S', 300.0 + 2.0 * (args.steps + args.warmup)))
+
+    def attempt(n, extra):
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(base_env, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
+                   TTSAMD_BENCH_ATTEMPT=str(n), **extra)
+        procs = []
+        for r in range(args.gpus):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        deadline, out0, why = time.monotonic() + budget, None, None
+        while True:
+            try:
+                out0, _ = procs[0].communicate(timeout=1.0)
+                break
+            except subprocess.TimeoutExpired:
+                dead = [r for r, p in enumerate(procs[1:], 1) if p.poll() not in (None, 0)]
+                if dead:
+                    why = f'rank(s) {dead} exited with {[procs[r].returncode for r in dead]} while rank 0 was still running'
+                    break
+                if time.monotonic() > deadline:
+                    why = f'no result within the watchdog budget of {budget:.0f} s'
+                    break
+        if why is not None:                                        # stalled or broken: end every child we started
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            return None, why
+        rcs = [procs[0].returncode]
+        for p in procs[1:]:
+            try:
+                rcs.append(p.wait(timeout=60))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                rcs.append(p.wait())
+        if any(rcs):
+            return None, f'rank exit codes {rcs}'
+        return out0.decode(), None
+
+    out, why = attempt(0, {})
+    if out is None:
+        print(f'bench.py watchdog: {why}; restarting all ranks with TTSAMD_DP_TRANSPORT=torch', file=sys.stderr)
+        out, why2 = attempt(1, {'TTSAMD_DP_TRANSPORT': 'torch', 'TTSAMD_BENCH_FALLBACK_REASON': why})
+        why = why2
+    if out is None:
+        print(f'bench.py: {why}', file=sys.stderr)
+        sys.exit(1)
+    for ln in out.splitlines():                                   # stdout carries the ONE json line; library chatter (gloo) goes to stderr
         print(ln, file=sys.stdout if ln.startswith('{') else sys.stderr)
     sys.stdout.flush()
-    if any(rcs):
-        print(f'bench.py: rank exit codes {rcs}', file=sys.stderr)
-        sys.exit(1)
     sys.exit(0)
 
 
@@ -145,6 +192,11 @@ def main():
     ap.add_argument('--pipeline', action='store_true',
                     help='two HIP streams (ttsamd.pipeline): FastPitch of step i+1 under HiFi-GAN of step i; measured +1.3 %% at '
                          'B=32 (the conv engine is busy either way), so the default stays the one-stream schedule')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='N > 1: weak = --batch utterances PER RANK (default); strong = --batch utterances in total, B/N per rank '
+                         '(north star: B=256 on 1/2/4/8 GPUs)')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the extra driver-visible sub-results (config 3 bf16 share, config 4 Tacotron2, config 5 Vocos, D2H)')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16x3'],
                     help='MFMA operand precision of the conv/linear GEMMs (f32 = BASELINE config 2; bf16 = config 3; '
                          'bf16x3 = split bf16, fp32-class accuracy)')
@@ -171,23 +223,33 @@ def main():
 
     set_precision(args.precision)
     dpx, transport = None, None
+    red_dev = dev                                   # where the small host-side reductions (timings, flags) live
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if one_dev:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         from ttsamd import dp
         transport = os.environ.get('TTSAMD_DP_TRANSPORT') or ('torch' if one_dev else 'rccl')
+        if os.environ.get('TTSAMD_BENCH_ATTEMPT', '0') == '0':      # tests/test_gpu_dp.py: fault injection, first attempt only
+            if os.environ.get('TTSAMD_BENCH_TEST_STALL') == f'{rank}':
+                time.sleep(3600)                    # a rank that never arrives
+            if os.environ.get('TTSAMD_BENCH_TEST_DIE') == f'{rank}':
+                os._exit(5)                         # a rank that dies before the rendezvous
+        if one_dev or transport == 'rccl':
+            # rendezvous, barriers and the few host-side reductions over gloo: with the ttsamd_dp_* transport a rank then
+            # holds exactly ONE RCCL communicator (the library's), created right below, not a second one next to torch's
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            red_dev = torch.device('cpu')
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         if transport == 'rccl':
-            # every rank probes the C-ABI RCCL binding (dlopen + id); if any rank cannot, ALL ranks use the same
-            # exchanges through torch.distributed's RCCL instead (same wire, same buffers) and the line says so
+            # every rank probes the C-ABI RCCL binding (dlopen + id) BEFORE the first collective; if any rank cannot,
+            # ALL ranks leave (exit code 3) and the parent's watchdog restarts them on the torch.distributed transport
             import ctypes
-            ok = torch.tensor([1 if L.load().ttsamd_dp_unique_id((ctypes.c_char * 128)()) == 0 else 0], device=dev)
+            ok = torch.tensor([1 if L.load().ttsamd_dp_unique_id((ctypes.c_char * 128)()) == 0 else 0])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
-                print('bench.py: ttsamd_dp_* unavailable on some rank, using torch.distributed transport', file=sys.stderr)
-                transport = 'torch'
+                print(f'bench.py rank {rank}: ttsamd_dp_* unavailable on some rank', file=sys.stderr)
+                dist.destroy_process_group()
+                sys.exit(3)
         dpx = dp.Dp(dev, transport=transport)
         # C1: only rank 0 holds the checkpoint
         fp_sd = synth.fastpitch_state_dict() if rank == 0 else None
@@ -206,13 +268,25 @@ def main():
         fp_sd, hg_sd = synth.fastpitch_state_dict(), synth.hifigan_state_dict()
         fp = FastPitchEngine(fp_sd, device=dev)
         hg = HifiGanEngine(hg_sd, device=dev)
-    B, Lt = args.batch, args.tokens
-    # distinct synthetic utterances per rank (global batch = world * B)
-    ids_all = synth.synth_ids(world * B, Lt)
-    dur_all = synth.synth_durations(world * B, Lt)
-    ids = torch.from_numpy(ids_all[rank * B:(rank + 1) * B]).to(dev)
-    dur = torch.from_numpy(dur_all[rank * B:(rank + 1) * B]).to(dev)
+    Lt = args.tokens
+    # distinct synthetic utterances per rank: weak scaling = --batch per rank (global batch world * B), strong scaling =
+    # --batch in total, contiguous balanced shards (ttsamd.dp.shard_bounds)
+    if args.scaling == 'strong' and world > 1:
+        from ttsamd.dp import shard_bounds
+        g_batch = args.batch
+        lo, hi = shard_bounds(g_batch, world, rank)
+        assert g_batch >= world, '--scaling strong needs at least one utterance per rank'
+    else:
+        g_batch = world * args.batch
+        lo, hi = rank * args.batch, (rank + 1) * args.batch
+    B = hi - lo
+    b_cap = -(-g_batch // world)                    # the largest shard (length exchange slot count)
+    ids_all = synth.synth_ids(g_batch, Lt)
+    dur_all = synth.synth_durations(g_batch, Lt)
+    ids = torch.from_numpy(ids_all[lo:hi]).to(dev)
+    dur = torch.from_numpy(dur_all[lo:hi]).to(dev)
     hop = hg.hop
+    xch_ev = []                                     # (start, end) event pairs around the per-step audio fan-in
 
     # --pipeline: two HIP streams (ttsamd.pipeline), the acoustic model of step i + 1 (150 short launches) under the vocoder of
     # step i.  Same work per step, same results; 79.4 -> 78.4 ms per step at B=32 (only FastPitch's non-conv kernels find idle CUs).
@@ -234,14 +308,18 @@ def main():
         state = {}
 
         def hook(dec_lens):                      # ONE host sync per step: own + every rank's lengths
-            state['all'] = dpx.exchange_lens(dec_lens, ids_.shape[0])
+            state['all'] = dpx.exchange_lens(dec_lens, max(b_cap, ids_.shape[0]))
             return state['all'][rank, 1:1 + ids_.shape[0]]
 
         def vocode(mel, dec_lens):
             wave = hg.forward(mel, dec_lens)
             all_samples = state['all'].copy()
             all_samples[:, 1:] *= hop
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             dpx.gather_flat(wave, dec_lens * hop, all_lens=all_samples)     # C2: audio fan-in to rank 0
+            e1.record()
+            xch_ev.append((e0, e1))
             return wave
 
         def step():
@@ -256,25 +334,20 @@ def main():
     sync = torch.cuda.synchronize
     barrier = dist.barrier if world > 1 else None
     if world > 1 and transport == 'rccl':
-        # first DP step under guard: if the C-ABI RCCL exchange raises on ANY rank, every rank switches to the same
-        # exchanges through torch.distributed (same wire) instead of failing the run; the line reports which one ran
+        # first DP step under guard.  A failure on one rank can leave the others inside an unmatched Send / Recv, which no
+        # in-process fallback can recover: a rank that raises exits with code 3, the parent's watchdog sees it (or, when
+        # the run was started by torch.distributed.run, the launcher does), ends every rank and -- in the self-launched
+        # case -- restarts fresh ranks on the torch.distributed transport
         try:
             step()
             sync()
-            ok = 1
         except Exception as e:                                   # noqa: BLE001
-            print(f'bench.py rank {rank}: ttsamd_dp_* step failed ({e}); falling back to torch.distributed', file=sys.stderr)
-            ok = 0
-        flag = torch.tensor([ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            dpx.close()
-            transport = 'torch'
-            dpx = dp.Dp(dev, transport=transport)
-            step = make_step(ids, dur)
+            print(f'bench.py rank {rank}: ttsamd_dp_* step failed ({e})', file=sys.stderr)
+            os._exit(3)
     for _ in range(args.warmup):
         step()
     sync()
+    xch_ev.clear()
 
     lib = L.load()
     import ctypes
@@ -286,84 +359,137 @@ def main():
 
     frames = int(dec_lens.sum().item())
     samples = frames * hop * args.steps
-    tot = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev if not one_dev else 'cpu')
+    xch_ms = sum(a.elapsed_time(b) for a, b in xch_ev) / max(1, args.steps) if xch_ev else 0.0
+    tot = torch.tensor([elapsed, float(samples), xch_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         mx = tot[:1].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot[1:].clone()
+        sm = tot[1:2].clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, samples = float(mx[0]), float(sm[0])
+        xm = tot[2:].clone()
+        dist.all_reduce(xm, op=dist.ReduceOp.MAX)
+        elapsed, samples, xch_ms = float(mx[0]), float(sm[0]), float(xm[0])
 
     from ttsamd.config import NET_CONFIG as NC, HIFIGAN_CONFIG as HC
     hg_fpf = hifigan_flops_per_frame(HC)
     dec_fpt, enc_fpt = fastpitch_conv_flops_per_pos(NC)
+    hg_bpf = hifigan_octet_bytes_per_frame(HC)
+    dec_bpt, enc_bpt = fastpitch_conv_bytes_per_pos(NC)
     # peak of the MFMA instruction actually issued: fp32 157.3; bf16 2500 dense; split bf16 issues
     # 3 bf16 MFMAs per algorithmic product -> 2500/3 algorithmic TFLOP/s
-    peak = {'f32': PEAK_F32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16x3': 2500.0 / 3}[args.precision]
+    PEAKS = {'f32': PEAK_F32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16x3': 2500.0 / 3}
+    peak = PEAKS[args.precision]
 
-    def small_config(b):
+    def step_flops(b, fr):
+        """algorithmic FLOPs (2*Cout*Cin*K per VALID output position) of one step's MFMA conv launches: HiFi-GAN and the
+        FastPitch decoder on sum(frames) (+ one position per utterance for the ragged tile edges), encoder / predictors on
+        B * L tokens (padded positions past an utterance's end are skipped by the kernels and are not counted)"""
+        return hg_fpf * fr + dec_fpt * (fr + b) + enc_fpt * b * Lt
+
+    def step_bytes_bf16(b, fr):
+        """algorithmic HBM bytes of the same launches in the bf16 mode: HiFi-GAN on the octet engine (bf16 activations, fused
+        pairs = one read + one write per pair), FastPitch on the bf16 MFMA engine with fp32 activations"""
+        return hg_bpf * fr + dec_bpt * (fr + b) + enc_bpt * b * Lt
+
+    def wall_roofline(prec, flops, byts, sec):
+        """roofline entry over the WALL time of a whole call (launch gaps, small kernels and stream overlap included)"""
+        ach = flops / sec / 1e12
+        r = {'bound': 'mfma', 'achieved': ach, 'peak': PEAKS[prec], 'unit': 'TFLOP/s', 'frac': ach / PEAKS[prec],
+             'basis': 'algorithmic conv FLOPs / wall time of the whole call (no per-launch events)'}
+        if prec == 'bf16':
+            gbs = byts / sec / 1e9
+            r = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                 'mfma_achieved_tflops': ach, 'mfma_peak_tflops': PEAKS[prec], 'mfma_frac': ach / PEAKS[prec],
+                 'basis': 'algorithmic HBM bytes (and conv FLOPs) / wall time of the whole call (no per-launch events)'}
+        return r
+
+    def small_config(b, prec=None, name=None):
         """Batch-b sub-result (north star: batch 1 / 8 / 32): same step function, own warm-up, timed WITHOUT the
-        per-launch events (they cost a B=1 call 17 %); its roofline figure is algorithmic FLOPs over the call's
+        per-launch events (they cost a B=1 call 17 %); its roofline figure is algorithmic work over the call's
         WALL time — launch gaps and the three-stream overlap included — so it can never exceed what ran."""
-        ids_b, dur_b = ids[:b].contiguous(), dur[:b].contiguous()
-        st = make_step(ids_b, dur_b)
-        for _ in range(5):
-            st()
-        sync()
-        n = max(args.steps, 20)
-        el, (_, dl) = _time_steps(st, n, sync)
-        fr, tm = int(dl.sum().item()), int(dl.max().item())
-        flops = hg_fpf * fr + dec_fpt * b * tm + enc_fpt * b * Lt
-        ach = flops / (el / n) / 1e12
-        return {'batch': b, 'ms_per_step': el / n * 1e3, 'value': fr * hop * n / el, 'unit': 'audio samples/s',
-                'rtf': el / (fr * hop * n / SAMPLE_RATE), 'frames': fr, 'steps': n,
-                'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                             'basis': 'algorithmic conv FLOPs / wall time of the whole call (no per-launch events)'}}
+        prec = prec or args.precision
+        set_precision(prec)
+        try:
+            ids_b, dur_b = ids[:b].contiguous(), dur[:b].contiguous()
+            st = make_step(ids_b, dur_b)
+            for _ in range(5):
+                st()
+            sync()
+            n = max(args.steps, 20)
+            el, (_, dl) = _time_steps(st, n, sync)
+        finally:
+            set_precision(args.precision)
+        fr = int(dl.sum().item())
+        out_c = {'batch': b, 'ms_per_step': el / n * 1e3, 'value': fr * hop * n / el, 'unit': 'audio samples/s',
+                 'rtf': el / (fr * hop * n / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': prec,
+                 'roofline': wall_roofline(prec, step_flops(b, fr), step_bytes_bf16(b, fr), el / n)}
+        if name:
+            out_c['config'] = name
+        return out_c
 
     if rank == 0:
-        conv_ms, n_launch = prof[0], prof[1]
-        # algorithmic FLOPs (2*Cout*Cin*K per output position) of the bracketed MFMA conv launches on
-        # this rank: HiFi-GAN convs process sum(frames)*upsampling positions (ragged, early exit),
-        # FastPitch decoder convs B*T_max positions, encoder/predictor convs B*L positions.
-        t_max = int(dec_lens.max().item())
-        flops = args.steps * (hg_fpf * frames + dec_fpt * B * t_max + enc_fpt * B * Lt)
+        conv_ms, n_launch, n_sections = prof[0], prof[1], prof[2]
+        flops = args.steps * step_flops(B, frames)
         achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes per conv launch: OFFLINE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (profiles/rN/traffic.json; gpurun forbids mixing PMC with the timed run), newest round first
         traffic, traffic_src = None, None
-        if B == 32 and Lt == 64 and args.precision == 'f32' and world == 1:
-            for rnd in ('r2', 'r1'):
+        if B == 32 and Lt == 64 and world == 1:
+            for rnd in ('r3', 'r2', 'r1'):
                 try:
-                    with open(os.path.join(REPO, 'profiles', rnd, 'traffic.json')) as f:
+                    with open(os.path.join(REPO, 'profiles', rnd, 'traffic.json' if args.precision == 'f32' else f'traffic_{args.precision}.json')) as f:
                         traffic = json.load(f)['bytes_per_conv_launch_corrected']
-                    traffic_src = f'offline PMC pass, profiles/{rnd}/traffic.json'
+                    traffic_src = f'offline PMC pass, profiles/{rnd}/' + ('traffic.json' if args.precision == 'f32' else f'traffic_{args.precision}.json')
                     break
                 except (OSError, KeyError):
                     pass
         prec_name = {'f32': 'fp32', 'bf16': 'bf16 MFMA', 'bf16x3': 'split-bf16 MFMA'}[args.precision]
         par = f'dp{world}' + (' (ranks share ONE device, gloo + host staging: functional check, not a scaling number)' if one_dev else '')
+        time_basis = ('HIP events on the launch stream: one pair per launch, one pair per fork..join section of the three-stream ResBlock '
+                      'schedule (wall time of the section); kernel time = length of the UNION of these intervals (the two pipeline '
+                      'streams overlap)')
+        if args.precision == 'bf16':
+            byts = args.steps * step_bytes_bf16(B, frames)
+            gbs = byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+            roof = {'bound': 'hbm', 'kernel': 'bf16 octet engine (bfo_resblock_pair + bfo_conv1d + bfo_convt) + conv1d_mfma_bf16 for FastPitch',
+                    'kernel_time_basis': time_basis, 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                    'mfma_achieved_tflops': achieved, 'mfma_peak_tflops': peak, 'mfma_frac': achieved / peak,
+                    'algorithmic_bytes_per_step': byts / args.steps}
+        else:
+            roof = {'bound': 'mfma',
+                    'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
+                    'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
+        roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
+                     'launches': int(n_launch), 'sections': int(n_sections),
+                     'avg_section_ms': conv_ms / max(1.0, n_sections), 'avg_launch_ms': conv_ms / max(1.0, n_launch),
+                     'launch_note': 'a section = one event pair = a single launch or a fork..join group of up to 18 concurrent '
+                                    'ResBlock launches on three streams; avg_launch_ms = kernel time / launches (overlapped launches share time)',
+                     'kernel_ms_per_step': conv_ms / args.steps})
         out = {
             'metric': 'audio samples/sec (FastPitch+HiFi-GAN, synthetic 64-phoneme inputs)',
             'value': samples / elapsed, 'unit': 'audio samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak',
             'vs_baseline': None, 'dtype': {'f32': 'f32', 'bf16': 'bf16', 'bf16x3': 'f32 via split-bf16 (3x bf16 MFMA, fp32 accumulate)'}[args.precision], 'data': 'synthetic (ids, forced durations, random-init weights)',
             'rtf': elapsed / (samples / SAMPLE_RATE),
             'config': {'workload': f'FastPitch+HiFi-GAN, synthetic {Lt}-phoneme x batch{B} per GPU, {prec_name}, '
-                                   f'{world}xMI355X', 'batch_per_gpu': B, 'n_tokens': Lt,
+                                   f'{world}xMI355X', 'batch_per_gpu': B, 'global_batch': g_batch, 'n_tokens': Lt,
                        'frames_per_step_rank0': frames, 'parallelism': par, 'dp_transport': transport,
+                       'dp_fallback_reason': os.environ.get('TTSAMD_BENCH_FALLBACK_REASON'),
                        'schedule': ('two HIP streams: FastPitch of step i+1 under HiFi-GAN of step i (ttsamd.pipeline)' if args.pipeline else
                                     'one stream per step')},
-            'roofline': {'bound': 'mfma' if args.precision == 'f32' else 'hbm (fp32 activations; MFMA figures for reference)',
-                         'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
-                         'kernel_time_basis': 'HIP events on the launch stream: one pair per launch, one pair per fork..join section of the three-stream ResBlock schedule (wall time of the section); kernel time = length of the UNION of these intervals (the two pipeline streams overlap)',
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
-                         'launches': int(n_launch), 'avg_launch_ms': conv_ms / max(1.0, n_launch),
-                         'kernel_ms_per_step': conv_ms / args.steps},
+            'roofline': roof,
         }
+        if world > 1:
+            out['exchange_ms_per_step'] = xch_ms          # C2 audio fan-in (pack + transfer), max over ranks; the length exchange
+            out['exchange_note'] = ('HIP events around the packed audio fan-in on each rank, max over ranks; the all-gather of the '
+                                    'lengths rides in the step\'s one host synchronisation')
         if world == 1 and not args.no_small and B > 8:
             out['configs'] = [small_config(1), small_config(8)]
+            if not args.no_extra:
+                out['configs'] += extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync)
+        if world == 1 and not args.no_extra:
+            out['d2h'] = d2h_probe(wave, dec_lens, hop)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(fp_sd, hg_sd, Lt)
         elif world > 1:
@@ -374,6 +500,147 @@ def main():
         dist.barrier()
         dpx.close()
         dist.destroy_process_group()
+
+
+def d2h_probe(wave, dec_lens, hop):
+    """the GPU number excludes the device -> host copy of the audio; reported here.  One copy of the padded
+    [B, n_max] wave into a pinned host buffer (what FastPitch2Wave.tts_batch does once per batch; the reference copies per
+    utterance, models/fastpitch/networks.py:345), median of 5."""
+    host = torch.empty(wave.shape, dtype=wave.dtype, pin_memory=True)
+    ts = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        host.copy_(wave, non_blocking=True)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[1:])
+    nbytes = wave.numel() * 4
+    return {'d2h_ms': ts[len(ts) // 2] * 1e3, 'bytes': nbytes, 'valid_bytes': int(dec_lens.sum().item()) * hop * 4,
+            'gb_per_s': nbytes / ts[len(ts) // 2] / 1e9, 'what': 'padded [B, n_max] fp32 wave -> pinned host buffer, one copy per batch'}
+
+
+def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync):
+    """The other BASELINE configs as driver-visible sub-results (each: ms_per_step, audio samples/s, a wall-time roofline):
+    C3  the per-GPU share (B = 256 / 8 = 32) of the bf16 configuration;
+    C4  Tacotron2 autoregressive decode + HiFi-GAN, batch 8, 448 forced decoder steps (the gate is biased shut so the work is
+        fixed; prenet dropout on);
+    C5  FastPitch 4-speaker + MelVocos('22k'), batch 32, one speaker id per call cycling 0..3."""
+    from ttsamd import engine as E, synth
+    from ttsamd.config import NET_CONFIG, TACOTRON2_CONFIG, HIFIGAN_CONFIG
+    res = []
+    B = ids.shape[0]
+    res.append(small_config(B, prec='bf16', name=f'C3 per-GPU share: FastPitch+HiFi-GAN, synthetic 64-phoneme x batch{B}, bf16 MFMA '
+                                                 '(HiFi-GAN on the bf16 octet engine)'))
+    n = max(args.steps, 10)
+    hgf = hifigan_flops_per_frame(HIFIGAN_CONFIG)
+    # ---- C4
+    try:
+        frames_t, bt = 448, 8
+        taco = E.Tacotron2Engine(synth.tacotron2_state_dict(TACOTRON2_CONFIG, seed=0, gate_bias=-30.0), TACOTRON2_CONFIG, device=dev)
+        tids = torch.from_numpy(synth.synth_ids(bt, 64)).to(dev)
+        tlens = torch.full((bt,), 64, dtype=torch.int64, device=dev)
+        sids = torch.zeros(bt, dtype=torch.int64, device=dev)
+
+        def c4(seed):
+            mel, mel_lens, _ = taco.infer(tids, sids, tlens, max_step=frames_t, dropout_seed=seed)
+            return hg.forward(mel.contiguous(), mel_lens.to(torch.int64)), mel_lens
+        for i in range(2):
+            c4(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(n):
+            _, ml = c4(100 + i)
+        sync()
+        el = (time.perf_counter() - t0) / n
+        t1 = time.perf_counter()
+        for i in range(n):
+            taco.infer(tids, sids, tlens, max_step=frames_t, dropout_seed=200 + i)
+        sync()
+        el_t = (time.perf_counter() - t1) / n
+        fr = int(ml.sum().item())
+        # decoder GEMVs per step and utterance: two LSTM cells (4 x 1024 rows over 1792 + 2560 inputs... counted from the config)
+        c = TACOTRON2_CONFIG
+        mem = c['encoder_embedding_dim'] + (c['speaker_embedding_dim'] if c.get('num_speakers', 1) > 1 else 0)
+        lstm = 2.0 * 4 * c['attention_rnn_dim'] * (c['prenet_dim'] + mem + c['attention_rnn_dim']) + \
+            2.0 * 4 * c['decoder_rnn_dim'] * (c['attention_rnn_dim'] + mem + c['decoder_rnn_dim'])
+        flops = hgf * fr + lstm * fr
+        res.append({'config': 'C4 Tacotron2 (autoregressive LSTM-attention decoder, persistent kernel) + HiFi-GAN, batch 8 x 64 tokens, '
+                              '448 forced decoder steps, fp32', 'batch': bt, 'ms_per_step': el * 1e3, 'value': fr * hop / el,
+                    'unit': 'audio samples/s', 'rtf': el / (fr * hop / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': 'f32',
+                    'ms_tacotron2': el_t * 1e3, 'us_per_decoder_step': el_t / frames_t * 1e6,
+                    'parity': 'unpinned (torchaudio Tacotron2 is not in the reference tree; SURVEY §8c)',
+                    'roofline': wall_roofline('f32', flops, 0.0, el)})
+        del taco
+    except Exception as e:                                       # noqa: BLE001  (a sub-result must not take the headline line down)
+        res.append({'config': 'C4 Tacotron2 + HiFi-GAN', 'error': str(e)[:300]})
+    # ---- C5
+    try:
+        cfg4 = dict(NET_CONFIG, n_speakers=4, speaker_emb_weight=1.0)
+        fp4 = E.FastPitchEngine(synth.fastpitch_state_dict(cfg4), cfg4, device=dev)
+        voc = E.VocosEngine(synth.vocos_state_dict(), device=dev)
+        spk = [0]
+
+        def c5():
+            spk[0] = (spk[0] + 1) % 4
+            mel, dl, *_ = fp4.infer(ids, dur_tgt=dur, speaker=spk[0])
+            return voc.forward(mel, dl), dl
+        for _ in range(3):
+            c5()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            _, dl = c5()
+        sync()
+        el = (time.perf_counter() - t0) / n
+        fr = int(dl.sum().item())
+        dec_fpt, enc_fpt = fastpitch_conv_flops_per_pos(cfg4)
+        flops = VOCOS_FLOPS_PER_FRAME * fr + dec_fpt * (fr + B) + enc_fpt * B * ids.shape[1]
+        res.append({'config': f'C5 FastPitch 4-speaker + MelVocos(22k) (ISTFT head), batch {B}, fp32', 'batch': B, 'ms_per_step': el * 1e3,
+                    'value': fr * hop / el, 'unit': 'audio samples/s', 'rtf': el / (fr * hop / SAMPLE_RATE), 'frames': fr, 'steps': n,
+                    'dtype': 'f32', 'roofline': wall_roofline('f32', flops, 0.0, el)})
+    except Exception as e:                                       # noqa: BLE001
+        res.append({'config': 'C5 FastPitch 4-speaker + MelVocos', 'error': str(e)[:300]})
+    return res
+
+
+VOCOS_FLOPS_PER_FRAME = 26.85e6      # SURVEY §8d: MelVocos('22k'), conv / linear / DFT GEMMs per mel frame
+
+
+def hifigan_octet_bytes_per_frame(h):
+    """Algorithmic HBM bytes per mel frame of the HiFi-GAN conv launches on the bf16 octet engine: every
+    tensor crosses HBM as bf16; a fused c1 -> c2 pair (C <= 128) reads its input once and writes once; at C = 256 c1 and c2
+    are two launches (read + write, read + residual + write); the two accumulating last pairs of a stage re-read the sum."""
+    c0 = h['upsample_initial_channel']
+    by = 2.0 * (h['num_mels'] + c0)
+    ch, mul = c0, 1
+    nk = len(h['resblock_kernel_sizes'])
+    for u in h['upsample_rates']:
+        by += 2.0 * (ch * mul + (ch // 2) * mul * u)
+        ch, mul = ch // 2, mul * u
+        per_pair = 2.0 * (2 if ch <= 128 else 5) * ch * mul
+        for dil in h['resblock_dilation_sizes']:
+            by += len(dil) * per_pair
+        by += 2.0 * (nk - 1) * ch * mul
+    return by
+
+
+def fastpitch_conv_bytes_per_pos(c):
+    """(decoder, encoder + predictors) algorithmic HBM bytes per position of FastPitch's conv launches with fp32
+    activations: 4 * (Cin + Cout * (1 + residual)) per conv."""
+    d = c['symbols_embedding_dim']
+
+    def layer(dh, nh, filt):
+        return 4.0 * ((d + 3 * nh * dh) + (nh * dh + 2 * d) + (d + filt) + (filt + 2 * d))
+    dec = c['out_fft_n_layers'] * layer(c['out_fft_d_head'], c['out_fft_n_heads'], c['out_fft_conv1d_filter_size']) + \
+        4.0 * (d + c['n_mel_channels'])
+    enc = c['in_fft_n_layers'] * layer(c['in_fft_d_head'], c['in_fft_n_heads'], c['in_fft_conv1d_filter_size'])
+    for p in ('dur', 'pitch', 'energy'):
+        if p == 'energy' and not c['energy_conditioning']:
+            continue
+        f, n = c[f'{p}_predictor_filter_size'], c[f'{p}_predictor_n_layers']
+        enc += 4.0 * ((d + f) + (n - 1) * 2 * f)
+    return dec, enc
 
 
 def hifigan_flops_per_frame(h):

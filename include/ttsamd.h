@@ -324,7 +324,8 @@ int32_t ttsamd_dp_gather_audio(void* comm, const float* packed, float* recv, con
 /* Timing hooks for bench.py (roofline of the dominant kernel): when enabled, hifigan
  * forward brackets its ResBlock conv launches with HIP events on the launch stream. */
 int32_t ttsamd_profile_enable(int32_t on);
-/* Fills: [0]=sum of conv-kernel ms, [1]=number of conv launches, [2]=conv GFLOP (algorithmic) */
+/* Fills: [0] = conv-kernel ms (length of the union of the timed sections' intervals), [1] = number of conv launches,
+ * [2] = number of timed sections (event pairs: a single launch, or one fork..join group of concurrent launches) */
 int32_t ttsamd_profile_read(double* out3);
 
 #ifdef __cplusplus

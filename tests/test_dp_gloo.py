@@ -129,6 +129,20 @@ def test_shard_bounds_cover():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
+def test_shard_indices_round_robin():
+    """tts_sharded deals the length-sorted list round-robin: every index exactly once, shard sizes within one, and
+    chunk c of every rank covers the same stretch of the sorted list (equal work per collective)."""
+    from ttsamd import dp
+    for n in (0, 1, 7, 32, 257):
+        order = list(range(n))[::-1]
+        for world in (1, 2, 3, 8):
+            shards = [dp.shard_indices(order, world, r) for r in range(world)]
+            assert sorted(i for sh in shards for i in sh) == sorted(order)
+            assert max(map(len, shards)) - min(map(len, shards)) <= 1
+            for sh in shards:
+                assert all(order.index(a) + world == order.index(b) for a, b in zip(sh, sh[1:]))
+
+
 def test_bench_self_launch_relays_failure():
     """`python bench.py --gpus 2` typed as is starts its own ranks; without a GPU every rank fails and the
     launcher must exit non-zero (never hang, never print a JSON line)."""

@@ -16,6 +16,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -164,6 +165,27 @@ def test_bench_two_ranks_one_device():
     assert 'ONE device' in out['config']['parallelism']
 
 
+@pytest.mark.parametrize('fault', ['TTSAMD_BENCH_TEST_STALL', 'TTSAMD_BENCH_TEST_DIE'])
+def test_bench_watchdog_restarts_stalled_or_dead_ranks(fault):
+    """The parent of a self-launched N > 1 run is the ranks' watchdog: a rank that never reaches the rendezvous (rank 0 then
+    blocks for gloo's 30-minute default) or dies must cost the watchdog budget ONCE -- every child is killed, fresh ranks
+    start on the torch.distributed transport, and the line says why."""
+    env = dict(os.environ, TTSAMD_BENCH_WATCHDOG_S='60')
+    env[fault] = '1'
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--batch', '4', '--tokens', '16'], capture_output=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0
+    why = out['config']['dp_fallback_reason']
+    assert why and ('watchdog budget' in why if fault.endswith('STALL') else 'exited with' in why), why
+    assert b'restarting all ranks' in p.stderr
+    assert time.time() - t0 < 400
+
+
 def _sharded_worker(rank, world, port, tmpdir):
     for p in (os.path.join(REPO, 'tts-arabic-pytorch_amd'), os.path.join(REPO, 'tests')):
         if p not in sys.path:
@@ -195,13 +217,13 @@ def _sharded_worker(rank, world, port, tmpdir):
         res = dp.tts_sharded(model, texts, batch_size=2, dp=dpx, denoise=0.005)
         if rank == 0:
             assert len(res) == len(texts) and all(w.device.type == 'cpu' and w.dim() == 1 for w in res)
-            # one process, the same sub-batches: length-sorted order, contiguous shards, chunks of batch_size
+            # one process, the same sub-batches: length-sorted order, round-robin shards, chunks of batch_size
             order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))
             ref = [None] * len(texts)
             for r in range(world):
-                lo, hi = dp.shard_bounds(len(order), world, r)
-                for c0 in range(lo, hi, 2):
-                    chunk = order[c0:min(hi, c0 + 2)]
+                shard = dp.shard_indices(order, world, r)
+                for c0 in range(0, len(shard), 2):
+                    chunk = shard[c0:c0 + 2]
                     waves = model.tts_batch([texts[i] for i in chunk], denoise=0.005)
                     for i, w in zip(chunk, waves):
                         ref[i] = w

@@ -395,7 +395,7 @@ int32_t ttsamd_profile_read(double* out3) {
     if (hi >= lo) ms += hi - lo;
     out3[0] = ms;
     out3[1] = (double)g_prof.launches;
-    out3[2] = g_prof.flops_per_frame;
+    out3[2] = (double)(g_prof.used / 2);
     return 0;
 }
 

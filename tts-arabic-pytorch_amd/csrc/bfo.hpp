@@ -43,6 +43,7 @@ struct BfoPairParams {
     float in_slope;        // activation x was stored with (0.1)
     float mid_slope;       // leaky-relu between c1 and c2 (0.1)
     float out_slope;       // y = leaky_relu(v, out_slope); 1 = raw
+    unsigned long long* timing;   // tools/bfo_pair_bench -DBFO_TIMING only: [blocks][16] shader-clock stamps (nullptr otherwise)
 };
 
 struct BfoConvParams {
@@ -100,7 +101,11 @@ __device__ __forceinline__ int bfo_pk(float a, float b) {      // v_cvt_pk_bf16_
     const bfo_f2 v = {a, b};
     return __builtin_bit_cast(int, __builtin_convertvector(v, bfo_h2));
 }
-__device__ __forceinline__ float bfo_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// leaky-relu for slopes in (0, 1] as max(v, v * slope) and its inverse (1 / slope >= 1) as min(a, a / slope): two VALU
+// operations instead of multiply + compare + select (the exchange and epilogue phases are VALU-bound next to a partner
+// wave that is issuing MFMAs)
+__device__ __forceinline__ float bfo_lrelu(float v, float slope) { return __builtin_fmaxf(v, v * slope); }
+__device__ __forceinline__ float bfo_unrelu(float a, float inv) { return __builtin_fminf(a, a * inv); }
 
 // One conv over an LDS-resident window: acc[j] += sum_{h, tap} A(h, tap) x B(h, tap, column tile j).
 //   wrs / wv  : buffer resource of the packed weights and this lane's byte offset in it (kk * CoutP + row) * 16

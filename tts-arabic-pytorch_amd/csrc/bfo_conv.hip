@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
             const float r[4] = {bfo_lo(rv[g].x), bfo_hi(rv[g].x), bfo_lo(rv[g].y), bfo_hi(rv[g].y)};
             const float s[4] = {bfo_lo(sv[g].x), bfo_hi(sv[g].x), bfo_lo(sv[g].y), bfo_hi(sv[g].y)};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = bfo_lrelu((v[e] + bfo_lrelu(r[e], rinv) + s[e]) * sc, os);
+            for (int e = 0; e < 4; ++e) v[e] = bfo_lrelu((v[e] + bfo_unrelu(r[e], rinv) + s[e]) * sc, os);
             bfo_i2 w;
             w.x = bfo_pk(v[0], v[1]);
             w.y = bfo_pk(v[2], v[3]);
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void bfo_unpack_kernel(const uint4* __restrict
     float* yr = out + ((int64_t)b * C + 8 * o) * L + t;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-        if (8 * o + e < C) yr[(int64_t)e * L] = bfo_lrelu(v[e], inv_slope);
+        if (8 * o + e < C) yr[(int64_t)e * L] = (inv_slope >= 1.f ? bfo_unrelu(v[e], inv_slope) : bfo_lrelu(v[e], inv_slope));
 }
 
 int32_t bfo_launch_pack(const float* x, int32_t B, int32_t C, int32_t L, float slope, void* out, hipStream_t s) {

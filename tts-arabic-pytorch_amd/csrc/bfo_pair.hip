@@ -53,6 +53,20 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
     int len = L;
     if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
     if (q0 >= len) return;
+#ifndef BFO_PRIO_VALU
+#define BFO_PRIO_VALU 2
+#endif
+#define BFO_PRIO(n) __builtin_amdgcn_s_setprio(n);
+#ifdef BFO_TIMING
+    const unsigned long long wc0 = wall_clock64();
+    unsigned long long tst[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tst[i] = 0;
+    tst[0] = clock64();
+#define BFO_STAMP(i) tst[i] = clock64();
+#else
+#define BFO_STAMP(i)
+#endif
     const int dil = p.dil;
     const int W1 = G::NCOLS + (K - 1) * dil;                // staged columns actually used
     const int x0 = q0 - H - (K - 1) * dil / 2;              // position of staged column 0
@@ -76,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
         }
     }
     __syncthreads();
+    BFO_STAMP(1)
 
     const int wv = (kk * C + 32 * wm + l31) * 16;           // this lane's A fragment inside a (h, tap) step
     const int cw = wn * (NT * 32) + l31;                    // this lane's column in tile 0
@@ -94,6 +109,8 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
     }
     bfo_mma<K, G::PH, NT>(acc, bfo_rsrc(p.w1, (unsigned)NH * K * 2 * C * 16), wv, 2 * C * 16, sB, NH, 2 * WS, dil);
 
+    BFO_STAMP(2)
+    BFO_PRIO(BFO_PRIO_VALU)                                 // the VALU-heavy phases outrank a partner wave's MFMA stream
     // residual (= the activated input at the output positions): 8 bytes per (tile, octet) in the C layout
     int vo[NT];
 #pragma unroll
@@ -107,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
 #pragma unroll
         for (int g = 0; g < 4; ++g) rv[j][g] = bfo_ld8(xrs, vo[j], (4 * wm + g) * L * 16, 0);
 
+    BFO_STAMP(6)
     __syncthreads();                                        // every wave is done with the window
+    BFO_STAMP(7)
     {
         const float ms = p.mid_slope;
 #pragma unroll
@@ -124,7 +143,9 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
             }
         }
     }
+    BFO_STAMP(8)
     __syncthreads();
+    BFO_STAMP(3)
 
     // ---- phase B: accumulators start from b2 + x (x = a >= 0 ? a : a / in_slope)
     {
@@ -137,14 +158,18 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float a0 = bfo_lo(rv[j][g].x), a1 = bfo_hi(rv[j][g].x), a2 = bfo_lo(rv[j][g].y), a3 = bfo_hi(rv[j][g].y);
-                acc[j][4 * g] = bv[4 * g] + bfo_lrelu(a0, inv);
-                acc[j][4 * g + 1] = bv[4 * g + 1] + bfo_lrelu(a1, inv);
-                acc[j][4 * g + 2] = bv[4 * g + 2] + bfo_lrelu(a2, inv);
-                acc[j][4 * g + 3] = bv[4 * g + 3] + bfo_lrelu(a3, inv);
+                acc[j][4 * g] = bv[4 * g] + bfo_unrelu(a0, inv);
+                acc[j][4 * g + 1] = bv[4 * g + 1] + bfo_unrelu(a1, inv);
+                acc[j][4 * g + 2] = bv[4 * g + 2] + bfo_unrelu(a2, inv);
+                acc[j][4 * g + 3] = bv[4 * g + 3] + bfo_unrelu(a3, inv);
             }
     }
+    BFO_STAMP(9)
+    BFO_PRIO(0)
     bfo_mma<K, G::PH, NT>(acc, bfo_rsrc(p.w2, (unsigned)NH * K * 2 * C * 16), wv, 2 * C * 16, sB, NH, 2 * WS, 1);
 
+    BFO_STAMP(4)
+    BFO_PRIO(BFO_PRIO_VALU)
     // ---- epilogue
     const bfo_i4 yrs = bfo_rsrc((char*)p.y + (int64_t)b * NO * L * 16, (unsigned)NO * L * 16);
     const float os = p.out_slope;
@@ -177,6 +202,18 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
                 bfo_st8(w, yrs, vo[j], (4 * wm + g) * L * 16, 0);
             }
     }
+#ifdef BFO_TIMING
+    tst[5] = clock64();
+    if (p.timing && tid == 0) {
+        unsigned long long* tp = p.timing + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) tp[i] = tst[i];
+        tp[12] = wall_clock64();
+        tp[13] = wc0;
+    }
+#endif
+#undef BFO_STAMP
+#undef BFO_PRIO
 }
 
 template <int K, int C>

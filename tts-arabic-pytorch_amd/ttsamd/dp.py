@@ -31,6 +31,12 @@ def shard_bounds(n_items, world, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def shard_indices(order, world, rank):
+    """Round-robin shard of a (length-sorted) index list: positions rank, rank + world, ...  Every rank's c-th chunk
+    then covers the same stretch of the sorted list, so the per-chunk collectives meet ranks with equal work."""
+    return list(order[rank::world])
+
+
 class _Grow:
     """Persistent buffer that only ever grows (x1.5), so steady-state calls allocate nothing."""
 
@@ -187,11 +193,16 @@ class Dp:
         b, stride = wave.shape
         if total == 0 or b == 0:
             return out[:0]
+        # the kernel takes raw pointers: a sliced wave or an int32 length tensor would be packed silently wrong
+        assert wave.dtype == torch.float32 and wave.stride(1) == 1 and wave.stride(0) >= wave.shape[1], 'wave: fp32 rows, unit stride'
+        assert nsamples.dtype == torch.int64 and nsamples.is_contiguous() and nsamples.device == wave.device and \
+            nsamples.numel() == b, 'nsamples: contiguous int64 [b] on the wave\'s device'
+        stride = wave.stride(0)
         if wave.device.type == 'cuda':
             from . import lib as L
             lib = L.load()
             with torch.cuda.device(wave.device):
-                L.check(lib.ttsamd_dp_pack_audio(self._ptr(wave), stride, self._ptr(nsamples), b, stride, self._ptr(out),
+                L.check(lib.ttsamd_dp_pack_audio(self._ptr(wave), stride, self._ptr(nsamples), b, wave.shape[1], self._ptr(out),
                                                  C.c_void_p(torch.cuda.current_stream(wave.device).cuda_stream)),
                         'dp_pack_audio')
         else:
@@ -311,8 +322,10 @@ def gather_audio(wave, lens, dst=0):
 
 def tts_sharded(model, texts, batch_size=32, dst=0, dp=None, **tts_kwargs):
     """Data-parallel `FastPitch2Wave.tts(list)`: every rank calls this with the SAME list.
-    Utterances are ordered by length (so each rank's padded sub-batches are tight), dealt out in contiguous
-    shards (`shard_bounds`) and synthesised locally in chunks of `batch_size` with
+    Utterances are ordered by length (so each rank's padded sub-batches are tight), dealt out ROUND-ROBIN over the
+    ranks (`shard_indices`: rank r takes the sorted positions r, r + world, ... -- chunk c of every rank then holds
+    texts of similar length, and since every chunk ends in a collective no rank waits for one that got all the long
+    ones) and synthesised locally in chunks of `batch_size` with
     `model.tts_batch_device` — waves stay in HBM — then each chunk's valid samples are packed and fanned in to
     rank `dst`, which does ONE device->host copy per chunk and returns the waves in the original order
     (other ranks: None).  Models without `tts_batch_device` (test stubs) go through `model.tts` + a host pad.
@@ -321,12 +334,12 @@ def tts_sharded(model, texts, batch_size=32, dst=0, dp=None, **tts_kwargs):
     dpx = dp if dp is not None else default(getattr(model, 'device', None))
     world, rank = dpx.world, dpx.rank
     order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))
-    spans = [shard_bounds(len(order), world, r) for r in range(world)]
-    lo, hi = spans[rank]
-    n_chunks = max((h - l + batch_size - 1) // batch_size for l, h in spans) if texts else 0
+    shards = [shard_indices(order, world, r) for r in range(world)]
+    mine_idx = shards[rank]
+    n_chunks = max((len(sh) + batch_size - 1) // batch_size for sh in shards) if texts else 0
     gathered = [[] for _ in range(world)]          # on dst: per source rank, waves in local order
     for c in range(n_chunks):
-        mine = [texts[i] for i in order[lo + c * batch_size:min(hi, lo + (c + 1) * batch_size)]]
+        mine = [texts[i] for i in mine_idx[c * batch_size:(c + 1) * batch_size]]
         if hasattr(model, 'tts_batch_device'):
             if mine:
                 wave, nsamp = model.tts_batch_device(mine, **tts_kwargs)       # original order within the chunk
@@ -352,7 +365,6 @@ def tts_sharded(model, texts, batch_size=32, dst=0, dp=None, **tts_kwargs):
         return None
     out = [None] * len(texts)
     for r in range(world):
-        l, _ = spans[r]
-        for i, w in enumerate(gathered[r]):
-            out[order[l + i]] = w
+        for i, w in zip(shards[r], gathered[r]):
+            out[i] = w
     return out
