@@ -151,6 +151,35 @@ def test_hifigan_ragged_batch_matches_unbatched(dev, synth_weights, hifigan_engi
         assert float(wave[b, 256 * n:].abs().max()) == 0.0 if n < 23 else True
 
 
+@pytest.mark.parametrize('mode,tol', [('f32', WAVE_TOL), ('bf16', 4e-2)])
+def test_hifigan_ragged_fused_kernels_vs_oracle(dev, synth_weights, monkeypatch, mode, tol):
+    """The fused c1 -> c2 pair and the all-phase transposed-conv kernels, FORCED ON, against the oracle on a ragged batch
+    whose utterances end inside a fused tile's halo: fp32 resblock_pair tiles hold 252 / 248 / 244 outputs at C = 32 (252 at
+    C = 64, k = 3) and the stage-4 / stage-3 lengths of 1- and 2-frame utterances (256, 512 / 128, 256) fall 4..12 columns
+    past a tile edge; the bf16 octet engine's C = 128 tiles hold 254 / 250 / 246 outputs and a 4-frame utterance is 256
+    positions there.  Every layer must zero-pad at the TRUE edge (models/fastpitch/networks.py:340-341 vocodes exact-length mels)."""
+    import tts_oracle as O
+    from ttsamd.config import HIFIGAN_CONFIG
+    from ttsamd.engine import HifiGanEngine, set_precision
+    monkeypatch.setenv('TTSAMD_FUSED_PAIR', '1')
+    monkeypatch.setenv('TTSAMD_FUSED_PAIR_C64', '1')
+    monkeypatch.setenv('TTSAMD_CONVT', '1')
+    monkeypatch.setenv('TTSAMD_BFO', '1')
+    w = O.fold_weight_norm(synth_weights['hifigan'])
+    rng = np.random.default_rng(11)
+    lens = [19, 1, 2, 4, 8]
+    mel = (rng.standard_normal((5, 80, 19)) * 1.5 - 4.0).astype(np.float32)
+    set_precision(mode)
+    try:
+        wave = HifiGanEngine(synth_weights['hifigan'], device=dev).forward(torch.from_numpy(mel).to(dev), torch.tensor(lens).to(dev)).cpu()
+    finally:
+        set_precision('f32')
+    for b, n in enumerate(lens):
+        ref = O.hifigan_forward(w, mel[b, :, :n], HIFIGAN_CONFIG)[0]
+        assert maxabs(wave[b, :256 * n], ref) < tol, (mode, b, maxabs(wave[b, :256 * n], ref))
+        assert float(wave[b, 256 * n:].abs().max()) == 0.0 if n < 19 else True
+
+
 @pytest.fixture(scope='module')
 def fastpitch_engine(dev, synth_weights):
     from ttsamd.engine import FastPitchEngine

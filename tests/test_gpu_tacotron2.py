@@ -315,3 +315,23 @@ def test_tacotron2_persistent_decoder_geometries(dev, monkeypatch):
             assert mel_lens.cpu().tolist() == lens_g.cpu().tolist() == [steps] * B
             assert bool(torch.isfinite(mel).all())
             assert maxabs(mel, mel_g) < MEL_TOL and maxabs(al, al_g) < ALIGN_TOL, (num_speakers, B, L, steps)
+
+
+def test_tacotron2_persistent_explicit_request_raises_when_it_does_not_fit(dev, monkeypatch):
+    """TTSAMD_TACO_PERSISTENT=1 / 2 is a demand, not a hint: a geometry outside the residency plan (batch 9 > 8) must raise instead
+    of silently taking the graph path (so the geometry test above really proves the persistent kernel ran); unset, the same call
+    runs on the graph path and matches it."""
+    from ttsamd.engine import Tacotron2Engine
+    from ttsamd.lib import TtsAmdError
+    cfg, sd = _weights(gate_bias=-20.0)
+    eng = Tacotron2Engine(sd, cfg, device=dev)
+    tok, lens = _tokens(9, 12, 3)
+    sids = torch.arange(9) % cfg['num_speakers']
+    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '2')
+    with pytest.raises(TtsAmdError, match='does not fit'):
+        eng.infer(tok, sids, lens, max_step=4, dropout_seed=-1)
+    monkeypatch.delenv('TTSAMD_TACO_PERSISTENT')
+    mel, mel_lens, _ = eng.infer(tok, sids, lens, max_step=4, dropout_seed=-1)
+    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '0')
+    mel_g, _, _ = eng.infer(tok, sids, lens, max_step=4, dropout_seed=-1)
+    assert mel_lens.cpu().tolist() == [4] * 9 and maxabs(mel, mel_g) == 0.0

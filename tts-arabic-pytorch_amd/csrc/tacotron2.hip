@@ -50,6 +50,10 @@ struct Taco2 {
     mutable std::mutex mu;
     mutable int32_t* pinned = nullptr;      // [TACO_RING][pinned_cap] finished flags copied back asynchronously
     mutable int pinned_cap = 0;
+    // persistent decoder: after a hand-off time-out (the 256 blocks were not co-resident: another stream held CUs) the next
+    // `persist_skip` calls go straight to the graph path instead of paying the 80 ms spin again; doubles up to 256 on every
+    // further time-out, resets on the first success
+    mutable int persist_skip = 0, persist_backoff = 0;
     mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mutable hipEvent_t ev_in = nullptr;
     mutable hipStream_t loop_stream = nullptr;   // capture is not allowed on the legacy default stream torch hands us
@@ -1904,12 +1908,24 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         const int MC = M / 32, NS = MC ? 256 / MC : 0, K4A = (P + M + A) / 4;
         const size_t lds = (size_t)16 * K4A * 16 +
                            sizeof(float) * ((size_t)L * MC + (size_t)PT * 8 + 16 * KS + 2 * (PT + 2 * half) + 256 + 128 + 64 + 256 + NS * MC + 16 + 1024);
-        int dev_id = 0, n_cu = 0, coop = 0;
+        int dev_id = 0, n_cu = 0, coop = 0, lds_max = 0;
         (void)hipGetDevice(&dev_id);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev_id);
-        const bool fits = want && B <= 8 && L <= 256 && (M == 512 || M == 640) && A == 1024 && D == 1024 && P == 256 && KS % 2 == 1 &&
-                          lds <= 160 * 1024 && n_cu >= 256 && coop && w.tail_o > 0;
+        (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_id);
+        const char* pe = getenv("TTSAMD_TACO_PERSISTENT");
+        const bool explicit_req = pe && (pe[0] == '1' || pe[0] == '2');          // an explicit request must run the persistent kernel or fail
+        bool fits = want && B <= 8 && L <= 256 && (M == 512 || M == 640) && A == 1024 && D == 1024 && P == 256 && KS % 2 == 1 &&
+                    lds <= (size_t)std::max(lds_max, 64 * 1024) && n_cu >= 256 && coop && w.tail_o > 0;
+        if (explicit_req && !fits) {
+            set_error("tacotron2_infer: TTSAMD_TACO_PERSISTENT=%c but the persistent decoder does not fit (B=%d <= 8, L=%d <= 256, memory dim %d in "
+                      "{512, 640}, %zu B of LDS <= %d, %d CUs >= 256, cooperative launch %d)", pe[0], B, L, M, lds, lds_max, n_cu, coop);
+            return TTSAMD_EINVAL;
+        }
+        if (fits && !explicit_req) {
+            std::lock_guard<std::mutex> lock(h->mu);
+            if (h->persist_skip > 0) { --h->persist_skip; fits = false; }        // a recent time-out: do not pay the spin again
+        }
         if (fits) {
             TacoPersist q;
             q.pre1 = W + h->pre1;
@@ -1931,28 +1947,46 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
                 TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0xFF, (size_t)w.tail_o * sizeof(float), s));
             TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0, (size_t)w.step_floats * sizeof(float), s));                 // region 0: the zero initial state
             TTS_CHECK_HIP(hipMemsetAsync(w.xch + w.tail_o, 0, 384 * sizeof(float), s));                        // barrier slots, error flag, step count
-            TTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             void* args[] = {&q};
             const double t0 = now_us();
-            TTS_CHECK_HIP(hipLaunchCooperativeKernel(fn, dim3(256), dim3(256), args, (unsigned)lds, s));
+            // LDS opt-in or cooperative launch rejected (another partitioning / device, hipErrorCooperativeLaunchTooLarge): the
+            // graph path below still works, so only an explicit request turns this into an error
+            hipError_t le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (le == hipSuccess) le = hipLaunchCooperativeKernel(fn, dim3(256), dim3(256), args, (unsigned)lds, s);
             int32_t tail[2] = {0, 0};                                   // err_o and steps_o are 64 floats apart: two copies
+            if (le != hipSuccess) {
+                (void)hipGetLastError();
+                if (explicit_req) {
+                    set_error("tacotron2_infer: launching the persistent decoder failed: %s", hipGetErrorString(le));
+                    return TTSAMD_EHIP;
+                }
+                fprintf(stderr, "ttsamd: tacotron2 persistent decoder could not be launched (%s), using the graph path\n", hipGetErrorString(le));
+                h->persist_skip = 1 << 30;                               // this device / partitioning will not change under us
+                tail[0] = -1;
+            } else {
             TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.tail_o + 256, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             TTS_CHECK_HIP(hipMemcpyAsync(&tail[1], w.xch + w.tail_o + 320, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             TTS_CHECK_HIP(hipStreamSynchronize(s));
+            }
             if (dbg) fprintf(stderr, "[taco] persistent decoder: %.0f us for %d steps (%zu B of LDS per block)\n", now_us() - t0, (int)tail[1], lds);
             if (tail[0] != 0) {
                 // a block waited > 80 ms for another one: the 256 blocks were not all resident (CUs held by other streams).  The
                 // graph path below recomputes the whole loop from the same state; only an explicit request is an error.
-                const char* e = getenv("TTSAMD_TACO_PERSISTENT");
-                if (e && (e[0] == '1' || e[0] == '2')) {
+                if (explicit_req) {
                     set_error("tacotron2_infer: the persistent decoder timed out waiting for another block (are 256 CUs free for it?)");
                     return TTSAMD_EHIP;
                 }
-                fprintf(stderr, "ttsamd: tacotron2 persistent decoder timed out, using the graph path\n");
+                if (tail[0] > 0) {
+                    h->persist_backoff = std::min(256, std::max(8, 2 * h->persist_backoff));
+                    h->persist_skip = h->persist_backoff;
+                    fprintf(stderr, "ttsamd: tacotron2 persistent decoder timed out, using the graph path (and for the next %d calls)\n",
+                            h->persist_skip);
+                }
                 TTS_CHECK_HIP(hipMemsetAsync(mel_lens, 0, (size_t)B * sizeof(int32_t), s));     // (the kernel had started counting)
             } else {
                 steps = tail[1];
                 done = true;
+                h->persist_backoff = 0;
             }
             if (const char* dump = done ? getenv("TTSAMD_TACO_DUMP") : nullptr) {   // debugging aid: the region the last step produced
                 std::vector<float> hx((size_t)w.step_floats);
