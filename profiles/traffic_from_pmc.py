@@ -2,7 +2,8 @@
 `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small`, with the calibration factors MEASURED in the conv
 engine's own access patterns (profiles/traffic_calib.py, tools/traffic_calib.hip; MI355X_MICROARCH.md's factor 2.0 for
 FETCH_SIZE is for 16 B/lane streaming reads), next to the ALGORITHMIC bytes of every launch
-    4 * (Cin * L + Cout * L * (1 + has_residual + accumulate))         (fused ResBlock pair: 4 * C * L * (2 + accumulate))
+    4 * (Cin * L + Cout * L * (1 + has_residual + accumulate))         (fused ResBlock pair: 4 * C * L * (2 + accumulate);
+    bf16 octet engine: the same with 2 bytes per element)
 taken from the library's own launch log (TTSAMD_CONV_LOG, launch order = dispatch order).
 usage: python profiles/traffic_from_pmc.py <fetch_dir> <write_dir> <conv_log.csv> <frames> [calib.json] > profiles/rN/traffic.json"""
 import csv
@@ -18,7 +19,7 @@ def dispatches(d, counter):
     rows = {}
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'convt_mfma')):
+            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'convt_mfma', 'bfo_conv1d', 'bfo_convt')):
                 k = int(r['Dispatch_Id'])
                 name = r['Kernel_Name'].split('(')[0].replace('void ttsamd::', '')
                 g = None
@@ -58,6 +59,12 @@ def main():
             L = frames * len_mul if ragged else nout * batch          # valid positions summed over the batch
             if kind == 'fused_pair':
                 alg = 4.0 * cin * L * (2 + (mode != 0))
+            elif kind == 'bfo_pair':                                  # bf16 octet engine: bf16 tensors, one read + one write per pair
+                alg = 2.0 * cin * L * (2 + (mode != 0))
+            elif kind == 'bfo':
+                alg = 2.0 * (cin * L + cout * L * (1 + has_res + (mode != 0)))
+            elif kind == 'bfo_convt':
+                alg = 2.0 * (cin * L + cout * L * n_phase)
             else:
                 alg = 4.0 * (cin * L + cout * L * n_phase * (1 + has_res + (mode != 0)))
         key = f'{name} grid{grid}'
