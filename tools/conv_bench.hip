@@ -1,6 +1,10 @@
 // Standalone micro-benchmark of the MFMA conv engine (kernel experiments; not part of the product).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DTTS_...] tools/conv_bench.hip -o /tmp/conv_bench
+#define TTS_WITH_DIRECT 1
+#include "../tts-arabic-pytorch_amd/csrc/common.hpp"
+namespace ttsamd { bool direct_supported(const ConvParams& p); int32_t launch_direct(const ConvParams& p, hipStream_t stream); }
 #include "../tts-arabic-pytorch_amd/csrc/conv_mfma.hip"
+#include "conv_direct_f32.hip"
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>

@@ -769,6 +769,12 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
              p.lens_out != nullptr, p.n_phase);
     if (p.precision != 0) return launch_conv_bf16_any(p, stream);
     TTS_REQUIRE(!p.x_packed && !p.y_packed, "conv: packed bf16 activations exist only in the bf16 mode");
+#ifdef TTS_WITH_DIRECT   /* tools/conv_bench.hip only: A/B against tools/conv_direct_f32.hip (round 3, no gain: DESIGN.md §4) */
+    {
+        const char* de = getenv("TTSAMD_DIRECT");
+        if (!(de && de[0] == '0') && direct_supported(p)) return launch_direct(p, stream);
+    }
+#endif
 #ifdef TTS_ONLY_K   /* kernel experiments: compile one kernel size only (tools/conv_bench, 10 s instead of 90 s) */
     if (p.K == TTS_ONLY_K) return launch_k<TTS_ONLY_K>(p, stream);
     set_error("conv: built with TTS_ONLY_K=%d", TTS_ONLY_K);
