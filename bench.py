@@ -626,12 +626,14 @@ def hifigan_octet_bytes_per_frame(h):
 
 
 def fastpitch_conv_bytes_per_pos(c):
-    """(decoder, encoder + predictors) algorithmic HBM bytes per position of FastPitch's conv launches with fp32
-    activations: 4 * (Cin + Cout * (1 + residual)) per conv."""
+    """(decoder, encoder + predictors) algorithmic HBM bytes per position of FastPitch's conv launches in the bf16 mode:
+    4 * (Cin + Cout * (1 + residual)) per conv with fp32 activations, 2 bytes per element where a tensor is bf16."""
     d = c['symbols_embedding_dim']
 
     def layer(dh, nh, filt):
-        return 4.0 * ((d + 3 * nh * dh) + (nh * dh + 2 * d) + (d + filt) + (filt + 2 * d))
+        # qkv and o_net on the bf16 MFMA engine with fp32 activations; the conv-FF pair on the octet engine: bf16 input copy,
+        # bf16 1536-channel intermediate, fp32 residual in and fp32 stream out
+        return 4.0 * ((d + 3 * nh * dh) + (nh * dh + 2 * d)) + 2.0 * (d + filt) + (2.0 * filt + 4.0 * 2 * d)
     dec = c['out_fft_n_layers'] * layer(c['out_fft_d_head'], c['out_fft_n_heads'], c['out_fft_conv1d_filter_size']) + \
         4.0 * (d + c['n_mel_channels'])
     enc = c['in_fft_n_layers'] * layer(c['in_fft_d_head'], c['in_fft_n_heads'], c['in_fft_conv1d_filter_size'])

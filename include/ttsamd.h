@@ -258,12 +258,15 @@ int32_t ttsamd_bfo_unpack(const void* in, int32_t batch, int32_t channels, int32
  * -> bf16 [phases][Cin/16][K][2][CoutP][8]; `out` holds ttsamd_bfo_weight_elems(...) uint16 */
 int64_t ttsamd_bfo_weight_elems(int32_t cout, int32_t cin, int32_t k, int32_t up);
 int32_t ttsamd_bfo_pack_weight(const float* w, int32_t cout, int32_t cin, int32_t k, int32_t up, uint16_t* out);
-/* y = act_out(([sum_in +] conv(x) + bias [+ raw(res)]) [/ div]): x, res activated tensors, sum_in raw; mode as below.
- * up > 1: ConvTranspose1d(stride up), y has len_in * up positions (no res / sum). */
+/* y = act_out(([sum_in +] conv(x) + bias [+ raw(res)]) [/ div]): x, res activated tensors, sum_in raw; mode as below;
+ * out_slope 0 = ReLU.  up > 1: ConvTranspose1d(stride up), y has len_in * up positions (no res / sum).
+ * y_f32 != NULL: the result leaves as fp32 channel-first [B][Cout][len] instead of y, res_f32 (NULL = none) is an fp32
+ * channel-first residual: FastPitch's Conv1d + ReLU -> Conv1d + residual block (models/fastpitch/fastpitch/transformer.py:72-90)
+ * keeps its residual stream in fp32 and only the 1536-channel intermediate in bf16. */
 int32_t ttsamd_bfo_conv1d(const void* x, const void* w_packed, const float* bias, const void* res, const void* sum_in,
                           const int64_t* lens, int32_t len_mul, int32_t batch, int32_t cin, int32_t cout, int32_t k,
                           int32_t dilation, int32_t up, int32_t len_in, int32_t mode, float div, float res_slope,
-                          float out_slope, void* y, void* stream);
+                          float out_slope, void* y, float* y_f32, const float* res_f32, void* stream);
 /* one c1 -> c2 pair of ResBlock1 (models.py:46-53) in one launch, C in {32, 64, 128}, k in {3, 7, 11}:
  *   v = raw(x) + conv(lrelu(conv(x, w1, dilation) + b1, mid_slope), w2) + b2
  *   mode 0: y = act(v)   1: y = act(sum_in + v)   2: y = act((sum_in + v) / div);   act = leaky_relu(out_slope), 1 = raw.

@@ -131,6 +131,29 @@ def test_conv1d(dev, cin, cout, k, dil, L, mode, res):
         close(got[i, :, :n], lrelu(v, 0.1), f'utt {i}')
 
 
+@pytest.mark.parametrize('S', [64, 40, 300])
+def test_conv_ff_pair_fp32_stream(dev, S):
+    """FastPitch's PositionwiseConvFF core (transformer.py:72-90) as config 3 runs it: fp32 LayerNorm output packed to bf16,
+    Conv1d(384 -> 1536, k3) + ReLU with a bf16 intermediate, Conv1d(1536 -> 384, k3) + fp32 residual -> fp32 channel-first;
+    64-column tiles for the encoder's short sequences (S <= 96), 256-column tiles otherwise."""
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(S)
+    B, d, di = 3, 384, 1536
+    x = torch.randn(B, d, S, generator=g)
+    w0 = torch.randn(di, d, 3, generator=g) / np.sqrt(d * 3)
+    w2 = torch.randn(d, di, 3, generator=g) / np.sqrt(di * 3)
+    b0, b2 = torch.randn(di, generator=g) * 0.3, torch.randn(d, generator=g) * 0.3
+    xo = bfo.pack(x.to(dev), 1.0)
+    hid = bfo.conv1d(xo, bfo.pack_weight(w0, device=dev), b0.to(dev), di, 3, out_slope=0.0)
+    y = bfo.conv1d(hid, bfo.pack_weight(w2, device=dev), b2.to(dev), d, 3, f32_out=True, res_f32=x.to(dev)).cpu()
+    a = bfo.unpack(xo, 1.0).cpu().double()
+    h_ref = bf(torch.relu(F.conv1d(a, bf(w0), b0.double(), padding=1)).float())
+    close(bfo.unpack(hid, 1.0).cpu(), h_ref, 'intermediate')
+    ref = F.conv1d(h_ref, bf(w2), b2.double(), padding=1) + x.double()
+    err = float((y.double() - ref).abs().max())
+    assert err < 2e-3, err                                  # fp32 output: only accumulation-order noise on O(1) values
+
+
 @pytest.mark.parametrize('cin,cout,u,L', [(512, 256, 8, 150), (256, 128, 8, 300), (128, 64, 2, 700), (64, 32, 2, 1100)])
 def test_conv_transpose1d(dev, cin, cout, u, L):
     """The four HiFi-GAN upsamplers (models.py:96-99): ConvTranspose1d(kernel 2u, stride u, padding u/2)."""

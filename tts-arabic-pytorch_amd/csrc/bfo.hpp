@@ -53,6 +53,8 @@ struct BfoConvParams {
     const float* bias;
     const void* res;       // residual in the y layout, activated with res_slope (nullptr = none)
     const void* sum_in;    // running sum, raw bf16 (mode != 0)
+    float* y_f32;          // != nullptr: the result leaves as fp32 channel-first [B][Cout][Lout] instead (y unused): FastPitch's
+    const float* res_f32;  //   second conv-FF conv writes the fp32 residual stream; res_f32 = fp32 channel-first residual or nullptr
     const int64_t* lens;
     int32_t len_mul, Lin, batch;
     int32_t Cin, Cout, K, dil;
@@ -84,6 +86,8 @@ __device__ bfo_i4 bfo_ld16(bfo_i4 rsrc, int voffset, int soffset, int aux) __asm
 __device__ bfo_i2 bfo_ld8(bfo_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
 __device__ void bfo_st16(bfo_i4 v, bfo_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4i32");
 __device__ void bfo_st8(bfo_i2 v, bfo_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
+__device__ float bfo_ld4f(bfo_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void bfo_st4f(float v, bfo_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 
 __device__ __forceinline__ bfo_i4 bfo_rsrc(const void* base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;

@@ -38,14 +38,15 @@ int32_t ttsamd_bfo_pack_weight(const float* w, int32_t cout, int32_t cin, int32_
 int32_t ttsamd_bfo_conv1d(const void* x, const void* w_packed, const float* bias, const void* res, const void* sum_in,
                           const int64_t* lens, int32_t len_mul, int32_t batch, int32_t cin, int32_t cout, int32_t k,
                           int32_t dilation, int32_t up, int32_t len_in, int32_t mode, float div, float res_slope,
-                          float out_slope, void* y, void* stream) {
-    TTS_REQUIRE(x && w_packed && y && batch >= 1, "bfo_conv1d: null argument");
-    TTS_REQUIRE(mode >= 0 && mode <= 2 && out_slope > 0.f && (!res || res_slope > 0.f), "bfo_conv1d: bad mode / slope");
+                          float out_slope, void* y, float* y_f32, const float* res_f32, void* stream) {
+    TTS_REQUIRE(x && w_packed && (y || y_f32) && batch >= 1, "bfo_conv1d: null argument");
+    TTS_REQUIRE(mode >= 0 && mode <= 2 && out_slope >= 0.f && (!res || res_slope > 0.f), "bfo_conv1d: bad mode / slope");
     BfoConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.y = y; p.w = w_packed; p.bias = bias; p.res = res; p.sum_in = sum_in; p.lens = lens;
     p.len_mul = len_mul; p.Lin = len_in; p.batch = batch; p.Cin = cin; p.Cout = cout; p.K = k; p.dil = dilation; p.up = up;
     p.mode = mode; p.div = div; p.res_slope = res ? res_slope : 1.f; p.out_slope = out_slope;
+    p.y_f32 = y_f32; p.res_f32 = res_f32;
     hipStream_t s = (hipStream_t)stream;
     prof_begin(s, 2.0 * cout * cin * k);
     const int32_t rc = up > 1 ? bfo_launch_convt(p, s) : bfo_launch_conv(p, s);

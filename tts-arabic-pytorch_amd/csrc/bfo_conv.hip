@@ -17,9 +17,9 @@ namespace ttsamd {
 // Conv1d: block = 4 waves, wave = 32 rows x 256 columns (8 accumulators), WM row slabs x WN column slabs; the input goes
 // through LDS in slabs of SH 16-channel groups (<= 78 KB: two blocks per CU), weights stream from L2 (bfo_mma).
 // =====================================================================================================================
-template <int K, int WM, int WN>
+template <int K, int WM, int WN, int NT_>
 struct BfoConvGeo {
-    static constexpr int NT = 8;
+    static constexpr int NT = NT_;                           // 32-column tiles per wave: 8, or 2 for short sequences (FastPitch encoder)
     static constexpr int NCOLS = WN * NT * 32;
     static constexpr int SH = 8 / WN;                        // 16-channel groups per slab
     static constexpr int WS = NCOLS + (K - 1) * BFO_DMAX;
@@ -29,9 +29,9 @@ struct BfoConvGeo {
     static constexpr size_t LDS = (size_t)NE * 16;
 };
 
-template <int K, int WM, int WN>
+template <int K, int WM, int WN, int NT_, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
-    using G = BfoConvGeo<K, WM, WN>;
+    using G = BfoConvGeo<K, WM, WN, NT_>;
     constexpr int NT = G::NT, WS = G::WS, NXI = G::NXI, SH = G::SH;
     extern __shared__ __attribute__((aligned(16))) uint4 Xs[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +96,26 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
 
     // ---- epilogue: [+ residual] [+ running sum] [/ div], activation of the consumer, 8-byte stores from the C layout
     if (co0 >= p.Cout) return;
+    if constexpr (OUT_F32) {
+        // fp32 channel-first output (+ fp32 residual): 4 bytes per lane and register, two 128-byte row segments per store
+        const bfo_i4 yrs = bfo_rsrc(p.y_f32 + (int64_t)b * p.Cout * L, (unsigned)p.Cout * L * 4);
+        const bool has_res = p.res_f32 != nullptr;
+        const bfo_i4 rrs = bfo_rsrc(has_res ? p.res_f32 + (int64_t)b * p.Cout * L : p.y_f32, (unsigned)p.Cout * L * 4);
+        const float os = p.out_slope;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int q = q0 + cw + 32 * j;
+            const int vq = q < len ? q * 4 + 4 * kk * L * 4 : BFO_OOB;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = bfo_ld4f(rrs, has_res ? vq : BFO_OOB, (co0 + 8 * (r >> 2) + (r & 3)) * L * 4, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bfo_st4f(bfo_lrelu(acc[j][r] + rv[r], os), yrs, vq, (co0 + 8 * (r >> 2) + (r & 3)) * L * 4, 0);
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     int vo[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -135,29 +155,38 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
     }
 }
 
-template <int K, int WM, int WN>
+template <int K, int WM, int WN, int NT, bool OUT_F32>
 static int32_t bfo_launch_conv_cfg(const BfoConvParams& p, hipStream_t stream) {
-    using G = BfoConvGeo<K, WM, WN>;
+    using G = BfoConvGeo<K, WM, WN, NT>;
     static bool attr_set[16] = {};
     int dev_id = 0;
     TTS_CHECK_HIP(hipGetDevice(&dev_id));
     dev_id &= 15;
     if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_conv1d<K, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_conv1d<K, WM, WN, NT, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
         attr_set[dev_id] = true;
     }
     const int CoutP = (p.Cout + 31) & ~31;
     dim3 grid((p.Lin + G::NCOLS - 1) / G::NCOLS, (CoutP + 32 * WM - 1) / (32 * WM), p.batch);
-    hipLaunchKernelGGL((bfo_conv1d<K, WM, WN>), grid, dim3(256), G::LDS, stream, p);
+    hipLaunchKernelGGL((bfo_conv1d<K, WM, WN, NT, OUT_F32>), grid, dim3(256), G::LDS, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 template <int K>
 static int32_t bfo_launch_conv_k(const BfoConvParams& p, hipStream_t stream) {
-    if (p.Cout >= 128) return bfo_launch_conv_cfg<K, 4, 1>(p, stream);
-    if (p.Cout >= 64) return bfo_launch_conv_cfg<K, 2, 2>(p, stream);
-    return bfo_launch_conv_cfg<K, 1, 4>(p, stream);
+    // short sequences (FastPitch encoder: 64 tokens per utterance): 64-column tiles instead of 256
+    const bool narrow = p.Lin <= 96 && p.Cout >= 128;
+    if (p.y_f32) {
+        if (narrow) return bfo_launch_conv_cfg<K, 4, 1, 2, true>(p, stream);
+        if (p.Cout >= 128) return bfo_launch_conv_cfg<K, 4, 1, 8, true>(p, stream);
+        set_error("bfo conv: fp32 output is built for Cout >= 128 (got %d)", p.Cout);
+        return TTSAMD_EINVAL;
+    }
+    if (narrow) return bfo_launch_conv_cfg<K, 4, 1, 2, false>(p, stream);
+    if (p.Cout >= 128) return bfo_launch_conv_cfg<K, 4, 1, 8, false>(p, stream);
+    if (p.Cout >= 64) return bfo_launch_conv_cfg<K, 2, 2, 8, false>(p, stream);
+    return bfo_launch_conv_cfg<K, 1, 4, 8, false>(p, stream);
 }
 
 int32_t bfo_launch_conv(const BfoConvParams& p, hipStream_t stream) {
@@ -166,6 +195,7 @@ int32_t bfo_launch_conv(const BfoConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.dil >= 1 && p.dil <= BFO_DMAX, "bfo conv: dilation %d outside [1,%d]", p.dil, BFO_DMAX);
     TTS_REQUIRE((int64_t)std::max(p.Cin, p.Cout) * p.Lin * 2 < ((int64_t)1 << 31), "bfo conv: tensor too large for 32-bit offsets");
     TTS_REQUIRE(p.mode == 0 || p.sum_in != nullptr, "bfo conv: mode %d needs sum_in", p.mode);
+    TTS_REQUIRE(!p.y_f32 || (p.mode == 0 && p.res == nullptr), "bfo conv: fp32 output takes res_f32, mode 0");
     if (p.Lin <= 0) return 0;
     conv_log("bfo", p.K, p.Cin, p.Cout, p.Lin, p.batch, p.res != nullptr, p.mode, p.len_mul, p.lens != nullptr, 1);
     switch (p.K) {

@@ -5,17 +5,20 @@
 // Internals are channel-first [B][C][S]; the k=3 conv-FF (97 % of the FLOPs), qkv/o_net/proj
 // and predictor convs all run on the MFMA conv engine (conv_mfma.hip).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "kernels.hpp"
+#include "bfo.hpp"
 
 namespace ttsamd {
 
 struct PConv {
     int64_t w_off = 0, b_off = -1, w16_off = 0;
+    int64_t wo_off = -1;   // bf16 octet engine weights [Cin/16][K][2][CoutP][8] in the uint16 blob (the conv-FF convs; -1: not packed)
     int cin = 0, cout = 0, k = 0;
 };
 struct FftLayer {
@@ -82,7 +85,7 @@ struct Builder {
         return off;
     }
     // Conv1d weight [cout][cin][k] or Linear weight [cout][cin] (k = 1)
-    PConv conv(const std::string& base, int cin, int cout, int k, bool bias) {
+    PConv conv(const std::string& base, int cin, int cout, int k, bool bias, bool octet = false) {
         PConv c;
         c.cin = cin; c.cout = cout; c.k = k;
         const ttsamd_tensor* w = get(base + ".weight", (int64_t)cin * cout * k);
@@ -95,6 +98,13 @@ struct Builder {
             c.w16_off = (int64_t)blob16.size();
             blob16.resize(blob16.size() + 2 * nn);
             split_packed_bf16(blob.data() + c.w_off, nn, blob16.data() + c.w16_off);
+        }
+        if (octet && cin % 8 == 0 && cout % 32 == 0 && cout >= 128 && (k == 1 || k == 3 || k == 7 || k == 11)) {
+            // the conv-FF pair also runs on the bf16 octet engine (config 3): v_mfma_f32_32x32x16_bf16, bf16 intermediate
+            blob16.resize(align_up((int64_t)blob16.size(), 64));
+            c.wo_off = (int64_t)blob16.size();
+            blob16.resize(blob16.size() + (size_t)bfo_packed_conv_elems(cout, cin, k));
+            bfo_pack_conv_weight(w->data, cout, cin, k, blob16.data() + c.wo_off);
         }
         blob.resize(align_up((int64_t)blob.size(), 64));
         if (bias) c.b_off = raw(base + ".bias", cout);
@@ -111,8 +121,8 @@ static void build_fft(Builder& b, const std::string& prefix, int n_layers, int d
         l.o_net = b.conv(p + "dec_attn.o_net", n_head * d_head, d_model, 1, false);
         l.ln1_g = b.raw(p + "dec_attn.layer_norm.weight", d_model);
         l.ln1_b = b.raw(p + "dec_attn.layer_norm.bias", d_model);
-        l.ff0 = b.conv(p + "pos_ff.CoreNet.0", d_model, d_inner, k, true);
-        l.ff2 = b.conv(p + "pos_ff.CoreNet.2", d_inner, d_model, k, true);   // index 2: ReLU at 1 (transformer.py:59-65 with Dropout commented out -> Sequential index 2)
+        l.ff0 = b.conv(p + "pos_ff.CoreNet.0", d_model, d_inner, k, true, true);
+        l.ff2 = b.conv(p + "pos_ff.CoreNet.2", d_inner, d_model, k, true, true);   // index 2: ReLU at 1 (transformer.py:59-65 with Dropout commented out -> Sequential index 2)
         l.ln2_g = b.raw(p + "pos_ff.layer_norm.weight", d_model);
         l.ln2_b = b.raw(p + "pos_ff.layer_norm.bias", d_model);
         out.push_back(l);
@@ -259,13 +269,40 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
                        const int64_t* lens, int B, int S, const FftWs& w, hipStream_t s) {
     const int d = h->cfg.d_model;
     const float scale = 1.0f / std::sqrt((float)d_head);
+    const char* ffe = std::getenv("TTSAMD_BFO_FF");              // read per call: the tests and A/B runs flip it
+    const bool octet_ff = default_precision() == 1 && !(ffe && ffe[0] == '0') && d % 8 == 0;
     for (const FftLayer& l : layers) {
         TTS_TRY(run_conv(h, l.qkv, x, w.q, nullptr, B, S, nullptr, 0, s));
         TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s));
         TTS_TRY(run_conv(h, l.o_net, w.a, w.y, x, B, S, nullptr, 0, s));
         TTS_TRY(launch_layernorm_cf(w.y, w.y, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
+        if (octet_ff && l.ff0.wo_off >= 0 && l.ff2.wo_off >= 0) {
+            // config 3: Conv1d + ReLU -> Conv1d + residual (transformer.py:72-90) on the bf16 octet engine.  The LayerNorm output
+            // is packed to bf16 entries once, the 1536-channel intermediate crosses HBM as bf16 (ReLU = leaky-relu slope 0 applied
+            // by the producer), the second conv adds the fp32 residual and writes the fp32 stream the next LayerNorm reads.
+            // Both tensors live in the fp32-sized `hid` buffer: [B][d_inner/8][S][8] bf16, then [B][d/8][S][8] bf16.
+            void* hid_o = w.hid;
+            void* xo = (char*)w.hid + (int64_t)B * l.ff0.cout * S * 2;
+            TTS_TRY(bfo_launch_pack(w.y, B, d, S, 1.f, xo, s));
+            BfoConvParams cp;
+            std::memset(&cp, 0, sizeof(cp));
+            cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
+            cp.x = xo; cp.y = hid_o; cp.w = h->dev16 + l.ff0.wo_off; cp.bias = h->dev + l.ff0.b_off;
+            cp.Cin = l.ff0.cin; cp.Cout = l.ff0.cout; cp.K = l.ff0.k; cp.out_slope = 0.f;
+            prof_begin(s, 2.0 * l.ff0.cout * l.ff0.cin * l.ff0.k);
+            int32_t rc = bfo_launch_conv(cp, s);
+            prof_end(s);
+            TTS_TRY(rc);
+            cp.x = hid_o; cp.y = nullptr; cp.y_f32 = x; cp.res_f32 = w.y; cp.w = h->dev16 + l.ff2.wo_off; cp.bias = h->dev + l.ff2.b_off;
+            cp.Cin = l.ff2.cin; cp.Cout = l.ff2.cout; cp.K = l.ff2.k; cp.out_slope = 1.f;
+            prof_begin(s, 2.0 * l.ff2.cout * l.ff2.cin * l.ff2.k);
+            rc = bfo_launch_conv(cp, s);
+            prof_end(s);
+            TTS_TRY(rc);
+        } else {
         TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s));
         TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, nullptr, 0, s));
+        }
         TTS_TRY(launch_layernorm_cf(x, x, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
     }
     return 0;

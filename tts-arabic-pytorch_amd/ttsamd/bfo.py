@@ -50,13 +50,20 @@ def pack_weight(w, up=1, device='cuda'):
 
 
 def conv1d(x, wp, bias, cout, k, dilation=1, up=1, lens=None, len_mul=1, res=None, res_slope=1.0, sum_in=None, mode=0,
-           div=1.0, out_slope=1.0, y=None):
+           div=1.0, out_slope=1.0, y=None, f32_out=False, res_f32=None):
+    """f32_out: the result is an fp32 channel-first [B, cout, L] tensor (+ the fp32 channel-first residual res_f32)."""
     B, no, Ln, _ = x.shape
+    if f32_out:
+        yf = torch.zeros(B, cout, Ln, dtype=torch.float32, device=x.device) if y is None else y
+        L.check(L.load().ttsamd_bfo_conv1d(_ptr(x), _ptr(wp), _ptr(bias), None, None, _ptr(lens), len_mul, B, no * 8, cout, k,
+                                           dilation, up, Ln, 0, 1.0, 1.0, float(out_slope), None, _ptr(yf), _ptr(res_f32),
+                                           _stream()), 'bfo_conv1d')
+        return yf
     if y is None:
         y = torch.zeros(B, cout // 8, Ln * up, 8, dtype=torch.int16, device=x.device)
     L.check(L.load().ttsamd_bfo_conv1d(_ptr(x), _ptr(wp), _ptr(bias), _ptr(res), _ptr(sum_in), _ptr(lens), len_mul, B, no * 8,
                                        cout, k, dilation, up, Ln, mode, float(div), float(res_slope), float(out_slope),
-                                       _ptr(y), _stream()), 'bfo_conv1d')
+                                       _ptr(y), None, None, _stream()), 'bfo_conv1d')
     return y
 
 
