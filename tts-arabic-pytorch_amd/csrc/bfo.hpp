@@ -105,11 +105,31 @@ __device__ __forceinline__ int bfo_pk(float a, float b) {      // v_cvt_pk_bf16_
     const bfo_f2 v = {a, b};
     return __builtin_bit_cast(int, __builtin_convertvector(v, bfo_h2));
 }
-// leaky-relu for slopes in (0, 1] as max(v, v * slope) and its inverse (1 / slope >= 1) as min(a, a / slope): two VALU
-// operations instead of multiply + compare + select (the exchange and epilogue phases are VALU-bound next to a partner
-// wave that is issuing MFMAs)
-__device__ __forceinline__ float bfo_lrelu(float v, float slope) { return __builtin_fmaxf(v, v * slope); }
-__device__ __forceinline__ float bfo_unrelu(float a, float inv) { return __builtin_fminf(a, a * inv); }
+// leaky-relu for slopes in [0, 1] as max(v, v * slope) and its inverse (1 / slope >= 1) as min(a, a / slope): two VALU
+// operations instead of multiply + compare + select.  v_max / v_min are issued through inline asm: on a value that comes out of
+// an MFMA the compiler otherwise prepends a canonicalising v_max(v, v) to every one (the exchange and epilogue phases of the
+// fused pair are VALU-bound next to a partner wave that is issuing MFMAs).
+__device__ __forceinline__ float bfo_vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float bfo_vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float bfo_lrelu(float v, float slope) { return bfo_vmax(v, v * slope); }
+__device__ __forceinline__ float bfo_unrelu(float a, float inv) { return bfo_vmin(a, a * inv); }
+// four accumulator values -> activated, rounded bf16 entry half (8 bytes); `mask` = 0 zeroes it without a branch
+__device__ __forceinline__ bfo_i2 bfo_act4(float v0, float v1, float v2, float v3, float slope, int mask) {
+    const bfo_f2 a = {v0, v1}, b = {v2, v3};
+    const bfo_f2 sa = a * slope, sb = b * slope;                       // v_pk_mul_f32
+    bfo_i2 w;
+    w.x = bfo_pk(bfo_vmax(v0, sa.x), bfo_vmax(v1, sa.y)) & mask;
+    w.y = bfo_pk(bfo_vmax(v2, sb.x), bfo_vmax(v3, sb.y)) & mask;
+    return w;
+}
 
 // One conv over an LDS-resident window: acc[j] += sum_{h, tap} A(h, tap) x B(h, tap, column tile j).
 //   wrs / wv  : buffer resource of the packed weights and this lane's byte offset in it (kk * CoutP + row) * 16

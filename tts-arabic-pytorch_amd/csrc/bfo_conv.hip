@@ -145,11 +145,8 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
             const float r[4] = {bfo_lo(rv[g].x), bfo_hi(rv[g].x), bfo_lo(rv[g].y), bfo_hi(rv[g].y)};
             const float s[4] = {bfo_lo(sv[g].x), bfo_hi(sv[g].x), bfo_lo(sv[g].y), bfo_hi(sv[g].y)};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = bfo_lrelu((v[e] + bfo_unrelu(r[e], rinv) + s[e]) * sc, os);
-            bfo_i2 w;
-            w.x = bfo_pk(v[0], v[1]);
-            w.y = bfo_pk(v[2], v[3]);
-            bfo_st8(w, yrs, vo[j], so0 + g * L * 16, 0);
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] + bfo_unrelu(r[e], rinv) + s[e]) * sc;
+            bfo_st8(bfo_act4(v[0], v[1], v[2], v[3], os, -1), yrs, vo[j], so0 + g * L * 16, 0);
         }
         if (j & 1) __builtin_amdgcn_sched_barrier(0);       // two tiles' loads in flight, not all eight (128 registers)
     }
@@ -292,10 +289,8 @@ __global__ __launch_bounds__(256, 2) void bfo_convt(const BfoConvParams p) {
                 const int n = cg * (NT * 32) + 32 * j + l31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    int2 w;
-                    w.x = bfo_pk(bfo_lrelu(acc[c][j][4 * g], os), bfo_lrelu(acc[c][j][4 * g + 1], os));
-                    w.y = bfo_pk(bfo_lrelu(acc[c][j][4 * g + 2], os), bfo_lrelu(acc[c][j][4 * g + 3], os));
-                    *reinterpret_cast<int2*>(reinterpret_cast<char*>(Xs + ((4 * rt + g) * NQ + n) * (U + 1) + rho) + 8 * kk) = w;
+                    const bfo_i2 w = bfo_act4(acc[c][j][4 * g], acc[c][j][4 * g + 1], acc[c][j][4 * g + 2], acc[c][j][4 * g + 3], os, -1);
+                    *reinterpret_cast<bfo_i2*>(reinterpret_cast<char*>(Xs + ((4 * rt + g) * NQ + n) * (U + 1) + rho) + 8 * kk) = w;
                 }
             }
         }

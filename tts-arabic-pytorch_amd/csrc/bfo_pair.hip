@@ -27,19 +27,21 @@ template <int K, int C>
 struct BfoPairGeo {
     static constexpr int NO = C / 8, NH = C / 16;
     static constexpr int WM = C / 32, WN = 4 / WM;          // waves over rows / over columns
-    static constexpr int NT = 8;                            // 32-column tiles per wave
+    // 32-column tiles per wave.  k = 3 at C <= 64: 4 tiles (half the window, 3-4 blocks per CU): 152 -> 137 us at C = 64, 118 -> 111 at
+    // C = 32 with the deeper weight ring below; no change at C = 128 (tools/bfo_pair_bench, -DBFO_PAIR_NT3 / PH3 variants)
+    static constexpr int NT = (K == 3 && C <= 64) ? 4 : 8;
     static constexpr int NCOLS = WN * NT * 32;              // columns of phase A
     static constexpr int H = (K - 1) / 2;
     static constexpr int TS = NCOLS - (K - 1);              // outputs per block
     static constexpr int WS = NCOLS + (K - 1) * BFO_DMAX;   // LDS entries per octet row
     static constexpr int NE = NO * WS;                      // entries of the window
     static constexpr int NXI = (NE + 255) / 256;            // ... per thread
-    static constexpr int PH = K <= 3 ? 2 : 1;               // 16-channel groups the A ring runs ahead
+    static constexpr int PH = K <= 3 ? (C <= 64 ? 4 : 2) : 1;   // 16-channel groups the A ring runs ahead
     static constexpr size_t LDS = (size_t)NE * 16;
 };
 
 template <int K, int C>
-__global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams p) {
+__global__ __launch_bounds__(256, (BfoPairGeo<K, C>::NT <= 4 ? 3 : 2)) void bfo_resblock_pair(const BfoPairParams p) {
     using G = BfoPairGeo<K, C>;
     constexpr int NO = G::NO, NH = G::NH, WN = G::WN, NT = G::NT, H = G::H, TS = G::TS, WS = G::WS, NXI = G::NXI;
     extern __shared__ __attribute__((aligned(16))) uint4 Xs[];
@@ -133,13 +135,11 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
         for (int j = 0; j < NT; ++j) {
             const int col = cw + 32 * j;
             const int pos = q0 - H + col;
-            const bool live = pos >= 0 && pos < len;
+            const int live = (pos >= 0 && pos < len) ? -1 : 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                int2 w;
-                w.x = live ? bfo_pk(bfo_lrelu(acc[j][4 * g], ms), bfo_lrelu(acc[j][4 * g + 1], ms)) : 0;
-                w.y = live ? bfo_pk(bfo_lrelu(acc[j][4 * g + 2], ms), bfo_lrelu(acc[j][4 * g + 3], ms)) : 0;
-                *reinterpret_cast<int2*>(reinterpret_cast<char*>(Xs + (4 * wm + g) * WS + col) + 8 * kk) = w;
+                const bfo_i2 w = bfo_act4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3], ms, live);
+                *reinterpret_cast<bfo_i2*>(reinterpret_cast<char*>(Xs + (4 * wm + g) * WS + col) + 8 * kk) = w;
             }
         }
     }
@@ -185,22 +185,16 @@ __global__ __launch_bounds__(256, 2) void bfo_resblock_pair(const BfoPairParams 
             for (int g = 0; g < 4; ++g) {
                 const float v0 = (acc[j][4 * g] + bfo_lo(sv[g].x)) * sc, v1 = (acc[j][4 * g + 1] + bfo_hi(sv[g].x)) * sc;
                 const float v2 = (acc[j][4 * g + 2] + bfo_lo(sv[g].y)) * sc, v3 = (acc[j][4 * g + 3] + bfo_hi(sv[g].y)) * sc;
-                bfo_i2 w;
-                w.x = bfo_pk(bfo_lrelu(v0, os), bfo_lrelu(v1, os));
-                w.y = bfo_pk(bfo_lrelu(v2, os), bfo_lrelu(v3, os));
-                bfo_st8(w, yrs, vo[j], (4 * wm + g) * L * 16, 0);
+                bfo_st8(bfo_act4(v0, v1, v2, v3, os, -1), yrs, vo[j], (4 * wm + g) * L * 16, 0);
             }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bfo_i2 w;
-                w.x = bfo_pk(bfo_lrelu(acc[j][4 * g], os), bfo_lrelu(acc[j][4 * g + 1], os));
-                w.y = bfo_pk(bfo_lrelu(acc[j][4 * g + 2], os), bfo_lrelu(acc[j][4 * g + 3], os));
-                bfo_st8(w, yrs, vo[j], (4 * wm + g) * L * 16, 0);
-            }
+            for (int g = 0; g < 4; ++g)
+                bfo_st8(bfo_act4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3], os, -1), yrs, vo[j],
+                        (4 * wm + g) * L * 16, 0);
     }
 #ifdef BFO_TIMING
     tst[5] = clock64();
