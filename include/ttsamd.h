@@ -87,6 +87,8 @@ typedef struct ttsamd_tacotron2_cfg {
     int32_t postnet_kernel_size;            /* 5 */
     int32_t postnet_embedding_dim;          /* 512 */
     float gate_threshold;                   /* 0.5 */
+    int32_t decoder_early_stopping;         /* 1: stop once every utterance's gate fired; 0: always decode max_step frames
+                                             *    (tacotron2_ms.py:139,169,197 -> torchaudio _Decoder.infer) */
 } ttsamd_tacotron2_cfg;
 
 /* models/diacritizers/shakkelha/network.py:10-27, shakkala/network.py:9-24 as one tagger geometry */

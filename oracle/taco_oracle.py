@@ -128,7 +128,7 @@ def tacotron2_infer(w, cfg, tokens, speaker_ids=None, lengths=None, max_step=Non
             trace.setdefault('prenet', []).append(p.clone())
         mel_lens[~finished] += 1
         finished |= torch.sigmoid(gate.squeeze(1)) > cfg['gate_threshold']
-        if bool(torch.all(finished)):
+        if cfg.get('decoder_early_stopping', True) and bool(torch.all(finished)):
             break
         dec_in = mel
     mel = torch.stack(mels, dim=2)                              # [B, 80, T]

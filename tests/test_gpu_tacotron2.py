@@ -335,3 +335,23 @@ def test_tacotron2_persistent_explicit_request_raises_when_it_does_not_fit(dev, 
     monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '0')
     mel_g, _, _ = eng.infer(tok, sids, lens, max_step=4, dropout_seed=-1)
     assert mel_lens.cpu().tolist() == [4] * 9 and maxabs(mel, mel_g) == 0.0
+
+
+@pytest.mark.parametrize('mode', ['0', '2'])
+def test_tacotron2_without_early_stopping(dev, monkeypatch, mode):
+    """decoder_early_stopping=False (tacotron2_ms.py:139,169,197): the loop runs to max_step although every utterance's gate fired;
+    the output has max_step frames, the per-utterance lengths are still the stop steps.  Graph path and persistent decoder vs the oracle."""
+    import taco_oracle as T
+    from ttsamd.engine import Tacotron2Engine
+    cfg, sd = _weights(gate_bias=-20.0)
+    tok, lens = _tokens(3, 15, 21)
+    sids = torch.tensor([1, 5, 9])
+    stops = [6, 11, 4]
+    sd = _gate_for_stops(cfg, sd, tok, sids, lens, stops, max_step=20, seed=3)
+    cfg = dict(cfg, decoder_early_stopping=False)
+    mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=20, seed=3)
+    assert mel_ref.shape[2] == 20 and np.asarray(lens_ref).tolist() == stops
+    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
+    mel, mel_lens, al = Tacotron2Engine(sd, cfg, device=dev).infer(tok, sids, lens, max_step=20, dropout_seed=3)
+    assert mel.shape == (3, 80, 20) and mel_lens.cpu().tolist() == stops
+    assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL

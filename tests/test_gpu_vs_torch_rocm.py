@@ -1,11 +1,13 @@
-"""Opt-in measurement (TTSAMD_TORCH_GPU_BASELINE=1): the reference's algorithm executed by PyTorch-ROCm
+"""Measurement: the reference's algorithm executed by PyTorch-ROCm
 (MIOpen / rocBLAS) on the same MI355X, next to the HIP path, on the bench.py workload (32 utterances x 64
 tokens, fp32, forced durations).  The torch side is oracle/tts_oracle.py (the restatement of the reference
 pinned by tests/test_oracle_golden.py) with its tensors on the GPU; /root/reference itself does not exist on
 the GPU box.  Two variants: the reference's own plumbing (batched FastPitch, vocoder looped per utterance,
 models/fastpitch/networks.py:340-345) and a batched vocoder call on the padded mel, which is what a user
-tuning the reference for throughput would do.  Skipped by default because MIOpen compiles its kernels on
-first use on a fresh box (minutes).  Result goes to gpurun_out/torch_rocm_baseline.json."""
+tuning the reference for throughput would do.  The COMPARISON always runs (same waves on both sides, timings printed and
+written to gpurun_out/torch_rocm_baseline.json: tests/test_gpu_fullsize.py, which runs before this file, has already paid
+MIOpen's first-use kernel compilation); the timing ASSERTION and the MIOpen find-mode variant stay opt-in
+(TTSAMD_TORCH_GPU_BASELINE=1): a shared box must not fail the suite on a noisy clock."""
 import json
 import os
 import time
@@ -17,7 +19,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(os.environ.get('TTSAMD_TORCH_GPU_BASELINE') != '1', reason='opt-in: TTSAMD_TORCH_GPU_BASELINE=1')
 def test_hip_path_beats_pytorch_rocm_on_the_same_gpu(synth_weights):
     import tts_oracle as O
     from ttsamd import synth
@@ -59,7 +60,8 @@ def test_hip_path_beats_pytorch_rocm_on_the_same_gpu(synth_weights):
             mel, dl, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids_np, dur_tgt=dur)
             return O.hifigan_forward(hw, mel, HIFIGAN_CONFIG), dl
 
-        for bench_mode in (False, True):
+        strict = os.environ.get('TTSAMD_TORCH_GPU_BASELINE') == '1'
+        for bench_mode in ((False, True) if strict else (False,)):
             torch.backends.cudnn.benchmark = bench_mode          # MIOpen find mode on / off
             tag = 'find' if bench_mode else 'default'
             t0 = time.perf_counter()
@@ -80,4 +82,5 @@ def test_hip_path_beats_pytorch_rocm_on_the_same_gpu(synth_weights):
     with open('gpurun_out/torch_rocm_baseline.json', 'w') as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res))
-    assert res['speedup_vs_best_torch_rocm'] > 1.0
+    if os.environ.get('TTSAMD_TORCH_GPU_BASELINE') == '1':
+        assert res['speedup_vs_best_torch_rocm'] > 1.0

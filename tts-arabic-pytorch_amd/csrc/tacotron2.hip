@@ -703,6 +703,7 @@ struct TacoPersist {
     int B, L, KS, Tcap, max_step, n_mels;
     float thr;
     long long seed;
+    int early_stop;             // 0: keep decoding to max_step after every utterance finished (decoder_early_stopping=False)
 };
 
 // One REGION of the exchange arena per decoder step.  Everything step s produces goes to region s + 1 (region 0 = the zero
@@ -1029,7 +1030,8 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 for (int n = 0; n < 4; ++n) xp[n] = xq[n];
                 fv = fn;
             }
-            if (__syncthreads_or(all_fin)) { steps = s; break; }          // (every wave sees the same flags once they are valid)
+            const int every_fin = __syncthreads_or(all_fin);              // (every wave sees the same flags once they are valid)
+            if (every_fin && p.early_stop) { steps = s; break; }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * n) * 64 + lane]);
@@ -1708,7 +1710,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         {
             int all = 1;
             for (int b = 0; b < B; ++b) all &= __builtin_bit_cast(int, cur[R_FIN + b]) != 0;
-            if (all) { steps = s + 1; break; }
+            if (all && p.early_stop) { steps = s + 1; break; }
         }
         // ---------------- S7: prenet layer 2, units 4 bid .. 4 bid + 3 on blocks 0..63 (input of the next step's attention cell)
         if (bid < 64) {
@@ -1938,7 +1940,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             q.xch = w.xch; q.tail_o = w.tail_o; q.step_floats = w.step_floats; q.Lp = w.Lp; q.PTp = w.PTp;
             q.mel_out = mel_raw; q.align_out = alignments; q.mel_lens = mel_lens;
             q.B = B; q.L = L; q.KS = KS; q.Tcap = Tcap; q.max_step = max_step; q.n_mels = c.n_mels;
-            q.thr = c.gate_threshold; q.seed = (long long)dropout_seed;
+            q.thr = c.gate_threshold; q.seed = (long long)dropout_seed; q.early_stop = c.decoder_early_stopping != 0;
             const bool flow = taco_persistent_mode() == 2;
             const void* fn = flow ? (M == 512 ? (const void*)taco_decoder_persistent<512, true> : (const void*)taco_decoder_persistent<640, true>)
                                   : (M == 512 ? (const void*)taco_decoder_persistent<512, false> : (const void*)taco_decoder_persistent<640, false>);
@@ -2070,7 +2072,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             run_err = hipEventSynchronize(h->ev[old]);
             bool all = true;
             for (int b = 0; b < B; ++b) all = all && h->pinned[(size_t)old * B + b];
-            if (all) break;
+            if (all && c.decoder_early_stopping != 0) break;
         }
     }
     const double t_loop1 = now_us();
@@ -2089,7 +2091,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     TTS_CHECK_HIP(hipStreamSynchronize(s));
     int T = 0;
     for (int b = 0; b < B; ++b) T = std::max(T, (int)lens_h[b]);
-    T = std::min(T, steps);
+    T = c.decoder_early_stopping != 0 ? std::min(T, steps) : steps;   // without early stopping the reference returns every step it ran
     *n_steps_out = T;
     // ---- postnet on [B][80][T] (row stride Tcap), residual fused into the last conv
     const float* px = mel_raw;

@@ -29,8 +29,6 @@ class Tacotron2MS(_HipModule):
         super().__init__()
         if n_frames_per_step != 1:
             raise ValueError('Only n_frames_per_step=1 is supported')
-        if not decoder_early_stopping:
-            raise NotImplementedError('decoder_early_stopping=False is not built')
         self.mask_padding, self.n_mels, self.n_frames_per_step = mask_padding, n_mels, n_frames_per_step
         self.taco_config = dict(TACOTRON2_CONFIG)
         self.taco_config.update(
@@ -41,7 +39,8 @@ class Tacotron2MS(_HipModule):
             attention_hidden_dim=attention_hidden_dim, attention_location_n_filter=attention_location_n_filter,
             attention_location_kernel_size=attention_location_kernel_size, prenet_dim=prenet_dim,
             postnet_n_convolution=postnet_n_convolution, postnet_kernel_size=postnet_kernel_size,
-            postnet_embedding_dim=postnet_embedding_dim, gate_threshold=gate_threshold)
+            postnet_embedding_dim=postnet_embedding_dim, gate_threshold=gate_threshold,
+            decoder_early_stopping=bool(decoder_early_stopping))
         self.decoder_max_step = decoder_max_step
         self.dropout_seed: Optional[int] = None
         self._sd = None

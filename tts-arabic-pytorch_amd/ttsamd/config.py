@@ -52,7 +52,7 @@ TACOTRON2_CONFIG = {
     'encoder_kernel_size': 5, 'decoder_rnn_dim': 1024, 'decoder_max_step': 3000,
     'attention_rnn_dim': 1024, 'attention_hidden_dim': 128, 'attention_location_n_filter': 32,
     'attention_location_kernel_size': 31, 'prenet_dim': 256, 'postnet_n_convolution': 5,
-    'postnet_kernel_size': 5, 'postnet_embedding_dim': 512, 'gate_threshold': 0.5,
+    'postnet_kernel_size': 5, 'postnet_embedding_dim': 512, 'gate_threshold': 0.5, 'decoder_early_stopping': True,
 }
 
 SAMPLE_RATE = 22050

@@ -312,7 +312,7 @@ class Tacotron2Engine:
         self.config = c
         cfg = L.Tacotron2Cfg()
         for name, _ in L.Tacotron2Cfg._fields_:
-            setattr(cfg, name, c[name])
+            setattr(cfg, name, int(bool(c.get(name, True))) if name == 'decoder_early_stopping' else c[name])
         arr, keep = L.make_tensors(state_dict)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):

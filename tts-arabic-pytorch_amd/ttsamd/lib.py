@@ -39,7 +39,7 @@ class Tacotron2Cfg(C.Structure):
         'encoder_n_convolution', 'encoder_kernel_size', 'n_mels', 'prenet_dim', 'attention_rnn_dim',
         'decoder_rnn_dim', 'attention_hidden_dim', 'attention_location_n_filter',
         'attention_location_kernel_size', 'postnet_n_convolution', 'postnet_kernel_size',
-        'postnet_embedding_dim')] + [('gate_threshold', C.c_float)]
+        'postnet_embedding_dim')] + [('gate_threshold', C.c_float), ('decoder_early_stopping', C.c_int32)]
 
 
 class TaggerCfg(C.Structure):
