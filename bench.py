@@ -114,7 +114,7 @@ def _self_launch(args):
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
         env = dict(base_env, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
-                   TTSAMD_BENCH_ATTEMPT=str(n), **extra)
+                   TTSAMD_BENCH_ATTEMPT=str(n), TTSAMD_BENCH_WORKER='1', **extra)
         procs = []
         for r in range(args.gpus):
             e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -165,6 +165,77 @@ def _self_launch(args):
     sys.exit(0)
 
 
+def _supervise_rank(args, rank, world):
+    """A rank started by an EXTERNAL launcher (`python -m torch.distributed.run ... bench.py --gpus N`, what the driver uses)
+    gets the same protection as the self-launched case: this process never touches the GPU; it runs the real rank as a child
+    process and watches it.  If the child stalls past the budget, dies, or ANY rank's supervisor on the node reports a failure
+    (a flag file keyed by the launcher's MASTER_PORT: one dead rank leaves its peers inside an unmatched collective), every
+    supervisor kills its child and starts a FRESH one with TTSAMD_DP_TRANSPORT=torch on a rendezvous of its own (rank 0's child
+    hosts a new TCPStore on MASTER_PORT + 1 + attempt: the launcher's store still holds the first attempt's keys).  The launcher
+    itself only ever sees the supervisors, which exit non-zero only when the second attempt failed too."""
+    import subprocess
+    import tempfile
+    import threading
+    port0 = int(os.environ.get('MASTER_PORT', '29500'))
+    budget = float(os.environ.get('TTSAMD_BENCH_WATCHDOG_S', 300.0 + 2.0 * (args.steps + args.warmup)))
+    why = None
+    for attempt in (0, 1):
+        flag = os.path.join(tempfile.gettempdir(), f'ttsamd_bench_{port0}_attempt{attempt}_failed')
+        if rank == 0 and os.path.exists(flag):
+            os.remove(flag)                                      # a stale flag of an earlier run on the same port
+        env = dict(os.environ, TTSAMD_BENCH_WORKER='1', TTSAMD_BENCH_ATTEMPT=str(attempt),
+                   TTSAMD_BENCH_INIT_TIMEOUT_S=str(int(budget) + 120))
+        if attempt == 1:
+            env.update(TTSAMD_DP_TRANSPORT='torch', MASTER_PORT=str(port0 + 2), TORCHELASTIC_USE_AGENT_STORE='False',
+                       TTSAMD_BENCH_FALLBACK_REASON=why or 'first attempt failed')
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                 stdout=subprocess.PIPE if rank == 0 else None)
+        lines = []
+
+        def pump(stream=child.stdout):
+            for ln in iter(stream.readline, b''):
+                lines.append(ln.decode())
+        th = None
+        if rank == 0:
+            th = threading.Thread(target=pump, daemon=True)
+            th.start()
+        deadline, why, t_line = time.monotonic() + budget, None, None
+        while child.poll() is None:
+            time.sleep(0.5)
+            if rank == 0 and t_line is None and any(ln.startswith('{') for ln in lines):
+                t_line = time.monotonic()                        # the line is out: only teardown is left
+            if t_line is not None and time.monotonic() - t_line > 60:
+                break                                            # hung in teardown after a complete result: keep the result
+            if os.path.exists(flag):
+                why = 'another rank reported a failure'
+                break
+            if time.monotonic() > deadline:
+                why = f'no result within the watchdog budget of {budget:.0f} s'
+                break
+        if child.poll() is None:
+            child.kill()
+        rc = child.wait()
+        if th is not None:
+            th.join(timeout=5)
+        got = [ln for ln in lines if ln.startswith('{')]
+        ok = (why is None and rc == 0) or (rank == 0 and got and why is None)
+        if why is None and not ok:
+            why = f'rank {rank} exited with {rc}'
+        if not ok:
+            try:
+                open(flag, 'w').close()                          # tell the other supervisors
+            except OSError:
+                pass
+            print(f'bench.py supervisor of rank {rank}: {why}' + ('; restarting on TTSAMD_DP_TRANSPORT=torch' if attempt == 0 else ''),
+                  file=sys.stderr)
+            continue
+        for ln in lines:
+            print(ln, end='', file=sys.stdout if ln.startswith('{') else sys.stderr)
+        sys.stdout.flush()
+        sys.exit(0)
+    sys.exit(1)
+
+
 def _time_steps(step, steps, sync, barrier=None):
     """K steps bracketed by barrier + synchronize on both sides -> seconds."""
     if barrier:
@@ -207,6 +278,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world == 1:
         _self_launch(args)                      # never returns
+    if world > 1 and os.environ.get('TTSAMD_BENCH_WORKER') != '1':
+        _supervise_rank(args, rank, world)      # never returns: ranks of an external launcher watch their own worker
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
     # TTSAMD_BENCH_ONE_DEVICE=1 (set by _self_launch on a box with fewer GPUs than ranks): all ranks share GPU 0
     # and exchange over gloo with host staging — exercises the N>1 code path on a 1-GPU box; the real
@@ -233,13 +306,15 @@ def main():
                 time.sleep(3600)                    # a rank that never arrives
             if os.environ.get('TTSAMD_BENCH_TEST_DIE') == f'{rank}':
                 os._exit(5)                         # a rank that dies before the rendezvous
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get('TTSAMD_BENCH_INIT_TIMEOUT_S', '600')))
         if one_dev or transport == 'rccl':
             # rendezvous, barriers and the few host-side reductions over gloo: with the ttsamd_dp_* transport a rank then
             # holds exactly ONE RCCL communicator (the library's), created right below, not a second one next to torch's
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=pg_timeout)
             red_dev = torch.device('cpu')
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         if transport == 'rccl':
             # every rank probes the C-ABI RCCL binding (dlopen + id) BEFORE the first collective; if any rank cannot,
             # ALL ranks leave (exit code 3) and the parent's watchdog restarts them on the torch.distributed transport

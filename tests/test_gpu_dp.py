@@ -186,6 +186,30 @@ def test_bench_watchdog_restarts_stalled_or_dead_ranks(fault):
     assert time.time() - t0 < 400
 
 
+@pytest.mark.parametrize('fault', [None, 'TTSAMD_BENCH_TEST_STALL', 'TTSAMD_BENCH_TEST_DIE'])
+def test_bench_under_torch_distributed_run(fault):
+    """What the driver types for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`.
+    Every rank the launcher starts is a supervisor that runs the real rank as a child process (bench.py::_supervise_rank): with no
+    fault ONE json line comes out; with a stalled or a dead rank the supervisors agree through a flag file, kill their children
+    and restart them once on the torch transport with a rendezvous of their own -- the launcher never sees a failure."""
+    env = dict(os.environ, TTSAMD_BENCH_WATCHDOG_S='60')
+    if fault:
+        env[fault] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '4', '--tokens', '16']
+    p = subprocess.run(cmd, capture_output=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0
+    if fault:
+        assert out['config']['dp_fallback_reason'] and b'restarting on TTSAMD_DP_TRANSPORT=torch' in p.stderr
+    else:
+        assert out['config']['dp_fallback_reason'] is None
+
+
 def _sharded_worker(rank, world, port, tmpdir):
     for p in (os.path.join(REPO, 'tts-arabic-pytorch_amd'), os.path.join(REPO, 'tests')):
         if p not in sys.path:
