@@ -68,7 +68,8 @@ def _pair_ref(a, w1, b1, w2, b2, k, dil, n, sum_raw, mode, div, in_slope, out_sl
     (64, 3, 5, 1100, 2, 0.1), (64, 7, 1, 600, 0, 0.1), (64, 11, 3, 1000, 1, 1.0),
     (32, 3, 3, 2100, 1, 1.0), (32, 7, 5, 1030, 2, 0.01), (32, 11, 1, 2500, 0, 0.1),
 ])
-def test_resblock_pair(dev, C, k, dil, L, mode, out_slope):
+@pytest.mark.parametrize('small_tiles', ['0', '1'])
+def test_resblock_pair(dev, monkeypatch, C, k, dil, L, mode, out_slope, small_tiles):
     """Fused c1 -> c2 pair vs the reference ops; ragged batch incl. an utterance ending inside a tile halo, one ending
     before the first tile boundary, and the untouched tail past each length."""
     from ttsamd import bfo
@@ -79,7 +80,10 @@ def test_resblock_pair(dev, C, k, dil, L, mode, out_slope):
     w2 = torch.randn(C, C, k, generator=g) / np.sqrt(C * k)
     b1, b2 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
     s_raw = torch.randn(B, C, L, generator=g)
-    ts = {128: 256, 64: 512, 32: 1024}[C] // (2 if (k == 3 and C <= 64) else 1) - (k - 1)     # outputs per block (BfoPairGeo::TS)
+    # both tile widths of the kernel: 256 columns per wave, or 128 (always for k = 3 at C <= 64; for small grids otherwise)
+    monkeypatch.setenv('TTSAMD_BFO_SMALL_TILES', small_tiles)
+    half = small_tiles == '1' or (k == 3 and C <= 64)
+    ts = {128: 256, 64: 512, 32: 1024}[C] // (2 if half else 1) - (k - 1)                     # outputs per block (BfoPairGeo::TS)
     lens = torch.tensor([L, min(L, ts + 2), max(1, min(L, ts) - 5)], dtype=torch.int64)     # ends 2 columns into tile 1 / inside tile 0
     xo = bfo.pack(x.to(dev), 0.1)
     so = bfo.pack(s_raw.to(dev), 1.0)

@@ -39,8 +39,9 @@ int main(int argc, char** argv) {
         BfoPairParams p; memset(&p, 0, sizeof p);
         p.x = x; p.y = y; p.w1 = w1; p.w2 = w2; p.b1 = b; p.b2 = b; p.len_mul = 1; p.L = s.L; p.dil = s.dil; p.batch = s.B;
         p.mode = 0; p.div = 1.f; p.in_slope = 0.1f; p.mid_slope = 0.1f; p.out_slope = 0.1f;
-        const int nt_ = (s.k == 3 && s.C <= 64) ? 4 : 8;
-        const int ts = (s.C == 128 ? 1 : s.C == 64 ? 2 : 4) * nt_ * 32 - (s.k - 1);
+        const int ts8 = (s.C == 128 ? 1 : s.C == 64 ? 2 : 4) * 256 - (s.k - 1);
+        const bool small_ = (s.k == 3 && s.C <= 64) || (size_t)((s.L + ts8 - 1) / ts8) * s.B < 384;
+        const int ts = (s.C == 128 ? 1 : s.C == 64 ? 2 : 4) * (small_ ? 128 : 256) - (s.k - 1);
         const size_t nblk = (size_t)((s.L + ts - 1) / ts) * s.B;
 #ifdef BFO_TIMING
         unsigned long long* tim; hipMalloc(&tim, nblk * 128); hipMemset(tim, 0, nblk * 128); p.timing = tim;

@@ -17,19 +17,24 @@
 //   epilogue [+ running ResBlock sum] [/ n_kernels], leaky-relu of the CONSUMER, bf16, 8-byte stores from the C layout
 //            (512 contiguous bytes per wave instruction).
 // LDS <= 78 KB -> two blocks per CU: one block's loads / exchange / stores run under the other's MFMAs.
+#include <cstdlib>
 #include <cstring>
 
 #include "bfo.hpp"
 
 namespace ttsamd {
 
+// 32-column tiles per wave: 8 (256 columns), or 4 -- half the window, 3-4 blocks per CU -- for k = 3 at C <= 64 (152 -> 137 us at
+// C = 64, 118 -> 111 at C = 32 with the deeper weight ring below; no change at C = 128: tools/bfo_pair_bench) and for small
+// batches, where 256-column tiles leave CUs without a block (batch 1: 115 blocks at C = 128)
 template <int K, int C>
+constexpr int bfo_pair_default_nt() { return (K == 3 && C <= 64) ? 4 : 8; }
+
+template <int K, int C, int NT_>
 struct BfoPairGeo {
     static constexpr int NO = C / 8, NH = C / 16;
     static constexpr int WM = C / 32, WN = 4 / WM;          // waves over rows / over columns
-    // 32-column tiles per wave.  k = 3 at C <= 64: 4 tiles (half the window, 3-4 blocks per CU): 152 -> 137 us at C = 64, 118 -> 111 at
-    // C = 32 with the deeper weight ring below; no change at C = 128 (tools/bfo_pair_bench, -DBFO_PAIR_NT3 / PH3 variants)
-    static constexpr int NT = (K == 3 && C <= 64) ? 4 : 8;
+    static constexpr int NT = NT_;
     static constexpr int NCOLS = WN * NT * 32;              // columns of phase A
     static constexpr int H = (K - 1) / 2;
     static constexpr int TS = NCOLS - (K - 1);              // outputs per block
@@ -40,9 +45,9 @@ struct BfoPairGeo {
     static constexpr size_t LDS = (size_t)NE * 16;
 };
 
-template <int K, int C>
-__global__ __launch_bounds__(256, (BfoPairGeo<K, C>::NT <= 4 ? 3 : 2)) void bfo_resblock_pair(const BfoPairParams p) {
-    using G = BfoPairGeo<K, C>;
+template <int K, int C, int NT_>
+__global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(const BfoPairParams p) {
+    using G = BfoPairGeo<K, C, NT_>;
     constexpr int NO = G::NO, NH = G::NH, WN = G::WN, NT = G::NT, H = G::H, TS = G::TS, WS = G::WS, NXI = G::NXI;
     extern __shared__ __attribute__((aligned(16))) uint4 Xs[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -210,21 +215,35 @@ __global__ __launch_bounds__(256, (BfoPairGeo<K, C>::NT <= 4 ? 3 : 2)) void bfo_
 #undef BFO_PRIO
 }
 
-template <int K, int C>
-static int32_t bfo_launch_pair_k(const BfoPairParams& p, hipStream_t stream) {
-    using G = BfoPairGeo<K, C>;
+template <int K, int C, int NT>
+static int32_t bfo_launch_pair_nt(const BfoPairParams& p, hipStream_t stream) {
+    using G = BfoPairGeo<K, C, NT>;
     static bool attr_set[16] = {};
     int dev_id = 0;
     TTS_CHECK_HIP(hipGetDevice(&dev_id));
     dev_id &= 15;
     if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_resblock_pair<K, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_resblock_pair<K, C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
         attr_set[dev_id] = true;
     }
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
-    hipLaunchKernelGGL((bfo_resblock_pair<K, C>), grid, dim3(256), G::LDS, stream, p);
+    hipLaunchKernelGGL((bfo_resblock_pair<K, C, NT>), grid, dim3(256), G::LDS, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int K, int C>
+static int32_t bfo_launch_pair_k(const BfoPairParams& p, hipStream_t stream) {
+    constexpr int NT0 = bfo_pair_default_nt<K, C>();
+    if constexpr (NT0 == 8) {
+        // fewer than 1.5 blocks per CU with 256-column tiles: halve them (TTSAMD_BFO_SMALL_TILES=0/1 forces either)
+        using G8 = BfoPairGeo<K, C, 8>;
+        const int64_t blocks8 = (int64_t)((p.L + G8::TS - 1) / G8::TS) * p.batch;
+        const char* e = getenv("TTSAMD_BFO_SMALL_TILES");
+        const bool small = e ? e[0] == '1' : blocks8 < 384;
+        if (small) return bfo_launch_pair_nt<K, C, 4>(p, stream);
+    }
+    return bfo_launch_pair_nt<K, C, NT0>(p, stream);
 }
 
 bool bfo_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L) {
