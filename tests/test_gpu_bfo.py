@@ -219,3 +219,36 @@ def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T):
     err, err_old = float((wave - ref).abs().max()), float((wave_old - ref).abs().max())
     print(f'T={T}: octet engine wave max-abs {err:.2e}, round-2 bf16 engine {err_old:.2e}')
     assert err < 4e-2 and err_old < 4e-2
+
+
+def test_bf16_attention_matches_the_fp32_kernel(dev, synth_weights, monkeypatch):
+    """FastPitch under config 3 with the bf16 MFMA attention (32-query tiles, the four waves of a block split the keys) against
+    the same run with the fp32 attention kernel and against the exact-fp32 engine: ragged batch, sequence lengths that are not
+    multiples of the 32-key tiles (70 / 41 / 13 tokens -> ~490 / 290 / 90 frames), so key masking, partial tiles, empty key
+    ranges of a wave and the four-way combine are all on the path (transformer.py:131-141)."""
+    from ttsamd import synth
+    from ttsamd.engine import FastPitchEngine, set_precision
+    ids = synth.synth_ids(3, 70)
+    ids[1, 41:] = 0
+    ids[2, 13:] = 0
+    dur = synth.synth_durations(3, 70) * (ids != 0)
+    fp = FastPitchEngine(synth_weights['fastpitch'], device=dev)
+    mel32, lens32, *_ = fp.infer(ids, dur_tgt=dur)
+    set_precision('bf16')
+    try:
+        monkeypatch.setenv('TTSAMD_BF16_ATTN', '1')
+        mel_a, lens_a, *_ = fp.infer(ids, dur_tgt=dur)
+        monkeypatch.setenv('TTSAMD_BF16_ATTN', '0')
+        mel_b, lens_b, *_ = fp.infer(ids, dur_tgt=dur)
+    finally:
+        set_precision('f32')
+    assert torch.equal(lens_a, lens32) and torch.equal(lens_b, lens32)
+    worst_ab = worst_a = worst_b = 0.0
+    for i in range(3):
+        n = int(lens32[i])
+        worst_ab = max(worst_ab, float((mel_a[i, :, :n] - mel_b[i, :, :n]).abs().max()))
+        worst_a = max(worst_a, float((mel_a[i, :, :n] - mel32[i, :, :n]).abs().max()))
+        worst_b = max(worst_b, float((mel_b[i, :, :n] - mel32[i, :, :n]).abs().max()))
+    print(f'bf16 attention vs fp32 attention (both under bf16 GEMMs): {worst_ab:.2e}; vs the fp32 engine: {worst_a:.2e} (fp32 attention: {worst_b:.2e})')
+    assert bool(torch.isfinite(mel_a).all())
+    assert worst_a < 6e-2 and worst_ab < 4e-2

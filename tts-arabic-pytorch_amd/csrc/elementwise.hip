@@ -2,6 +2,8 @@
 // [B][C][T] so that consecutive lanes touch consecutive time steps (coalesced, 64-wide waves).
 #include <cstdint>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace ttsamd {
@@ -396,6 +398,10 @@ int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32
                          float* out, hipStream_t s) {
     TTS_REQUIRE(D == ATT_D, "attention: d_head=%d, only %d is built", D, ATT_D);
     if (S <= 0 || B <= 0) return 0;
+    if (default_precision() == 1) {                              // config 3: bf16 MFMA attention (TTSAMD_BF16_ATTN=0: the fp32 kernel)
+        const char* e = getenv("TTSAMD_BF16_ATTN");
+        if (!(e && e[0] == '0')) return launch_attention_bf16(qkv, lens, B, D, S, scale, out, s);
+    }
     if ((int64_t)((S + 63) / 64) * B >= 1024) {
         dim3 grid((S + 63) / 64, B);
         hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, qkv, lens, S, scale, out);

@@ -30,6 +30,10 @@ int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos
 int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S,
                          float scale, float* out, hipStream_t s);
 
+// the same on the bf16 matrix cores (attention_bf16.hip; config 3): launch_attention routes here under ttsamd_set_precision(1)
+int32_t launch_attention_bf16(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S, float scale, float* out,
+                              hipStream_t s);
+
 // Predictor head (model.py:132): out[b][t] = (bias + sum_c w[c]*x[b][c][t]) * (t < lens[b]);
 // mode 1 additionally writes dur = clamp(exp(out)-1, 0, max_dur) (model.py:368) to out2.
 int32_t launch_pred_fc(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t B,
