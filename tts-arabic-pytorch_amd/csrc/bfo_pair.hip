@@ -60,10 +60,6 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
     int len = L;
     if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
     if (q0 >= len) return;
-#ifndef BFO_PRIO_VALU
-#define BFO_PRIO_VALU 2
-#endif
-#define BFO_PRIO(n) __builtin_amdgcn_s_setprio(n);
 #ifdef BFO_TIMING
     const unsigned long long wc0 = wall_clock64();
     unsigned long long tst[12];
@@ -117,7 +113,6 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
     bfo_mma<K, G::PH, NT>(acc, bfo_rsrc(p.w1, (unsigned)NH * K * 2 * C * 16), wv, 2 * C * 16, sB, NH, 2 * WS, dil);
 
     BFO_STAMP(2)
-    BFO_PRIO(BFO_PRIO_VALU)                                 // the VALU-heavy phases outrank a partner wave's MFMA stream
     // residual (= the activated input at the output positions): 8 bytes per (tile, octet) in the C layout
     int vo[NT];
 #pragma unroll
@@ -170,11 +165,9 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
             }
     }
     BFO_STAMP(9)
-    BFO_PRIO(0)
     bfo_mma<K, G::PH, NT>(acc, bfo_rsrc(p.w2, (unsigned)NH * K * 2 * C * 16), wv, 2 * C * 16, sB, NH, 2 * WS, 1);
 
     BFO_STAMP(4)
-    BFO_PRIO(BFO_PRIO_VALU)
     // ---- epilogue
     const bfo_i4 yrs = bfo_rsrc((char*)p.y + (int64_t)b * NO * L * 16, (unsigned)NO * L * 16);
     const float os = p.out_slope;
@@ -212,7 +205,6 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
     }
 #endif
 #undef BFO_STAMP
-#undef BFO_PRIO
 }
 
 template <int K, int C, int NT>
