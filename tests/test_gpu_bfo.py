@@ -221,9 +221,10 @@ def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T):
     assert err < 4e-2 and err_old < 4e-2
 
 
-def test_bf16_attention_matches_the_fp32_kernel(dev, synth_weights, monkeypatch):
-    """FastPitch under config 3 with the bf16 MFMA attention (32-query tiles, the four waves of a block split the keys) against
-    the same run with the fp32 attention kernel and against the exact-fp32 engine: ragged batch, sequence lengths that are not
+def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch):
+    """FastPitch under config 3 with the whole FFT block on the bf16 matrix cores (octet-engine qkv / o_net / conv-FF convs, LayerNorm
+    that writes the octet copies, bf16 MFMA attention: 32-query tiles, the four waves of a block split the keys) against the same run
+    on the round-2 bf16 conv engine with the fp32 attention kernel, and against the exact-fp32 engine: ragged batch, sequence lengths that are not
     multiples of the 32-key tiles (70 / 41 / 13 tokens -> ~490 / 290 / 90 frames), so key masking, partial tiles, empty key
     ranges of a wave and the four-way combine are all on the path (transformer.py:131-141)."""
     from ttsamd import synth
@@ -236,9 +237,11 @@ def test_bf16_attention_matches_the_fp32_kernel(dev, synth_weights, monkeypatch)
     mel32, lens32, *_ = fp.infer(ids, dur_tgt=dur)
     set_precision('bf16')
     try:
-        monkeypatch.setenv('TTSAMD_BF16_ATTN', '1')
+        monkeypatch.setenv('TTSAMD_BF16_ATTN', '1')                       # the whole FFT block on the bf16 matrix cores (the default)
+        monkeypatch.setenv('TTSAMD_BFO_FF', '1')
         mel_a, lens_a, *_ = fp.infer(ids, dur_tgt=dur)
-        monkeypatch.setenv('TTSAMD_BF16_ATTN', '0')
+        monkeypatch.setenv('TTSAMD_BF16_ATTN', '0')                       # round-2 bf16 conv engine + the fp32 attention kernel
+        monkeypatch.setenv('TTSAMD_BFO_FF', '0')
         mel_b, lens_b, *_ = fp.infer(ids, dur_tgt=dur)
     finally:
         set_precision('f32')

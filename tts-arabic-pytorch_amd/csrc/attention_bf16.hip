@@ -21,7 +21,7 @@ constexpr int ATB_D = 64;
 constexpr float ATB_NEG = -1.0e30f;      // "minus infinity" that survives exp() and subtraction without NaN
 
 __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lens, int S,
-                                                             float scale, float* __restrict__ out) {
+                                                             float scale, float* __restrict__ out, uint4* __restrict__ out_o) {
     __shared__ float Ml[4][2][32];                    // [wave][m | l][query]
     __shared__ float Os[4][ATB_D][33];                // [wave][d][query]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -134,6 +134,24 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
         Os[wid][32 + d][l31] = o1[r];
     }
     __syncthreads();
+    if (out_o) {
+        // octet bf16 output [B][8][S][8] for the o_net conv on the octet engine: thread = (octet, query) = one 16-byte entry
+        const int o = tid >> 5, q = tid & 31;
+        const float m0 = Ml[0][0][q], m1 = Ml[1][0][q], m2 = Ml[2][0][q], m3 = Ml[3][0][q];
+        const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float e0 = __expf(m0 - M), e1 = __expf(m1 - M), e2 = __expf(m2 - M), e3 = __expf(m3 - M);
+        const float inv = 1.f / (e0 * Ml[0][1][q] + e1 * Ml[1][1][q] + e2 * Ml[2][1][q] + e3 * Ml[3][1][q]);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = 8 * o + e;
+            v[e] = (e0 * Os[0][d][q] + e1 * Os[1][d][q] + e2 * Os[2][d][q] + e3 * Os[3][d][q]) * inv;
+        }
+        uint4 w;
+        w.x = (unsigned)bfo_pk(v[0], v[1]); w.y = (unsigned)bfo_pk(v[2], v[3]); w.z = (unsigned)bfo_pk(v[4], v[5]); w.w = (unsigned)bfo_pk(v[6], v[7]);
+        if (q0 + q < S) out_o[((int64_t)b * (ATB_D / 8) + o) * S + q0 + q] = w;
+        return;
+    }
     float* ob = out + (int64_t)b * ATB_D * S;
 #pragma unroll
     for (int i = 0; i < ATB_D * 32 / 256; ++i) {
@@ -149,12 +167,12 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
 }
 
 int32_t launch_attention_bf16(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S, float scale, float* out,
-                              hipStream_t s) {
+                              hipStream_t s, void* out_octet) {
     TTS_REQUIRE(D == ATB_D, "attention (bf16): d_head=%d, only %d is built", D, ATB_D);
     TTS_REQUIRE((int64_t)3 * ATB_D * S * 4 < ((int64_t)1 << 31), "attention (bf16): sequence too long for 32-bit offsets");
     if (S <= 0 || B <= 0) return 0;
     dim3 grid((S + 31) / 32, B);
-    hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
+    hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, s, qkv, lens, S, scale, out, (uint4*)out_octet);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "bfo.hpp"
+#include "kernels.hpp"
 
 namespace ttsamd {
 
@@ -372,6 +373,76 @@ __global__ __launch_bounds__(256) void bfo_unpack_kernel(const uint4* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e)
         if (8 * o + e < C) yr[(int64_t)e * L] = (inv_slope >= 1.f ? bfo_unrelu(v[e], inv_slope) : bfo_lrelu(v[e], inv_slope));
+}
+
+// LayerNorm over the channel axis of a channel-first fp32 tensor (transformer.py:88,158,174,176) that ALSO writes its result as
+// octet bf16 entries: the input copy of the conv that follows (FastPitch under config 3).  Block = 32 positions x 8 channel groups;
+// group g owns the CONTIGUOUS channels [g C/8, (g+1) C/8) = C/64 whole octets, so its entries are complete in one thread.
+constexpr int LNO_MAXV = 64;
+__global__ __launch_bounds__(256) void layernorm_cf_octet_kernel(const float* __restrict__ x, float* __restrict__ y, uint4* __restrict__ yo,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const int64_t* __restrict__ lens, int apply_mask, int C, int S, float eps) {
+    __shared__ float red[8][32];
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tl;
+    const bool ok = t < S;
+    const int cpg = C / 8, c0 = g * cpg;
+    const float* xb = x + ((int64_t)b * C + c0) * S + (ok ? t : 0);
+    float v[LNO_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNO_MAXV; ++i) {
+        v[i] = (i < cpg) ? xb[(int64_t)i * S] : 0.f;
+        sum += v[i];
+    }
+    red[g][tl] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][tl];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNO_MAXV; ++i) {
+        const float d = (i < cpg) ? v[i] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+    }
+    red[g][tl] = sq;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][tl];
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+    if (!ok) return;
+    float m = 1.f;
+    if (apply_mask && lens && t >= (int)lens[b]) m = 0.f;
+    float* yb = y + ((int64_t)b * C + c0) * S + t;
+#pragma unroll
+    for (int i = 0; i < LNO_MAXV; ++i)
+        if (i < cpg) {
+            v[i] = ((v[i] - mean) * rstd * gamma[c0 + i] + beta[c0 + i]) * m;
+            yb[(int64_t)i * S] = v[i];
+        }
+#pragma unroll
+    for (int o = 0; o < LNO_MAXV / 8; ++o)
+        if (8 * o < cpg) {
+            uint4 w;
+            w.x = (unsigned)bfo_pk(v[8 * o], v[8 * o + 1]); w.y = (unsigned)bfo_pk(v[8 * o + 2], v[8 * o + 3]);
+            w.z = (unsigned)bfo_pk(v[8 * o + 4], v[8 * o + 5]); w.w = (unsigned)bfo_pk(v[8 * o + 6], v[8 * o + 7]);
+            yo[((int64_t)b * (C / 8) + c0 / 8 + o) * S + t] = w;
+        }
+}
+
+int32_t launch_layernorm_cf_octet(const float* x, float* y, void* y_octet, const float* gamma, const float* beta,
+                                  const int64_t* lens, int32_t apply_mask, int32_t B, int32_t C, int32_t S, hipStream_t s, float eps) {
+    TTS_REQUIRE(C % 64 == 0 && C <= 8 * LNO_MAXV && y_octet, "layernorm (octet): C %% 64 must be 0 and C <= %d (C=%d)", 8 * LNO_MAXV, C);
+    if (S <= 0 || B <= 0) return 0;
+    dim3 grid((S + 31) / 32, B);
+    hipLaunchKernelGGL(layernorm_cf_octet_kernel, grid, dim3(256), 0, s, x, y, (uint4*)y_octet, gamma, beta, lens, apply_mask, C, S, eps);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int32_t bfo_launch_pack(const float* x, int32_t B, int32_t C, int32_t L, float slope, void* out, hipStream_t s) {

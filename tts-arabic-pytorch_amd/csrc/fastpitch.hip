@@ -117,8 +117,8 @@ static void build_fft(Builder& b, const std::string& prefix, int n_layers, int d
     for (int i = 0; i < n_layers && b.rc == 0; ++i) {
         const std::string p = prefix + ".layers." + std::to_string(i) + ".";
         FftLayer l;
-        l.qkv = b.conv(p + "dec_attn.qkv_net", d_model, 3 * n_head * d_head, 1, true);
-        l.o_net = b.conv(p + "dec_attn.o_net", n_head * d_head, d_model, 1, false);
+        l.qkv = b.conv(p + "dec_attn.qkv_net", d_model, 3 * n_head * d_head, 1, true, true);
+        l.o_net = b.conv(p + "dec_attn.o_net", n_head * d_head, d_model, 1, false, true);
         l.ln1_g = b.raw(p + "dec_attn.layer_norm.weight", d_model);
         l.ln1_b = b.raw(p + "dec_attn.layer_norm.bias", d_model);
         l.ff0 = b.conv(p + "pos_ff.CoreNet.0", d_model, d_inner, k, true, true);
@@ -270,39 +270,54 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
     const int d = h->cfg.d_model;
     const float scale = 1.0f / std::sqrt((float)d_head);
     const char* ffe = std::getenv("TTSAMD_BFO_FF");              // read per call: the tests and A/B runs flip it
-    const bool octet_ff = default_precision() == 1 && !(ffe && ffe[0] == '0') && d % 8 == 0;
+    bool octet = default_precision() == 1 && !(ffe && ffe[0] == '0') && d % 64 == 0 && d <= 512 && d_head == 64;
+    for (const FftLayer& l : layers)
+        octet = octet && l.ff0.wo_off >= 0 && l.ff2.wo_off >= 0 && l.qkv.wo_off >= 0 && l.o_net.wo_off >= 0 && l.qkv.cout == 3 * d_head;
+    if (octet) {
+        // ---- config 3: the whole FFT block on the bf16 matrix cores.  The residual stream x / y stays fp32 channel-first (LayerNorm
+        // statistics, residual adds); every GEMM reads a bf16 octet copy of its input (bfo.hpp) that its producer writes alongside:
+        //   xo (LayerNorm 2 / the initial pack) -> qkv conv -> fp32 q|k|v -> bf16 MFMA attention -> ao (octet)
+        //   -> o_net conv + x -> y (fp32) -> LayerNorm 1 -> y, yo -> Conv1d + ReLU -> hid (octet, 1536 channels)
+        //   -> Conv1d + y -> x (fp32) -> LayerNorm 2 -> x, xo                                   (transformer.py:113-160, 72-90, 172-177)
+        // All octet tensors live in the fp32-sized `hid` buffer: 2 B S (d_inner + 2 d + 64) bytes of its 4 B S d_inner.
+        const int di = layers[0].ff0.cout;
+        char* base = (char*)w.hid;
+        void* hid_o = base;
+        void* xo = base + (int64_t)B * di * S * 2;
+        void* yo = (char*)xo + (int64_t)B * d * S * 2;
+        void* ao = (char*)yo + (int64_t)B * d * S * 2;
+        TTS_REQUIRE((int64_t)2 * (di + 2 * d + d_head) <= (int64_t)4 * di, "fastpitch: octet buffers do not fit the hidden buffer");
+        TTS_TRY(bfo_launch_pack(x, B, d, S, 1.f, xo, s));
+        BfoConvParams cp;
+        auto conv = [&](const PConv& c, const void* in, void* out_o, float* out_f, const float* res_f, float out_slope) -> int32_t {
+            std::memset(&cp, 0, sizeof(cp));
+            cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
+            cp.x = in; cp.y = out_o; cp.y_f32 = out_f; cp.res_f32 = res_f;
+            cp.w = h->dev16 + c.wo_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
+            cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = out_slope;
+            prof_begin(s, 2.0 * c.cout * c.cin * c.k);
+            const int32_t rc = bfo_launch_conv(cp, s);
+            prof_end(s);
+            return rc;
+        };
+        for (const FftLayer& l : layers) {
+            TTS_TRY(conv(l.qkv, xo, nullptr, w.q, nullptr, 1.f));
+            TTS_TRY(launch_attention_bf16(w.q, lens, B, d_head, S, scale, nullptr, s, ao));
+            TTS_TRY(conv(l.o_net, ao, nullptr, w.y, x, 1.f));
+            TTS_TRY(launch_layernorm_cf_octet(w.y, w.y, yo, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
+            TTS_TRY(conv(l.ff0, yo, hid_o, nullptr, nullptr, 0.f));               // ReLU = leaky-relu with slope 0, applied by the producer
+            TTS_TRY(conv(l.ff2, hid_o, nullptr, x, w.y, 1.f));
+            TTS_TRY(launch_layernorm_cf_octet(x, x, xo, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
+        }
+        return 0;
+    }
     for (const FftLayer& l : layers) {
         TTS_TRY(run_conv(h, l.qkv, x, w.q, nullptr, B, S, nullptr, 0, s));
         TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s));
         TTS_TRY(run_conv(h, l.o_net, w.a, w.y, x, B, S, nullptr, 0, s));
         TTS_TRY(launch_layernorm_cf(w.y, w.y, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
-        if (octet_ff && l.ff0.wo_off >= 0 && l.ff2.wo_off >= 0) {
-            // config 3: Conv1d + ReLU -> Conv1d + residual (transformer.py:72-90) on the bf16 octet engine.  The LayerNorm output
-            // is packed to bf16 entries once, the 1536-channel intermediate crosses HBM as bf16 (ReLU = leaky-relu slope 0 applied
-            // by the producer), the second conv adds the fp32 residual and writes the fp32 stream the next LayerNorm reads.
-            // Both tensors live in the fp32-sized `hid` buffer: [B][d_inner/8][S][8] bf16, then [B][d/8][S][8] bf16.
-            void* hid_o = w.hid;
-            void* xo = (char*)w.hid + (int64_t)B * l.ff0.cout * S * 2;
-            TTS_TRY(bfo_launch_pack(w.y, B, d, S, 1.f, xo, s));
-            BfoConvParams cp;
-            std::memset(&cp, 0, sizeof(cp));
-            cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
-            cp.x = xo; cp.y = hid_o; cp.w = h->dev16 + l.ff0.wo_off; cp.bias = h->dev + l.ff0.b_off;
-            cp.Cin = l.ff0.cin; cp.Cout = l.ff0.cout; cp.K = l.ff0.k; cp.out_slope = 0.f;
-            prof_begin(s, 2.0 * l.ff0.cout * l.ff0.cin * l.ff0.k);
-            int32_t rc = bfo_launch_conv(cp, s);
-            prof_end(s);
-            TTS_TRY(rc);
-            cp.x = hid_o; cp.y = nullptr; cp.y_f32 = x; cp.res_f32 = w.y; cp.w = h->dev16 + l.ff2.wo_off; cp.bias = h->dev + l.ff2.b_off;
-            cp.Cin = l.ff2.cin; cp.Cout = l.ff2.cout; cp.K = l.ff2.k; cp.out_slope = 1.f;
-            prof_begin(s, 2.0 * l.ff2.cout * l.ff2.cin * l.ff2.k);
-            rc = bfo_launch_conv(cp, s);
-            prof_end(s);
-            TTS_TRY(rc);
-        } else {
         TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s));
         TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, nullptr, 0, s));
-        }
         TTS_TRY(launch_layernorm_cf(x, x, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
     }
     return 0;

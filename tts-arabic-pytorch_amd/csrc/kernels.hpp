@@ -18,6 +18,10 @@ int32_t launch_conv_post(const float* x, int64_t x_bs, int32_t x_cs, const float
 int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const float* beta,
                             const int64_t* lens, int32_t apply_mask, int32_t B, int32_t C, int32_t S,
                             hipStream_t s, float eps = 1e-5f);
+// the same, also writing the result as an octet bf16 tensor [B][C/8][S][8] (bfo.hpp): the next conv's input copy (C % 64 == 0, C <= 512)
+int32_t launch_layernorm_cf_octet(const float* x, float* y, void* y_octet, const float* gamma, const float* beta,
+                                  const int64_t* lens, int32_t apply_mask, int32_t B, int32_t C, int32_t S,
+                                  hipStream_t s, float eps = 1e-5f);
 
 // Encoder input: x[b][c][t] = word_emb[ids[b][t]][c] + pos[t][c]*(ids!=pad) + spk[c]
 // (transformer.py:212-219; model.py:355-361).  Also writes lens[b] = #non-pad tokens.
@@ -31,8 +35,9 @@ int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32
                          float scale, float* out, hipStream_t s);
 
 // the same on the bf16 matrix cores (attention_bf16.hip; config 3): launch_attention routes here under ttsamd_set_precision(1)
+// out_octet != nullptr: the result leaves as an octet bf16 tensor [B][D/8][S][8] (bfo.hpp) instead of fp32 channel-first
 int32_t launch_attention_bf16(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S, float scale, float* out,
-                              hipStream_t s);
+                              hipStream_t s, void* out_octet = nullptr);
 
 // Predictor head (model.py:132): out[b][t] = (bias + sum_c w[c]*x[b][c][t]) * (t < lens[b]);
 // mode 1 additionally writes dur = clamp(exp(out)-1, 0, max_dur) (model.py:368) to out2.
