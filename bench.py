@@ -606,7 +606,9 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
     res = []
     B = ids.shape[0]
     res.append(small_config(B, prec='bf16', name=f'C3 per-GPU share: FastPitch+HiFi-GAN, synthetic 64-phoneme x batch{B}, bf16 MFMA '
-                                                 '(HiFi-GAN on the bf16 octet engine)'))
+                                                 '(HiFi-GAN and the FastPitch FFT blocks on the bf16 octet engine)'))
+    for b_small in (8, 1):                          # north star: batch 1 / 8 / 32 -- the bf16 configuration at the small batches too
+        res.append(small_config(b_small, prec='bf16', name=f'C3 at batch {b_small}: FastPitch+HiFi-GAN, synthetic 64-phoneme, bf16 MFMA'))
     n = max(args.steps, 10)
     hgf = hifigan_flops_per_frame(HIFIGAN_CONFIG)
     # ---- C4

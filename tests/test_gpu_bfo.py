@@ -255,3 +255,33 @@ def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch
     print(f'bf16 attention vs fp32 attention (both under bf16 GEMMs): {worst_ab:.2e}; vs the fp32 engine: {worst_a:.2e} (fp32 attention: {worst_b:.2e})')
     assert bool(torch.isfinite(mel_a).all())
     assert worst_a < 6e-2 and worst_ab < 4e-2
+
+
+def test_split_k_small_batch(dev, synth_weights, monkeypatch):
+    """Batch 1: the octet engine's convs split K over their C-in slabs (partial sums in fp32, summed in slice order by
+    bfo_splitk_reduce: deterministic) because a batch-1 launch is a handful of blocks.  Same results as the un-split launches up to
+    the fp32 summation order, run-to-run bit-identical, and inside the bf16 tolerances against the exact-fp32 engines."""
+    from ttsamd import synth
+    from ttsamd.engine import FastPitchEngine, HifiGanEngine, set_precision
+    ids = synth.synth_ids(1, 40)
+    dur = synth.synth_durations(1, 40)
+    fp, hg = FastPitchEngine(synth_weights['fastpitch'], device=dev), HifiGanEngine(synth_weights['hifigan'], device=dev)
+    mel32, lens32, *_ = fp.infer(ids, dur_tgt=dur)
+    wave32 = hg.forward(mel32, lens32)
+    set_precision('bf16')
+    try:
+        monkeypatch.setenv('TTSAMD_BFO_SPLITK', '1')
+        mel_a, _, *_ = fp.infer(ids, dur_tgt=dur)
+        wave_a = hg.forward(mel32, lens32)
+        mel_a2, _, *_ = fp.infer(ids, dur_tgt=dur)
+        wave_a2 = hg.forward(mel32, lens32)
+        monkeypatch.setenv('TTSAMD_BFO_SPLITK', '0')
+        mel_b, _, *_ = fp.infer(ids, dur_tgt=dur)
+        wave_b = hg.forward(mel32, lens32)
+    finally:
+        set_precision('f32')
+    assert torch.equal(mel_a, mel_a2) and torch.equal(wave_a, wave_a2)
+    e_ab, e_a = float((mel_a - mel_b).abs().max()), float((mel_a - mel32).abs().max())
+    w_ab, w_a = float((wave_a - wave_b).abs().max()), float((wave_a - wave32).abs().max())
+    print(f'split K vs un-split: mel {e_ab:.2e}, wave {w_ab:.2e}; vs fp32: mel {e_a:.2e}, wave {w_a:.2e}')
+    assert e_a < 6e-2 and w_a < 4e-2 and e_ab < 2e-2 and w_ab < 2e-2

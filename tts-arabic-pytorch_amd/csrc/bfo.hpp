@@ -61,6 +61,12 @@ struct BfoConvParams {
     int32_t up;            // 1: Conv1d ("same" padding); u > 1: ConvTranspose1d(stride u, kernel 2u, padding u/2)
     int32_t mode;
     float div, res_slope, out_slope;
+    // split K for launches that cannot fill the chip (batch 1 / 8: FastPitch's 1536 -> 384 conv is 6 blocks at batch 1): the C-in
+    // slabs are dealt to `ksplit` blocks per tile (extra grid.y factor) that write raw fp32 partial sums to
+    // splitk_ws[ks][b][Cout][L]; bfo_splitk_reduce then sums them IN ORDER and applies the epilogue (deterministic, no atomics)
+    float* splitk_ws;      // >= splitk_floats floats of scratch, or nullptr (never split)
+    int64_t splitk_floats;
+    int32_t ksplit;        // set by the launcher
 };
 
 // kernel-level launchers (bfo_pair.hip, bfo_conv.hip)

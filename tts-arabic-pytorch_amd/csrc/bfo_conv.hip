@@ -6,6 +6,7 @@
 //   bfo_conv_post           leaky_relu(0.01) -> Conv1d(C -> 1, k7) -> tanh on an octet tensor
 // and the host-side weight packers.  Reference ops: vocoder/hifigan/models.py:46-53 (ResBlock1), :96-99,114-115
 // (upsamplers), :112 (conv_pre), :123-125 (conv_post).
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -41,7 +42,9 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
     const int wm = wid / WN, wn = wid % WN;
     const int b = blockIdx.z;
     const int q0 = blockIdx.x * G::NCOLS;
-    const int co0 = blockIdx.y * (32 * WM) + 32 * wm;       // this wave's first output row
+    const int nrb = gridDim.y / p.ksplit;                    // row blocks; blockIdx.y = row block + nrb * (split-K slice)
+    const int ks = blockIdx.y / nrb;
+    const int co0 = (blockIdx.y - ks * nrb) * (32 * WM) + 32 * wm;       // this wave's first output row
     const int L = p.Lin;
     int len = L;
     if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
@@ -61,15 +64,18 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
     {
         float bv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = p.bias ? p.bias[min(co0 + 8 * (r >> 2) + 4 * kk + (r & 3), p.Cout - 1)] : 0.f;
+        for (int r = 0; r < 16; ++r)
+            bv[r] = (p.bias && p.ksplit == 1) ? p.bias[min(co0 + 8 * (r >> 2) + 4 * kk + (r & 3), p.Cout - 1)] : 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = bv[r];
     }
-    for (int s0 = 0; s0 < NHT; s0 += SH) {
+    const int n_slabs = (NHT + SH - 1) / SH;
+    const int sl_beg = ks * n_slabs / p.ksplit, sl_end = (ks + 1) * n_slabs / p.ksplit;
+    for (int s0 = sl_beg * SH; s0 < min(sl_end * SH, NHT); s0 += SH) {
         const int nh = min(SH, NHT - s0);
-        if (s0 > 0) __syncthreads();                        // the previous slab has been consumed
+        if (s0 > sl_beg * SH) __syncthreads();              // the previous slab has been consumed
         // staged 8 entries per thread at a time: the accumulators are live here, a whole slab in flight would spill
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));                     // opaque: the per-entry index math must not be hoisted out of the
@@ -97,6 +103,18 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
 
     // ---- epilogue: [+ residual] [+ running sum] [/ div], activation of the consumer, 8-byte stores from the C layout
     if (co0 >= p.Cout) return;
+    if (p.ksplit > 1) {
+        // raw partial sums, fp32 channel-first [ks][b][Cout][L]; bias / residual / activation happen in bfo_splitk_reduce
+        const bfo_i4 prs = bfo_rsrc(p.splitk_ws + ((int64_t)ks * p.batch + b) * p.Cout * L, (unsigned)p.Cout * L * 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int q = q0 + cw + 32 * j;
+            const int vq = q < len ? q * 4 + 4 * kk * L * 4 : BFO_OOB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bfo_st4f(acc[j][r], prs, vq, (co0 + 8 * (r >> 2) + (r & 3)) * L * 4, 0);
+        }
+        return;
+    }
     if constexpr (OUT_F32) {
         // fp32 channel-first output (+ fp32 residual): 4 bytes per lane and register, two 128-byte row segments per store
         const bfo_i4 yrs = bfo_rsrc(p.y_f32 + (int64_t)b * p.Cout * L, (unsigned)p.Cout * L * 4);
@@ -153,8 +171,57 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
     }
 }
 
+// Second half of a split-K conv: thread = (octet, position); y = epilogue(sum_ks partial[ks]) in slice order, with exactly the
+// epilogue of bfo_conv1d (bias, fp32 or octet residual, running sum, / div, activation; fp32 channel-first or octet output).
+__global__ __launch_bounds__(256) void bfo_splitk_reduce(const BfoConvParams p) {
+    const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    const int L = p.Lin;
+    int len = L;
+    if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
+    if (t >= len) return;
+    const int NOO = p.Cout / 8;
+    const int64_t per = (int64_t)p.batch * p.Cout * L;
+    const float* pp = p.splitk_ws + ((int64_t)b * p.Cout + 8 * o) * L + t;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = 0.f;
+        for (int ks = 0; ks < p.ksplit; ++ks) a += pp[ks * per + (int64_t)e * L];
+        v[e] = a + (p.bias ? p.bias[8 * o + e] : 0.f);
+    }
+    if (p.y_f32) {
+        float* yp = p.y_f32 + ((int64_t)b * p.Cout + 8 * o) * L + t;
+        const float* rp = p.res_f32 ? p.res_f32 + ((int64_t)b * p.Cout + 8 * o) * L + t : nullptr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yp[(int64_t)e * L] = bfo_lrelu(v[e] + (rp ? rp[(int64_t)e * L] : 0.f), p.out_slope);
+        return;
+    }
+    const int64_t ent = ((int64_t)b * NOO + o) * L + t;
+    if (p.res) {
+        const uint4 r = reinterpret_cast<const uint4*>(p.res)[ent];
+        const float rinv = 1.f / p.res_slope;
+        const float rr[8] = {bfo_lo((int)r.x), bfo_hi((int)r.x), bfo_lo((int)r.y), bfo_hi((int)r.y),
+                             bfo_lo((int)r.z), bfo_hi((int)r.z), bfo_lo((int)r.w), bfo_hi((int)r.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bfo_unrelu(rr[e], rinv);
+    }
+    if (p.mode != 0) {
+        const uint4 r = reinterpret_cast<const uint4*>(p.sum_in)[ent];
+        const float ss[8] = {bfo_lo((int)r.x), bfo_hi((int)r.x), bfo_lo((int)r.y), bfo_hi((int)r.y),
+                             bfo_lo((int)r.z), bfo_hi((int)r.z), bfo_lo((int)r.w), bfo_hi((int)r.w)};
+        const float sc = p.mode == 2 ? 1.f / p.div : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + ss[e]) * sc;
+    }
+    const bfo_i2 lo = bfo_act4(v[0], v[1], v[2], v[3], p.out_slope, -1), hi = bfo_act4(v[4], v[5], v[6], v[7], p.out_slope, -1);
+    uint4 w;
+    w.x = (unsigned)lo.x; w.y = (unsigned)lo.y; w.z = (unsigned)hi.x; w.w = (unsigned)hi.y;
+    reinterpret_cast<uint4*>(p.y)[ent] = w;
+}
+
 template <int K, int WM, int WN, int NT, bool OUT_F32>
-static int32_t bfo_launch_conv_cfg(const BfoConvParams& p, hipStream_t stream) {
+static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream) {
+    BfoConvParams p = p_in;
     using G = BfoConvGeo<K, WM, WN, NT>;
     static bool attr_set[16] = {};
     int dev_id = 0;
@@ -166,15 +233,38 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p, hipStream_t stream) {
     }
     const int CoutP = (p.Cout + 31) & ~31;
     dim3 grid((p.Lin + G::NCOLS - 1) / G::NCOLS, (CoutP + 32 * WM - 1) / (32 * WM), p.batch);
+    // split K when the tile grid leaves most CUs without a block and the reduction depth allows it (batch 1 / 8)
+    p.ksplit = 1;
+    const int64_t blocks = (int64_t)grid.x * grid.y * grid.z;
+    const int n_slabs = ((p.Cin + 15) / 16 + G::SH - 1) / G::SH;
+    const int64_t per = (int64_t)p.batch * p.Cout * p.Lin;
+    const char* ske = getenv("TTSAMD_BFO_SPLITK");              // 0 disables (A/B and parity runs)
+    const char* mse = getenv("TTSAMD_BFO_SPLITK_MIN_SLABS");
+    const int min_slabs = mse ? atoi(mse) : 4;
+    if (p.splitk_ws && blocks < 128 && n_slabs >= min_slabs && !(ske && ske[0] == '0')) {
+        const char* mk = getenv("TTSAMD_BFO_SPLITK_MAX");
+        int64_t ks = std::min<int64_t>((256 + blocks - 1) / blocks, n_slabs);
+        ks = std::min<int64_t>(ks, mk ? atoi(mk) : 4);
+        ks = std::min<int64_t>(ks, p.splitk_floats / std::max<int64_t>(per, 1));
+        if (ks >= 2) p.ksplit = (int)ks;
+    }
+    grid.y *= p.ksplit;
     hipLaunchKernelGGL((bfo_conv1d<K, WM, WN, NT, OUT_F32>), grid, dim3(256), G::LDS, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
+    if (p.ksplit > 1) {
+        dim3 rg((p.Lin + 255) / 256, p.Cout / 8, p.batch);
+        hipLaunchKernelGGL(bfo_splitk_reduce, rg, dim3(256), 0, stream, p);
+        TTS_CHECK_HIP(hipGetLastError());
+    }
     return 0;
 }
 
 template <int K>
 static int32_t bfo_launch_conv_k(const BfoConvParams& p, hipStream_t stream) {
     // short sequences (FastPitch encoder: 64 tokens per utterance): 64-column tiles instead of 256
-    const bool narrow = p.Lin <= 96 && p.Cout >= 128;
+    // ... and for small grids: with 256-column tiles a batch-1 decoder conv is 2 column tiles
+    const int64_t blocks8 = (int64_t)((p.Lin + 255) / 256) * ((p.Cout + 127) / 128) * p.batch;
+    const bool narrow = p.Cout >= 128 && (p.Lin <= 96 || blocks8 < 48);
     if (p.y_f32) {
         if (narrow) return bfo_launch_conv_cfg<K, 4, 1, 2, true>(p, stream);
         if (p.Cout >= 128) return bfo_launch_conv_cfg<K, 4, 1, 8, true>(p, stream);

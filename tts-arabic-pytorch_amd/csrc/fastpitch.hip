@@ -295,6 +295,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
             cp.x = in; cp.y = out_o; cp.y_f32 = out_f; cp.res_f32 = res_f;
             cp.w = h->dev16 + c.wo_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
             cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = out_slope;
+            cp.splitk_ws = t_splitk_ws; cp.splitk_floats = t_splitk_ws ? kSplitKFloatsFp : 0;
             prof_begin(s, 2.0 * c.cout * c.cin * c.k);
             const int32_t rc = bfo_launch_conv(cp, s);
             prof_end(s);

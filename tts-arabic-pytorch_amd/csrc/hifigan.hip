@@ -431,6 +431,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                         cp.x = src; cp.y = t1; cp.w = W16 + w1.wo_off; cp.bias = h->dev + w1.b_off; cp.res = nullptr; cp.sum_in = nullptr;
                         cp.len_mul = mul; cp.Lin = L; cp.Cin = w1.cin; cp.Cout = w1.cout; cp.K = w1.k; cp.dil = d; cp.up = 1;
                         cp.mode = 0; cp.out_slope = 0.1f; cp.res_slope = 1.f;
+                        cp.splitk_ws = splitks[j % 3]; cp.splitk_floats = kSplitKFloats;     // batch 1: 30 blocks per stage-1 conv
                         if (in_section) prof_add(fl); else prof_begin(st, fl);
                         rc = bfo_launch_conv(cp, st);
                         if (rc == 0) {
