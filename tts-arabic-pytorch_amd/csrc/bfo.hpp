@@ -57,6 +57,8 @@ struct BfoConvParams {
     const float* res_f32;  //   second conv-FF conv writes the fp32 residual stream; res_f32 = fp32 channel-first residual or nullptr
     const int64_t* lens;
     int32_t len_mul, Lin, batch;
+    int32_t out_all;       // 1: `lens` masks the INPUT only; all Lin output positions are computed and stored (FastPitch's predictors,
+                           //    model.py:129-133: enc_out * mask goes in, the hidden layers are not masked)
     int32_t Cin, Cout, K, dil;
     int32_t up;            // 1: Conv1d ("same" padding); u > 1: ConvTranspose1d(stride u, kernel 2u, padding u/2)
     int32_t mode;

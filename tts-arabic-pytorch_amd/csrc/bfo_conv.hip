@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
     const int L = p.Lin;
     int len = L;
     if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
-    if (q0 >= len) return;
+    const int len_o = p.out_all ? L : len;                   // outputs computed / stored; `len` keeps masking the input
+    if (q0 >= len_o) return;
     const int dil = p.dil;
     const int W1 = G::NCOLS + (K - 1) * dil;
     const int x0 = q0 - (K - 1) * dil / 2;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int q = q0 + cw + 32 * j;
-            const int vq = q < len ? q * 4 + 4 * kk * L * 4 : BFO_OOB;
+            const int vq = q < len_o ? q * 4 + 4 * kk * L * 4 : BFO_OOB;
 #pragma unroll
             for (int r = 0; r < 16; ++r) bfo_st4f(acc[j][r], prs, vq, (co0 + 8 * (r >> 2) + (r & 3)) * L * 4, 0);
         }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int q = q0 + cw + 32 * j;
-            const int vq = q < len ? q * 4 + 4 * kk * L * 4 : BFO_OOB;
+            const int vq = q < len_o ? q * 4 + 4 * kk * L * 4 : BFO_OOB;
             float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) rv[r] = bfo_ld4f(rrs, has_res ? vq : BFO_OOB, (co0 + 8 * (r >> 2) + (r & 3)) * L * 4, 0);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int q = q0 + cw + 32 * j;
-        vo[j] = q < len ? q * 16 + 8 * kk : BFO_OOB;
+        vo[j] = q < len_o ? q * 16 + 8 * kk : BFO_OOB;
     }
     const bfo_i4 yrs = bfo_rsrc((char*)p.y + (int64_t)b * NOO * L * 16, (unsigned)NOO * L * 16);
     const int so0 = (co0 >> 3) * L * 16;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void bfo_splitk_reduce(const BfoConvParams p) 
     const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
     const int L = p.Lin;
     int len = L;
-    if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
+    if (p.lens && !p.out_all) len = min(len, (int)p.lens[b] * p.len_mul);
     if (t >= len) return;
     const int NOO = p.Cout / 8;
     const int64_t per = (int64_t)p.batch * p.Cout * L;

@@ -134,7 +134,7 @@ static void build_predictor(Builder& b, const std::string& prefix, int d_in, int
     pr.filter = filter;
     for (int i = 0; i < n_layers && b.rc == 0; ++i) {
         const std::string p = prefix + ".layers." + std::to_string(i) + ".";
-        pr.convs.push_back(b.conv(p + "conv", i == 0 ? d_in : filter, filter, k, true));
+        pr.convs.push_back(b.conv(p + "conv", i == 0 ? d_in : filter, filter, k, true, true));
         pr.ln_g.push_back(b.raw(p + "norm.weight", filter));
         pr.ln_b.push_back(b.raw(p + "norm.bias", filter));
     }
@@ -330,6 +330,40 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
                              float add, hipStream_t s) {
     const float* src = x;
     float* bufs[2] = {t0, t1};
+    {
+        // config 3: Conv1d + ReLU -> LayerNorm chain on the bf16 octet engine (input packed once, masked on load; LayerNorm writes the
+        // next conv's octet copy).  The octet tensors sit behind the fp32 buffers' used part: t0 / t1 are sized for the widest filter.
+        const char* ffe = std::getenv("TTSAMD_BFO_FF");
+        bool octet = default_precision() == 1 && !(ffe && ffe[0] == '0') && pr.convs.size() == 2 && pr.filter % 64 == 0 && pr.filter <= 512 &&
+                     pr.convs[0].cin % 8 == 0 && pr.convs[0].cin <= pr.filter * 2;
+        for (const PConv& c : pr.convs) octet = octet && c.wo_off >= 0;
+        if (octet) {
+            // t1 ([B][filter][S] fp32) holds the octet tensors one after the other: the packed input ([B][cin/8][S][8] bf16, cin <= 2 filter),
+            // then -- once the first conv has consumed it -- the octet copy of the first LayerNorm's output
+            void* xo = t1;
+            BfoConvParams cp;
+            auto conv = [&](const PConv& c, const void* in, float* out_f, const int64_t* lens_in) -> int32_t {
+                std::memset(&cp, 0, sizeof(cp));
+                cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
+                cp.x = in; cp.y_f32 = out_f; cp.lens = lens_in; cp.out_all = 1;
+                cp.w = h->dev16 + c.wo_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
+                cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = 0.f;                      // ReLU
+                cp.splitk_ws = t_splitk_ws; cp.splitk_floats = t_splitk_ws ? kSplitKFloatsFp : 0;
+                prof_begin(s, 2.0 * c.cout * c.cin * c.k);
+                const int32_t rc = bfo_launch_conv(cp, s);
+                prof_end(s);
+                return rc;
+            };
+            TTS_TRY(bfo_launch_pack(x, B, pr.convs[0].cin, S, 1.f, xo, s));
+            TTS_TRY(conv(pr.convs[0], xo, t0, lens));
+            // LayerNorm of layer 0 in place (fp32, t0) + its octet copy into t1 (the packed input there is dead now)
+            TTS_TRY(launch_layernorm_cf_octet(t0, t0, t1, h->dev + pr.ln_g[0], h->dev + pr.ln_b[0], nullptr, 0, B, pr.filter, S, s));
+            // the second conv reads the octet copy; the fp32 LayerNorm output in t0 is dead, so its result goes there
+            TTS_TRY(conv(pr.convs[1], t1, t0, nullptr));
+            TTS_TRY(launch_layernorm_cf(t0, t0, h->dev + pr.ln_g[1], h->dev + pr.ln_b[1], nullptr, 0, B, pr.filter, S, s));
+            return launch_pred_fc(t0, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul, add, s);
+        }
+    }
     for (size_t i = 0; i < pr.convs.size(); ++i) {
         float* dst = bufs[i & 1];
         TTS_TRY(run_conv(h, pr.convs[i], src, dst, nullptr, B, S, i == 0 ? lens : nullptr, 1, s));
