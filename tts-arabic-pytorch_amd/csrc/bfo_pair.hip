@@ -13,7 +13,7 @@
 //   T -> LDS lrelu(T), zero outside the utterance (c2 pads at the TRUE edge), bf16, over the dead window (8-byte writes
 //            straight from the C layout);
 //   phase B  Y = conv(T, w2) for the TS outputs [q0, q0 + TS); accumulators start from b2 + the residual, whose loads are
-//            issued before the exchange barriers;
+//            read back from the LDS window before the intermediate overwrites it;
 //   epilogue [+ running ResBlock sum] [/ n_kernels], leaky-relu of the CONSUMER, bf16, 8-byte stores from the C layout
 //            (512 contiguous bytes per wave instruction).
 // LDS <= 78 KB -> two blocks per CU: one block's loads / exchange / stores run under the other's MFMAs.
@@ -120,11 +120,17 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
         const int n = cw + 32 * j, q = q0 + n;
         vo[j] = (n < TS && q < len) ? q * 16 + 8 * kk : BFO_OOB;
     }
+    // ... read back from the LDS window (column n + h + pad of the staged tile) before the intermediate overwrites it: the block's
+    // vector-memory pipe already carries the window, the weight stream and the stores (a CU sustains ~11 B per cycle on that path)
     bfo_i2 rv[NT][4];
+    {
+        const int rc0 = cw + H + (K - 1) * dil / 2;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rv[j][g] = bfo_ld8(xrs, vo[j], (4 * wm + g) * L * 16, 0);
+            for (int g = 0; g < 4; ++g)
+                rv[j][g] = *reinterpret_cast<const bfo_i2*>(reinterpret_cast<const char*>(Xs + (4 * wm + g) * WS + rc0 + 32 * j) + 8 * kk);
+    }
 
     BFO_STAMP(6)
     __syncthreads();                                        // every wave is done with the window
