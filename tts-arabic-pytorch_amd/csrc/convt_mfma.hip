@@ -13,6 +13,7 @@
 // outputs y[co][q*u .. q*u+u) of every row: u = 8 -> two float4 stores per row, u = 2 -> one float2, full lines either way.
 #include <cstring>
 
+#include <cstdlib>
 #include "conv_mfma_common.hpp"
 
 namespace ttsamd {
@@ -210,6 +211,10 @@ static int32_t launch_convt_cfg(const ConvParams& p, hipStream_t stream) {
 // all phases; returns false if this geometry is not covered (the caller then uses the generic engine).
 bool convt_supported(const ConvParams& p) {
     const bool u_ok = (p.n_phase == 8 || p.n_phase == 2) && p.phase_p * 2 == p.n_phase;
+    // a grid that leaves most CUs without a block (batch 1: 32 blocks for the first upsampler) does
+    // better on the polyphase launch of the generic engine, which has one block per (phase, co tile) and splits K
+    static const int min_blocks = [] { const char* e = std::getenv("TTSAMD_CONVT_MIN_BLOCKS"); return e ? atoi(e) : 100; }();
+    if (u_ok && p.n_phase == 8 && (int64_t)((p.Nout + 63) / 64) * (p.CoutP / 64) * p.batch < min_blocks) return false;
     return p.precision == 0 && u_ok && p.K == 2 && p.dil == -1 && p.y_ts == p.n_phase && p.res == nullptr && p.mode == 0 &&
            p.scale == nullptr && p.relu_out == 0 && p.Cin % 8 == 0 && !p.x_packed && !p.y_packed &&
            (p.y_cs % 4) == 0 && (p.y_bs % 4) == 0 && (((uintptr_t)p.y) & 15) == 0 &&
