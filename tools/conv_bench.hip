@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
             unsigned st = 12345u;
             int64_t mx = 0, sum = 0;
             for (auto& v : hl) { int t = 0; for (int i = 0; i < 64; ++i) { st = st * 1664525u + 1013904223u; t += 2 + (int)((st >> 16) % 11u); } v = t; mx = std::max<int64_t>(mx, t); }
-            for (auto& v : hl) { v = std::min<int64_t>(T, v * T / mx); sum += v; }
+            for (auto& v : hl) { v = getenv("RAGGED_FRAC") ? (int64_t)(T * atof(getenv("RAGGED_FRAC"))) : std::min<int64_t>(T, v * T / mx); sum += v; }   // RAGGED_FRAC=f: every utterance f x the padded length
             int64_t* dl; hipMalloc(&dl, s.B * 8); hipMemcpy(dl, hl.data(), s.B * 8, hipMemcpyHostToDevice);
             p.lens_in = dl; p.lens_out = dl; p.len_in_mul = p.len_out_mul = mul;
             valid_frac = (double)sum / ((double)T * s.B);
@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
         hipMemset(tbuf, 0, tblocks * 8 * sizeof(unsigned long long));
         p.timing = tbuf;
 #endif
+        auto do_launch = [&] { launch_conv(p, 0); };
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         // warm the clocks: the GPU drops to its idle state during the host-side setup above and needs tens of ms of
         // work to return to its compute clock (a cold 0.5 ms kernel ran at 1.7 GHz instead of 2.2-2.3, tools/conv_timeline.py)
@@ -86,23 +87,23 @@ int main(int argc, char** argv) {
             float el = 0.f;
             int it = 0;
             do {
-                for (int i = 0; i < 8; ++i) launch_conv(p, 0);
+                for (int i = 0; i < 8; ++i) do_launch();
                 hipEventRecord(w1, 0); hipEventSynchronize(w1);
                 hipEventElapsedTime(&el, w0, w1);
             } while (el < (float)warm_ms && ++it < 10000);
         }
         hipEventRecord(e0, 0);
         const int n = getenv("ITERS") ? atoi(getenv("ITERS")) : 20;
-        for (int i = 0; i < n; ++i) launch_conv(p, 0);
+        for (int i = 0; i < n; ++i) do_launch();
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= n;
         double fl = 2.0 * s.cout * s.cin * s.k * (double)s.B * s.L * valid_frac;
-        printf("B%d cin%d cout%d k%d d%d L%d: %.3f ms %.1f TF\n", s.B, s.cin, s.cout, s.k, s.dil, s.L, ms, fl / ms / 1e9);
+        printf("B%d cin%d cout%d k%d d%d L%d: %.3f ms %.1f TF (valid %.3f)\n", s.B, s.cin, s.cout, s.k, s.dil, s.L, ms, fl / ms / 1e9, valid_frac);
         fflush(stdout);
 #ifdef TTS_TIMING
         {
             hipMemset(tbuf, 0, tblocks * 8 * sizeof(unsigned long long));
-            for (int i = 0; i < 20; ++i) launch_conv(p, 0);      // the stamped launch is the last, clocks warm
+            for (int i = 0; i < 20; ++i) do_launch();      // the stamped launch is the last, clocks warm
             hipDeviceSynchronize();
             std::vector<unsigned long long> ht(tblocks * 8);
             hipMemcpy(ht.data(), tbuf, ht.size() * 8, hipMemcpyDeviceToHost);

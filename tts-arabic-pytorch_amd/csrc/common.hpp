@@ -98,6 +98,8 @@ struct ConvParams {
     int32_t x_packed;         // read x in that layout (x_cs = positions per row; in_slope is ignored)
     int32_t xcd_w;            // set by the launcher: gcd(n_co_tiles, 8) co-tile classes, one per XCD residue (weight locality; 0 = off)
     int32_t tile_major;       // set by the launcher: blockIdx.x = utterance slot, blockIdx.z = time tile (ragged batches)
+    int32_t compact;          // set by the launcher (ragged batches): the (utterance, time tile) pair of a block is looked up in the
+                              // utterance-major list of LIVE tiles (live_tile below), so every dead block sits at the end of the grid
     unsigned long long* timing;   // tools/conv_bench -DTTS_TIMING only: [blocks][8] clock samples (nullptr otherwise)
 };
 constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)
@@ -107,6 +109,7 @@ void conv_log(const char* kind, int K, int cin, int cout, int nout, int batch, i
               int n_phase);
 // block order of a launch (conv_mfma.hip)
 bool tile_major_order(const ConvParams& p, unsigned n_tiles);
+bool compact_order(const void* lens, int batch);
 // Launches the kernel; returns 0 or a negative code.
 int32_t launch_conv(const ConvParams& p, hipStream_t stream);
 // ConvTranspose1d with all output phases per wave (convt_mfma.hip): takes the polyphase ConvParams of the generic engine

@@ -72,34 +72,18 @@ struct Geo {
 //   3: row epilogue with the residual (and, in the accumulate modes, the previous y) PRELOADED into the accumulators
 //      (every c2 conv of a ResBlock, o_net and the second conv-FF conv): nothing is read after the main loop
 template <int K, int MT, int NTL, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+__device__ __forceinline__ void conv_tile(const ConvParams& p, float4* smem4, const int b, const int q0, const unsigned by_) {
     constexpr int CO_BLK = WM * MT * 32;
     constexpr int NT_BLK = WN * NTL * 32;
     using G = Geo<K, NT_BLK, CO_BLK>;
     constexpr int KC = G::KC, WS = G::WS, NXI = G::NXI, NW = G::NW, NGRP = G::NGRP, NSTAGE = G::NSTAGE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    // ragged batches: tile-major block order (x = utterance slot, z = time tile), see ConvParams::tile_major
-    unsigned bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
-    if (p.xcd_w) {
-        // weight locality: workgroups go to the 8 XCDs round-robin by linear id; every XCD gets its own class of co-tiles, so
-        // that the weight slice its 4 MB L2 has to hold next to the streaming activations is 1/g of the layer (C=256 k=11:
-        // 2.9 MB of weights were re-fetched ~36x per XCD and launch; stand-alone +4 % there, +2.4 % for C=128 k=11, production
-        // +0.2 % because three concurrent launches share the L2; TTSAMD_XCD_W=0 disables)
-        // g = gcd(n_co_tiles, 8) classes of co-tiles; XCD x serves class x % g = the n_co_tiles / g co-tiles {x % g + g*k}
-        const unsigned lin = bx_ + gridDim.x * (by_ + gridDim.y * bz_), xcd = lin & 7u, slot = lin >> 3;
-        const unsigned nct = gridDim.y, g = (unsigned)p.xcd_w, per = nct / g;
-        const unsigned idx2 = slot * (8u / g) + xcd / g, rest = idx2 / per;
-        by_ = xcd % g + g * (idx2 % per); bx_ = rest % gridDim.x; bz_ = rest / gridDim.x;
-    }
-    const int b = p.tile_major ? (int)((bx_ + bz_) % (unsigned)p.batch) : (int)bz_;
     const int n_co_tiles = p.CoutP / CO_BLK;
     const int tiles_y = n_co_tiles * p.n_phase;
     const int ks = by_ / tiles_y, by = by_ % tiles_y;   // ks = split-K slice (0 when ksplit == 1)
     const int phase = by / n_co_tiles;
     const int co_blk0 = (by % n_co_tiles) * CO_BLK;
-    const int q0 = (p.tile_major ? bz_ : bx_) * NT_BLK;
 
     int n_out = p.Nout;
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
@@ -596,6 +580,34 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
     }   // EPI == 2
 }
 
+template <int K, int MT, int NTL, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    constexpr int NT_BLK = WN * NTL * 32;
+    // ragged batches: tile-major block order (x = utterance slot, z = time tile), see ConvParams::tile_major
+    unsigned bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+    if (p.xcd_w) {
+        // weight locality: workgroups go to the 8 XCDs round-robin by linear id; every XCD gets its own class of co-tiles, so
+        // that the weight slice its 4 MB L2 has to hold next to the streaming activations is 1/g of the layer (C=256 k=11:
+        // 2.9 MB of weights were re-fetched ~36x per XCD and launch; stand-alone +4 % there, +2.4 % for C=128 k=11, production
+        // +0.2 % because three concurrent launches share the L2; TTSAMD_XCD_W=0 disables)
+        // g = gcd(n_co_tiles, 8) classes of co-tiles; XCD x serves class x % g = the n_co_tiles / g co-tiles {x % g + g*k}
+        const unsigned lin = bx_ + gridDim.x * (by_ + gridDim.y * bz_), xcd = lin & 7u, slot = lin >> 3;
+        const unsigned nct = gridDim.y, g = (unsigned)p.xcd_w, per = nct / g;
+        const unsigned idx2 = slot * (8u / g) + xcd / g, rest = idx2 / per;
+        by_ = xcd % g + g * (idx2 % per); bx_ = rest % gridDim.x; bz_ = rest / gridDim.x;
+    }
+    int b = p.tile_major ? (int)((bx_ + bz_) % (unsigned)p.batch) : (int)bz_;
+    int q0 = (p.tile_major ? bz_ : bx_) * NT_BLK;
+    if (p.compact) {   // dead blocks last (live_tile, conv_mfma_common.hpp)
+        int tile = 0;
+        if (!live_tile(p.lens_out, p.len_out_mul, p.Nout, NT_BLK, p.batch, bz_ * gridDim.x + bx_, b, tile)) return;
+        b = __builtin_amdgcn_readfirstlane(b);
+        q0 = __builtin_amdgcn_readfirstlane(tile) * NT_BLK;
+    }
+    conv_tile<K, MT, NTL, WM, WN, EPI>(p, smem4, b, q0, by_);
+}
+
 // Second half of a split-K conv: y = epilogue(sum_ks partial[ks]) with exactly the epilogue of the main kernel.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
     const int b = blockIdx.z, co = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
@@ -623,12 +635,12 @@ static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_
     int dev_id = 0;
     TTS_CHECK_HIP(hipGetDevice(&dev_id));
     dev_id &= 15;
+    const auto kern = conv1d_mfma_f32<K, MT, NTL, WM, WN, EPI>;
     if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_f32<K, MT, NTL, WM, WN, EPI>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev_id] = true;
     }
-    hipLaunchKernelGGL((conv1d_mfma_f32<K, MT, NTL, WM, WN, EPI>), grid, dim3(256), lds, stream, q);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -640,6 +652,13 @@ static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_
 // tile, utterance = (slot + tile) % batch so that the XCD <-> utterance assignment rotates) recovers +4-5 % there.  On the
 // bench workload (10 % shorter on average) it measures -0.5 % (84.2 vs 83.8 ms per step: neighbouring blocks no longer
 // share their halo columns in L2), so the default stays time-major.
+// Dead blocks last (live_tile, conv_mfma_common.hpp): default for every ragged launch; TTSAMD_COMPACT=0 restores the plain
+// (time tile, co tile, utterance) grid.
+bool compact_order(const void* lens, int batch) {
+    static const bool on = [] { const char* e = getenv("TTSAMD_COMPACT"); return !(e && e[0] == '0'); }();
+    return on && lens != nullptr && batch > 1;
+}
+
 bool tile_major_order(const ConvParams& p, unsigned n_tiles) {
     static const int force = [] { const char* e = getenv("TTSAMD_TILE_MAJOR"); return e ? atoi(e) : 0; }();
     return force != 0 && p.lens_out != nullptr && p.batch > 1 && n_tiles <= 65535;
@@ -656,6 +675,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     q.ksplit = 1;
     q.tile_major = tile_major_order(p, grid.x) ? 1 : 0;
     if (q.tile_major) std::swap(grid.x, grid.z);
+    q.compact = (!q.tile_major && compact_order(p.lens_out, p.batch)) ? 1 : 0;
     {
         static const bool xw = [] { const char* e = getenv("TTSAMD_XCD_W"); return !(e && e[0] == '0'); }();
         const unsigned nct = grid.y;
