@@ -242,7 +242,9 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream
     const char* ske = getenv("TTSAMD_BFO_SPLITK");              // 0 disables (A/B and parity runs)
     const char* mse = getenv("TTSAMD_BFO_SPLITK_MIN_SLABS");
     const int min_slabs = mse ? atoi(mse) : 4;
-    if (p.splitk_ws && blocks < 128 && n_slabs >= min_slabs && !(ske && ske[0] == '0')) {
+    const char* mbe = getenv("TTSAMD_BFO_SPLITK_BLOCKS");
+    const int max_blocks = mbe ? atoi(mbe) : 256;   // under one block per CU
+    if (p.splitk_ws && blocks < max_blocks && n_slabs >= min_slabs && !(ske && ske[0] == '0')) {
         const char* mk = getenv("TTSAMD_BFO_SPLITK_MAX");
         int64_t ks = std::min<int64_t>((256 + blocks - 1) / blocks, n_slabs);
         ks = std::min<int64_t>(ks, mk ? atoi(mk) : 4);
