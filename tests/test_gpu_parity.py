@@ -90,6 +90,13 @@ def test_conv1d_kernel_large_tiles_fuzz(dev):
     _conv_fuzz(dev, _large_tile_cases(2024), 3e-5, 2024)
 
 
+@pytest.mark.gpu
+def test_conv1d_kernel_ragged_batch_over_64_utterances(dev):
+    """Ragged launches look their (utterance, tile) pair up in the list of LIVE tiles, 64 utterances per pass
+    (conv_mfma_common.hpp: live_tile): more than 64 utterances, some empty, lengths on and around tile edges."""
+    _conv_fuzz(dev, [(32, 32, 3, 1, 700, 70), (64, 64, 7, 3, 520, 130), (128, 128, 3, 2, 300, 67)], 3e-5, 77)
+
+
 def test_length_regulate_exact(dev, golden):
     import tts_oracle as O
     from ttsamd.engine import length_regulate

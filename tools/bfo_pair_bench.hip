@@ -12,6 +12,7 @@ namespace ttsamd {
 static thread_local std::string g_err;
 void set_error(const char* fmt, ...) { char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); g_err = buf; fprintf(stderr, "ERR %s\n", buf); }
 void conv_log(const char*, int, int, int, int, int, int, int, int, int, int) {}
+bool compact_order(const void* lens, int batch) { return lens != nullptr && batch > 1; }
 int64_t bfo_packed_conv_elems(int cout, int cin, int k) { return (int64_t)((cin + 15) / 16) * k * 2 * ((cout + 31) & ~31) * 8; }
 }
 using namespace ttsamd;

@@ -43,6 +43,7 @@ struct BfoPairParams {
     float in_slope;        // activation x was stored with (0.1)
     float mid_slope;       // leaky-relu between c1 and c2 (0.1)
     float out_slope;       // y = leaky_relu(v, out_slope); 1 = raw
+    int32_t compact;              // set by the launcher: ragged batch, blocks take the lin-th LIVE tile (common.hpp: live_tile)
     unsigned long long* timing;   // tools/bfo_pair_bench -DBFO_TIMING only: [blocks][16] shader-clock stamps (nullptr otherwise)
 };
 
@@ -69,6 +70,7 @@ struct BfoConvParams {
     float* splitk_ws;      // >= splitk_floats floats of scratch, or nullptr (never split)
     int64_t splitk_floats;
     int32_t ksplit;        // set by the launcher
+    int32_t compact;       // set by the launcher: ragged batch, blocks take the lin-th LIVE tile (common.hpp: live_tile)
 };
 
 // kernel-level launchers (bfo_pair.hip, bfo_conv.hip)

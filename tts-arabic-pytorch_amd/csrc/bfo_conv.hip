@@ -40,8 +40,14 @@ __global__ __launch_bounds__(256, 2) void bfo_conv1d(const BfoConvParams p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 5, l31 = lane & 31;
     const int wm = wid / WN, wn = wid % WN;
-    const int b = blockIdx.z;
-    const int q0 = blockIdx.x * G::NCOLS;
+    int b = blockIdx.z;
+    int q0 = blockIdx.x * G::NCOLS;
+    if (p.compact) {   // ragged batch: dead blocks last (common.hpp: live_tile)
+        int tile = 0;
+        if (!live_tile(p.lens, p.len_mul, p.Lin, G::NCOLS, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        b = __builtin_amdgcn_readfirstlane(b);
+        q0 = __builtin_amdgcn_readfirstlane(tile) * G::NCOLS;
+    }
     const int nrb = gridDim.y / p.ksplit;                    // row blocks; blockIdx.y = row block + nrb * (split-K slice)
     const int ks = blockIdx.y / nrb;
     const int co0 = (blockIdx.y - ks * nrb) * (32 * WM) + 32 * wm;       // this wave's first output row
@@ -236,6 +242,7 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream
     dim3 grid((p.Lin + G::NCOLS - 1) / G::NCOLS, (CoutP + 32 * WM - 1) / (32 * WM), p.batch);
     // split K when the tile grid leaves most CUs without a block and the reduction depth allows it (batch 1 / 8)
     p.ksplit = 1;
+    p.compact = (compact_order(p.lens, p.batch) && !p.out_all) ? 1 : 0;
     const int64_t blocks = (int64_t)grid.x * grid.y * grid.z;
     const int n_slabs = ((p.Cin + 15) / 16 + G::SH - 1) / G::SH;
     const int64_t per = (int64_t)p.batch * p.Cout * p.Lin;
@@ -317,8 +324,14 @@ __global__ __launch_bounds__(256, 2) void bfo_convt(const BfoConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z;
-    const int q0 = blockIdx.x * NQ;
+    int b = blockIdx.z;
+    int q0 = blockIdx.x * NQ;
+    if (p.compact) {   // ragged batch: dead blocks last (common.hpp: live_tile)
+        int tile = 0;
+        if (!live_tile(p.lens, p.len_mul, p.Lin, NQ, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        b = __builtin_amdgcn_readfirstlane(b);
+        q0 = __builtin_amdgcn_readfirstlane(tile) * NQ;
+    }
     const int co0 = blockIdx.y * (32 * RT);
     const int L = p.Lin, Lo = L * U;
     int len = L;
@@ -421,7 +434,9 @@ static int32_t bfo_launch_convt_cfg(const BfoConvParams& p, hipStream_t stream) 
         attr_lds[dev_id] = 80 * 1024;
     }
     dim3 grid((p.Lin + NQ - 1) / NQ, (p.Cout + 32 * RT - 1) / (32 * RT), p.batch);
-    hipLaunchKernelGGL((bfo_convt<U, RT, NQT, NT>), grid, dim3(256), lds, stream, p);
+    BfoConvParams q = p;
+    q.compact = compact_order(p.lens, p.batch) ? 1 : 0;
+    hipLaunchKernelGGL((bfo_convt<U, RT, NQT, NT>), grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }

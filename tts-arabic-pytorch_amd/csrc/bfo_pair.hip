@@ -54,8 +54,14 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 5, l31 = lane & 31;
     const int wm = wid / WN, wn = wid % WN;
-    const int b = blockIdx.z;
-    const int q0 = blockIdx.x * TS;
+    int b = blockIdx.z;
+    int q0 = blockIdx.x * TS;
+    if (p.compact) {   // ragged batch: dead blocks last (common.hpp: live_tile)
+        int tile = 0;
+        if (!live_tile(p.lens, p.len_mul, p.L, TS, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        b = __builtin_amdgcn_readfirstlane(b);
+        q0 = __builtin_amdgcn_readfirstlane(tile) * TS;
+    }
     const int L = p.L;
     int len = L;
     if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
@@ -225,7 +231,9 @@ static int32_t bfo_launch_pair_nt(const BfoPairParams& p, hipStream_t stream) {
         attr_set[dev_id] = true;
     }
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
-    hipLaunchKernelGGL((bfo_resblock_pair<K, C, NT>), grid, dim3(256), G::LDS, stream, p);
+    BfoPairParams q = p;
+    q.compact = compact_order(p.lens, p.batch) ? 1 : 0;
+    hipLaunchKernelGGL((bfo_resblock_pair<K, C, NT>), grid, dim3(256), G::LDS, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
