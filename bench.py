@@ -28,6 +28,9 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E, spec
+# what v_mfma_f32_32x32x16_bf16 sustains on random data with nothing else running (register-only loop on every SIMD, power-managed
+# clock 1.72-1.78 GHz): tools/mfma_peak_bench.hip, profiles/r3/mfma_sustained_peak.txt.  Reported NEXT to the guide's peak, never instead.
+BF16_MFMA_SUSTAINED_TFLOPS = 1700.0
 SAMPLE_RATE = 22050
 
 
@@ -475,6 +478,7 @@ def main():
             gbs = byts / sec / 1e9
             r = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
                  'mfma_achieved_tflops': ach, 'mfma_peak_tflops': PEAKS[prec], 'mfma_frac': ach / PEAKS[prec],
+                 'mfma_sustained_tflops': BF16_MFMA_SUSTAINED_TFLOPS, 'mfma_frac_of_sustained': ach / BF16_MFMA_SUSTAINED_TFLOPS,
                  'basis': 'algorithmic HBM bytes (and conv FLOPs) / wall time of the whole call (no per-launch events)'}
         return r
 
@@ -526,9 +530,12 @@ def main():
         if args.precision == 'bf16':
             byts = args.steps * step_bytes_bf16(B, frames)
             gbs = byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
-            roof = {'bound': 'hbm', 'kernel': 'bf16 octet engine (bfo_resblock_pair + bfo_conv1d + bfo_convt) + conv1d_mfma_bf16 for FastPitch',
+            roof = {'bound': 'hbm', 'kernel': 'bf16 octet engine (bfo_resblock_pair + bfo_conv1d + bfo_convt; HiFi-GAN, FastPitch FFT blocks and predictors) + conv1d_mfma_bf16 for the remaining FastPitch convs',
                     'kernel_time_basis': time_basis, 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
                     'mfma_achieved_tflops': achieved, 'mfma_peak_tflops': peak, 'mfma_frac': achieved / peak,
+                    'mfma_sustained_tflops': BF16_MFMA_SUSTAINED_TFLOPS, 'mfma_frac_of_sustained': achieved / BF16_MFMA_SUSTAINED_TFLOPS,
+                    'mfma_sustained_note': 'register-only v_mfma_f32_32x32x16_bf16 loop on random data, power-managed clock 1.72-1.78 GHz '
+                                           '(tools/mfma_peak_bench.hip, profiles/r3/mfma_sustained_peak.txt); the 2.5 PFLOP/s peak needs 2.4 GHz',
                     'algorithmic_bytes_per_step': byts / args.steps}
         else:
             roof = {'bound': 'mfma',

@@ -1,7 +1,7 @@
 // What the matrix pipe of this chip sustains with nothing else going on: every SIMD of every CU issues back-to-back independent MFMAs on
 // register operands (no LDS, no memory), long enough for the power management to settle.  Prints TFLOP/s and the shader clock the run
-// settled at (clock64 vs the 100 MHz wall clock), for v_mfma_f32_32x32x16_bf16 and v_mfma_f32_32x32x2_f32, with random and with zero operands
-// (switching activity, hence power, depends on the data).  The guide's peaks (2.5 PFLOP/s bf16, 157.3 TFLOP/s fp32) assume 2.4 GHz.
+// settled at (clock64 vs the 100 MHz wall clock), for v_mfma_f32_32x32x16_bf16 and v_mfma_f32_32x32x2_f32, with random operands (the same
+// pair for every MFMA, or 32 pairs in rotation) and with zeros: switching activity, hence power, depends on the data.  The guide's peaks (2.5 PFLOP/s bf16, 157.3 TFLOP/s fp32) assume 2.4 GHz.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_peak_bench.hip -o tools/bin/mfma_peak_bench
 // Run:   mfma_peak_bench [waves_per_simd = 1] [ms_per_case = 400]
 #include <hip/hip_runtime.h>
@@ -14,11 +14,18 @@
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 h8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f16v;
 
-template <bool BF16>
+// ROT: every MFMA takes another (A, B) register pair than the one before it (4 A fragments x 8 B fragments in registers), as a
+// kernel that streams operands does; without it the same two fragments feed every MFMA and the operand buses never toggle
+template <bool BF16, bool ROT>
 __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ in, float* __restrict__ out, int iters, unsigned long long* clk) {
     const int tid = threadIdx.x;
     const unsigned long long w0 = wall_clock64(), c0 = clock64();
     uint4 a = in[tid], b = in[256 + tid];
+    uint4 av[4], bv[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) av[u] = in[(tid + 37 * u) & 511];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = in[(tid + 61 * j + 256) & 511];
     f16v acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -30,10 +37,11 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ in, f
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                const uint4 aa = ROT ? av[u] : a, bb = ROT ? bv[j] : b;
                 if constexpr (BF16)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h8, aa), __builtin_bit_cast(h8, bb), acc[j], 0, 0, 0);
                 else
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, aa.x), __builtin_bit_cast(float, bb.x), acc[j], 0, 0, 0);
             }
     }
     float s = 0.f;
@@ -45,7 +53,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ in, f
     if (tid == 0 && blockIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
-template <bool BF16>
+template <bool BF16, bool ROT>
 static void run(const char* name, const uint4* in, float* out, unsigned long long* clk, int blocks, double target_ms) {
     const double flop_per_mfma = BF16 ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 2;
     int iters = 2000;
@@ -53,7 +61,7 @@ static void run(const char* name, const uint4* in, float* out, unsigned long lon
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {                      // calibrate, settle, measure
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(mfma_loop<BF16>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
+        hipLaunchKernelGGL((mfma_loop<BF16, ROT>), dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         if (rep == 0) iters = (int)(iters * target_ms / ms) + 1;
@@ -77,9 +85,11 @@ int main(int argc, char** argv) {
     hipMemcpy(rnd, h.data(), 512 * 16, hipMemcpyHostToDevice);
     hipMemset(zero, 0, 512 * 16);
     printf("%d CUs, %d wave(s) per SIMD\n", prop.multiProcessorCount, wps);
-    run<true>("v_mfma_f32_32x32x16_bf16, random operands", rnd, out, clk, blocks, target_ms);
-    run<true>("v_mfma_f32_32x32x16_bf16, zero operands", zero, out, clk, blocks, target_ms);
-    run<false>("v_mfma_f32_32x32x2_f32, random operands", rnd, out, clk, blocks, target_ms);
-    run<false>("v_mfma_f32_32x32x2_f32, zero operands", zero, out, clk, blocks, target_ms);
+    run<true, true>("v_mfma_f32_32x32x16_bf16, random, 32 operand pairs", rnd, out, clk, blocks, target_ms);
+    run<true, false>("v_mfma_f32_32x32x16_bf16, random, one operand pair", rnd, out, clk, blocks, target_ms);
+    run<true, false>("v_mfma_f32_32x32x16_bf16, zero operands", zero, out, clk, blocks, target_ms);
+    run<false, true>("v_mfma_f32_32x32x2_f32, random, 32 operand pairs", rnd, out, clk, blocks, target_ms);
+    run<false, false>("v_mfma_f32_32x32x2_f32, random, one operand pair", rnd, out, clk, blocks, target_ms);
+    run<false, false>("v_mfma_f32_32x32x2_f32, zero operands", zero, out, clk, blocks, target_ms);
     return 0;
 }
