@@ -22,6 +22,7 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, 'tts-arabic-pytorch_amd'))
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # one hardware queue per stream the path uses (ttsamd/__init__.py), before any GPU call
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -263,9 +264,12 @@ def main():
     ap.add_argument('--tokens', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-small', action='store_true', help='skip the batch 1 / batch 8 sub-results (N=1 only)')
-    ap.add_argument('--pipeline', action='store_true',
-                    help='two HIP streams (ttsamd.pipeline): FastPitch of step i+1 under HiFi-GAN of step i; measured +1.3 %% at '
-                         'B=32 (the conv engine is busy either way), so the default stays the one-stream schedule')
+    ap.add_argument('--pipeline', action='store_true', default=None,
+                    help='two HIP streams (ttsamd.pipeline): FastPitch of step i+1 under HiFi-GAN of step i, same work and same '
+                         'results per step.  fp32: +0.6 ... 1.3 %% at B=32 (the conv engine is busy either way), so the default is '
+                         'the one-stream schedule; bf16: 12.5 -> 10.6 ms per step (FastPitch is 18 %% of that step and mostly '
+                         'launch- and latency-bound), so --precision bf16 pipelines by default')
+    ap.add_argument('--no-pipeline', dest='pipeline', action='store_false', help='force the one-stream schedule')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='N > 1: weak = --batch utterances PER RANK (default); strong = --batch utterances in total, B/N per rank '
                          '(north star: B=256 on 1/2/4/8 GPUs)')
@@ -369,9 +373,19 @@ def main():
     # --pipeline: two HIP streams (ttsamd.pipeline), the acoustic model of step i + 1 (150 short launches) under the vocoder of
     # step i.  Same work per step, same results; 79.4 -> 78.4 ms per step at B=32 (only FastPitch's non-conv kernels find idle CUs).
     from ttsamd.pipeline import FastPitchHifiGan
-    pipe = FastPitchHifiGan(fp, hg, dev) if args.pipeline else None
+    if args.pipeline is None:
+        # default: bf16 on one GPU.  N > 1 stays on the one-stream schedule unless asked: two streams issuing the length exchange and
+        # the audio fan-in on one communicator has never run between distinct devices
+        args.pipeline = args.precision == 'bf16' and world == 1
+    pipe_obj = []
 
-    def make_step(ids_, dur_):
+    def get_pipe():
+        if not pipe_obj:
+            pipe_obj.append(FastPitchHifiGan(fp, hg, dev))
+        return pipe_obj[0]
+
+    def make_step(ids_, dur_, pipelined=None):
+        pipe = get_pipe() if (args.pipeline if pipelined is None else pipelined) else None
         if world == 1:
             if pipe is not None:
                 def step():
@@ -429,7 +443,7 @@ def main():
 
     lib = L.load()
     import ctypes
-    lib.ttsamd_profile_enable(1)
+    lib.ttsamd_profile_enable(0 if os.environ.get("TTSAMD_BENCH_NO_EVENTS") else 1)
     elapsed, (wave, dec_lens) = _time_steps(step, args.steps, sync, barrier)
     prof = (ctypes.c_double * 3)()
     L.check(lib.ttsamd_profile_read(prof), 'profile_read')
@@ -482,7 +496,7 @@ def main():
                  'basis': 'algorithmic HBM bytes (and conv FLOPs) / wall time of the whole call (no per-launch events)'}
         return r
 
-    def small_config(b, prec=None, name=None):
+    def small_config(b, prec=None, name=None, pipelined=False):
         """Batch-b sub-result (north star: batch 1 / 8 / 32): same step function, own warm-up, timed WITHOUT the
         per-launch events (they cost a B=1 call 17 %); its roofline figure is algorithmic work over the call's
         WALL time — launch gaps and the three-stream overlap included — so it can never exceed what ran."""
@@ -490,7 +504,7 @@ def main():
         set_precision(prec)
         try:
             ids_b, dur_b = ids[:b].contiguous(), dur[:b].contiguous()
-            st = make_step(ids_b, dur_b)
+            st = make_step(ids_b, dur_b, pipelined)
             for _ in range(5):
                 st()
             sync()
@@ -502,6 +516,8 @@ def main():
         out_c = {'batch': b, 'ms_per_step': el / n * 1e3, 'value': fr * hop * n / el, 'unit': 'audio samples/s',
                  'rtf': el / (fr * hop * n / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': prec,
                  'roofline': wall_roofline(prec, step_flops(b, fr), step_bytes_bf16(b, fr), el / n)}
+        out_c['schedule'] = ('two HIP streams: FastPitch of step i+1 under HiFi-GAN of step i (ttsamd.pipeline)' if pipelined
+                             else 'one call after the other on one stream')
         if name:
             out_c['config'] = name
         return out_c
@@ -568,6 +584,9 @@ def main():
                                     'lengths rides in the step\'s one host synchronisation')
         if world == 1 and not args.no_small and B > 8:
             out['configs'] = [small_config(1), small_config(8)]
+            if args.precision == 'f32' and not args.pipeline and B == 32:
+                out['configs'].append(small_config(B, pipelined=True, name='C2 (this line\'s workload) on the two-stream schedule: FastPitch of '
+                                                                          'step i+1 under HiFi-GAN of step i, same work and results per step'))
             if not args.no_extra:
                 out['configs'] += extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync)
         if world == 1 and not args.no_extra:
@@ -612,8 +631,14 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
     from ttsamd.config import NET_CONFIG, TACOTRON2_CONFIG, HIFIGAN_CONFIG
     res = []
     B = ids.shape[0]
-    res.append(small_config(B, prec='bf16', name=f'C3 per-GPU share: FastPitch+HiFi-GAN, synthetic 64-phoneme x batch{B}, bf16 MFMA '
-                                                 '(HiFi-GAN and the FastPitch FFT blocks on the bf16 octet engine)'))
+    # the throughput configuration runs the two-stream schedule (FastPitch of batch i+1 under HiFi-GAN of batch i: FastPitch is 18 % of
+    # a bf16 step and mostly launch- and latency-bound); the one-stream time of the same work rides along.  Batch 8 / 1 are latency
+    # numbers: one call after the other on one stream.
+    c3 = small_config(B, prec='bf16', pipelined=True,
+                      name=f'C3 per-GPU share: FastPitch+HiFi-GAN, synthetic 64-phoneme x batch{B}, bf16 MFMA '
+                           '(HiFi-GAN and the FastPitch FFT blocks on the bf16 octet engine)')
+    c3['ms_per_step_one_stream'] = small_config(B, prec='bf16')['ms_per_step']
+    res.append(c3)
     for b_small in (8, 1):                          # north star: batch 1 / 8 / 32 -- the bf16 configuration at the small batches too
         res.append(small_config(b_small, prec='bf16', name=f'C3 at batch {b_small}: FastPitch+HiFi-GAN, synthetic 64-phoneme, bf16 MFMA'))
     n = max(args.steps, 10)

@@ -5,4 +5,14 @@ this package only moves pointers: PyTorch-ROCm tensors supply device memory and 
 current stream.  There is NO CPU / PyTorch fallback: importing `ttsamd.lib` without the
 built shared object, or running an engine without a gfx950 device, raises.
 """
+import os as _os
+
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a
+# queue run one after the other.  The path uses up to seven at once (caller's stream, the two stages of ttsamd.pipeline, the two
+# ResBlock branch streams of HiFi-GAN, the list pipeline's copy stream): with four queues the FastPitch stage of the pipeline
+# lands on a vocoder queue whenever a one-stream call came first and nothing overlaps (bf16 B=32: 11.7 ms per step instead of
+# 10.2, tools/pipe_debug.py).  Read by the runtime when it initialises, i.e. before the first GPU call of the process: set
+# here unless the user chose a value; a process that touched the GPU before importing ttsamd keeps its own setting.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 from .config import NET_CONFIG, HIFIGAN_CONFIG, SAMPLE_RATE, HOP  # noqa: F401
