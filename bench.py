@@ -694,18 +694,31 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
             spk[0] = (spk[0] + 1) % 4
             mel, dl, *_ = fp4.infer(ids, dur_tgt=dur, speaker=spk[0])
             return voc.forward(mel, dl), dl
-        for _ in range(3):
-            c5()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            _, dl = c5()
-        sync()
-        el = (time.perf_counter() - t0) / n
+        from ttsamd.pipeline import FastPitchHifiGan
+        pipe5 = FastPitchHifiGan(fp4, voc, dev)                  # the same two-stream schedule with Vocos as the second stage
+
+        def c5p():
+            spk[0] = (spk[0] + 1) % 4
+            _, dl, wave = pipe5.submit(ids, vocode=voc.forward, dur_tgt=dur, speaker=spk[0])
+            return wave, dl
+
+        def timed(f):
+            for _ in range(3):
+                f()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                _, dl_ = f()
+            sync()
+            return (time.perf_counter() - t0) / n, dl_
+        el1, dl = timed(c5)
+        el, dl = timed(c5p)
         fr = int(dl.sum().item())
         dec_fpt, enc_fpt = fastpitch_conv_flops_per_pos(cfg4)
         flops = VOCOS_FLOPS_PER_FRAME * fr + dec_fpt * (fr + B) + enc_fpt * B * ids.shape[1]
         res.append({'config': f'C5 FastPitch 4-speaker + MelVocos(22k) (ISTFT head), batch {B}, fp32', 'batch': B, 'ms_per_step': el * 1e3,
+                    'ms_per_step_one_stream': el1 * 1e3,
+                    'schedule': 'two HIP streams: FastPitch of step i+1 under Vocos of step i (ttsamd.pipeline)',
                     'value': fr * hop / el, 'unit': 'audio samples/s', 'rtf': el / (fr * hop / SAMPLE_RATE), 'frames': fr, 'steps': n,
                     'dtype': 'f32', 'roofline': wall_roofline('f32', flops, 0.0, el)})
     except Exception as e:                                       # noqa: BLE001

@@ -24,13 +24,15 @@ TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYC
 FRAMES=$(python3 -c "import json;print(json.load(open('$O/final_bench_line.json'))['config']['frames_per_step_rank0'])")
 python3 profiles/traffic_from_pmc.py $O/pmc_fetch $O/pmc_write $O/conv_log.csv $FRAMES $O/traffic_calib.json > $O/traffic.json
 for p in bf16x3 bf16; do python3 bench.py --precision $p --no-cpu-baseline --no-extra > $O/${p}_bench_line.json 2>> $O/bench.err; done
+# bf16 runs the two-stream schedule by default (FastPitch of step i+1 under HiFi-GAN of step i); the one-stream line of the same work:
+python3 bench.py --precision bf16 --no-pipeline --no-cpu-baseline --no-small --no-extra > $O/bf16_one_stream_bench_line.json 2>> $O/bench.err
 # config 3 (bf16 octet engine): kernel stats (three streams / one stream), HBM traffic and MFMA counters of the same command
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats -- python3 bench.py --precision bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-small --no-extra > $O/bstats.log 2>&1
-TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats1 -- python3 bench.py --precision bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-small --no-extra > $O/bstats1.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats1 -- python3 bench.py --precision bf16 --no-pipeline --steps 5 --warmup 2 --no-cpu-baseline --no-small --no-extra > $O/bstats1.log 2>&1
 rm -f $O/conv_log_bf16.csv
-TTSAMD_HIFIGAN_STREAMS=0 TTSAMD_CONV_LOG=$O/conv_log_bf16.csv rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/bpmc_fetch -- python3 bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/bpmc_fetch.log 2>&1
-TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/bpmc_write -- python3 bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/bpmc_write.log 2>&1
-TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/bpmc_mfma -- python3 bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/bpmc_mfma.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 TTSAMD_CONV_LOG=$O/conv_log_bf16.csv rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/bpmc_fetch -- python3 bench.py --precision bf16 --no-pipeline --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/bpmc_fetch.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/bpmc_write -- python3 bench.py --precision bf16 --no-pipeline --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/bpmc_write.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/bpmc_mfma -- python3 bench.py --precision bf16 --no-pipeline --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/bpmc_mfma.log 2>&1
 python3 profiles/traffic_from_pmc.py $O/bpmc_fetch $O/bpmc_write $O/conv_log_bf16.csv $FRAMES $O/traffic_calib.json > $O/traffic_bf16.json
 python3 profiles/summarize.py $(ls $O/bstats/*/*kernel_trace.csv | head -1) > $O/bf16_by_grid.txt
 python3 profiles/summarize.py $(ls $O/bstats1/*/*kernel_trace.csv | head -1) > $O/bf16_by_grid_one_stream.txt
