@@ -38,3 +38,14 @@ def test_product_path_never_imports_oracle():
                 with open(os.path.join(dp_, fn), encoding='utf-8') as f:
                     src = f.read()
                 assert 'tts_oracle' not in src and 'import oracle' not in src, os.path.join(dp_, fn)
+
+
+def test_package_import_asks_for_one_hardware_queue_per_stream():
+    """ttsamd/__init__.py: GPU_MAX_HW_QUEUES=8 unless the user chose a value (read by the HIP runtime at its first GPU call)."""
+    import subprocess
+    import sys
+    code = "import os, sys; sys.path.insert(0, %r); import ttsamd; print(os.environ['GPU_MAX_HW_QUEUES'])" % os.path.join(REPO, 'tts-arabic-pytorch_amd')
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == '8'
+    env['GPU_MAX_HW_QUEUES'] = '2'
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == '2'
