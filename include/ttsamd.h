@@ -277,6 +277,13 @@ int32_t ttsamd_bfo_resblock_pair(const void* x, const void* w1, const float* b1,
                                  const void* sum_in, const int64_t* lens, int32_t len_mul, int32_t batch, int32_t channels,
                                  int32_t k, int32_t dilation, int32_t len, int32_t mode, float div, float in_slope,
                                  float mid_slope, float out_slope, void* y, void* stream);
+/* a whole k = 3 ResBlock1 (the three pairs of models.py:46-53 with dilations[0..2], C in {32, 64, 128}) in one launch; w1 / b1 / w2 /
+ * b2 are arrays of three device pointers.  Equals three ttsamd_bfo_resblock_pair calls (out_slope = in_slope between them, mode /
+ * sum_in / out_slope on the last) bit for bit. */
+int32_t ttsamd_bfo_resblock_chain(const void* x, const void* const* w1, const float* const* b1, const void* const* w2,
+                                  const float* const* b2, const int32_t* dilations, const void* sum_in, const int64_t* lens,
+                                  int32_t len_mul, int32_t batch, int32_t channels, int32_t len, int32_t mode, float div,
+                                  float in_slope, float mid_slope, float out_slope, void* y, void* stream);
 /* wave[b][t] = tanh(bias + conv7(x)); x = 32-channel octet tensor already activated with slope 0.01 (models.py:123-125) */
 int32_t ttsamd_bfo_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul,
                              int32_t batch, int32_t channels, int32_t len, float* wave, int64_t wave_stride, void* stream);

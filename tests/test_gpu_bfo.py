@@ -103,6 +103,41 @@ def test_resblock_pair(dev, monkeypatch, C, k, dil, L, mode, out_slope, small_ti
         assert torch.equal(got[i, :, n:], before[i, :, n:]), 'positions past the utterance must stay untouched'
 
 
+@pytest.mark.parametrize('C,L,mode,out_slope,B', [(128, 700, 0, 1.0, 3), (64, 900, 1, 1.0, 3), (32, 1500, 2, 0.1, 3), (128, 300, 2, 0.01, 70)])
+def test_resblock_chain_equals_three_pairs_bit_for_bit(dev, C, L, mode, out_slope, B):
+    """The whole k = 3 ResBlock in one launch (bfo_chain.hip) against three fused-pair launches of the same weights: identical bits
+    (the chained kernel rounds the tensor between two pairs exactly where the pair launch rounds it for HBM).  Ragged batch: an
+    utterance ending inside the 24-column halo of a 232-column tile, one shorter than a tile, (last case) more than 64 utterances."""
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(C + L + mode)
+    dils = (1, 3, 5)
+    x = torch.randn(B, C, L, generator=g) * 1.5
+    ws = [[torch.randn(C, C, 3, generator=g) / np.sqrt(C * 3) for _ in range(3)] for _ in range(2)]
+    bs = [[torch.randn(C, generator=g) * 0.3 for _ in range(3)] for _ in range(2)]
+    s_raw = torch.randn(B, C, L, generator=g)
+    ts = {128: 256, 64: 256, 32: 512}[C] - 24
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2] = L, min(L, ts + 5), max(1, min(L, ts) - 9)
+    lens_d = lens.to(dev)
+    xo, so = bfo.pack(x.to(dev), 0.1), bfo.pack(s_raw.to(dev), 1.0)
+    w1p, w2p = [bfo.pack_weight(w, device=dev) for w in ws[0]], [bfo.pack_weight(w, device=dev) for w in ws[1]]
+    b1d, b2d = [b.to(dev) for b in bs[0]], [b.to(dev) for b in bs[1]]
+    # three pair launches, as csrc/hifigan.hip issues them
+    t = xo
+    for m in range(3):
+        last = m == 2
+        y = (so.clone() if mode != 0 else torch.full_like(xo, 0x4242)) if last else torch.zeros_like(xo)
+        bfo.resblock_pair(t, w1p[m], b1d[m], w2p[m], b2d[m], 3, dils[m], lens=lens_d, sum_in=y if (last and mode != 0) else None,
+                          mode=mode if last else 0, div=3.0, out_slope=out_slope if last else 0.1, y=y)
+        t = y
+    ref = t
+    y = so.clone() if mode != 0 else torch.full_like(xo, 0x4242)
+    bfo.resblock_chain(xo, w1p, b1d, w2p, b2d, dils, lens=lens_d, sum_in=y if mode != 0 else None, mode=mode, div=3.0,
+                       out_slope=out_slope, y=y)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+
+
 @pytest.mark.parametrize('cin,cout,k,dil,L,mode,res', [
     (256, 256, 3, 1, 600, 0, False), (256, 256, 7, 3, 300, 1, True), (256, 256, 11, 5, 515, 2, True),
     (80, 512, 7, 1, 90, 0, False), (128, 64, 3, 1, 700, 0, False), (64, 32, 7, 1, 1500, 0, True), (512, 128, 1, 1, 100, 0, False),

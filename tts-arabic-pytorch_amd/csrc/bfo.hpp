@@ -47,6 +47,26 @@ struct BfoPairParams {
     unsigned long long* timing;   // tools/bfo_pair_bench -DBFO_TIMING only: [blocks][16] shader-clock stamps (nullptr otherwise)
 };
 
+// A whole k = 3 ResBlock1 (three c1 -> c2 pairs, vocoder/hifigan/models.py:46-53) in one launch: bfo_chain.hip
+struct BfoChainParams {
+    const void* x;         // [B][C/8][L][8] bf16, activated with in_slope: input of the first pair
+    void* y;               // output of the LAST pair, same layout; must not alias x
+    const void* sum_in;    // mode != 0: running ResBlock sum, RAW bf16 (may alias y)
+    const void* w1[3];     // packed bf16 [C/16][3][2][C][8] per pair
+    const void* w2[3];
+    const float* b1[3];
+    const float* b2[3];
+    const int64_t* lens;
+    int32_t len_mul, L, batch;
+    int32_t dil[3];        // dilation of each pair's first conv
+    int32_t mode;          // applied to the last pair's output, as BfoPairParams::mode
+    float div;
+    float in_slope;        // activation x is stored with AND the one between the pairs (0.1)
+    float mid_slope;       // leaky-relu between c1 and c2 (0.1)
+    float out_slope;       // of the last pair's output; 1 = raw
+    int32_t compact;       // set by the launcher
+};
+
 struct BfoConvParams {
     const void* x;         // [B][Cin/8][Lin][8] bf16, already activated (plain copy into LDS)
     void* y;               // [B][Cout/8][Lout][8] bf16 (Lout = Lin * up)
@@ -76,6 +96,9 @@ struct BfoConvParams {
 // kernel-level launchers (bfo_pair.hip, bfo_conv.hip)
 bool bfo_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L);
 int32_t bfo_launch_pair(int32_t channels, int32_t k, const BfoPairParams& p, hipStream_t s);
+// a whole k = 3 ResBlock in one launch (bfo_chain.hip); TTSAMD_BFO_CHAIN=0: three pair launches
+bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch);
+int32_t bfo_launch_chain(int32_t channels, const BfoChainParams& p, hipStream_t s);
 int32_t bfo_launch_conv(const BfoConvParams& p, hipStream_t s);
 int32_t bfo_launch_convt(const BfoConvParams& p, hipStream_t s);
 // fp32 channel-first [B][C][L] <-> octet bf16 (leaky-relu with `slope` on the way in, its inverse on the way out)

@@ -51,7 +51,13 @@ static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
     if (h->cfg.n_kernels != 3) return false;
     const char* env = std::getenv("TTSAMD_HIFIGAN_STREAMS");   // read per call: the tests flip it
     if (env) return env[0] == '1';
-    (void)B; (void)T;
+    // bf16 octet engine: the launches are power-bound at batch 32 and latency-bound below; the fork / join events cost more than the
+    // overlap returns under ~8 k frames (batch 1: 2.09 -> 1.92 ms, batch 8: 4.35 -> 4.26 on one stream; batch 32: 10.02 -> 9.88 ms with
+    // three under the two-stream pipeline)
+    if (default_precision() == 1 && h->bfo_ok) {
+        const char* bfo_env = std::getenv("TTSAMD_BFO");
+        if (!(bfo_env && bfo_env[0] == '0')) return (int64_t)B * T >= 8192;
+    }
     return true;
 }
 
@@ -142,6 +148,8 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
     blob.resize(align_up((int64_t)blob.size(), 64));
     return get_bias(tm, base, cout, blob, cw.b_off);
 }
+
+__global__ void hifigan_touch_kernel() {}   // first dispatch of a branch stream (hifigan_create)
 
 int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hifigan_cfg* cfg, HifiGan** out) {
     TTS_REQUIRE(weights && cfg && out, "hifigan_create: null argument");
@@ -247,6 +255,28 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
         if (e != hipSuccess) {
             set_error("hifigan_create: weight upload failed: %s", hipGetErrorString(e));
             rc = TTSAMD_EHIP;
+        }
+        // The two ResBlock branch streams exist and have dispatched once BEFORE the caller's own side streams do (the runtime
+        // binds a stream to a hardware queue at its first dispatch).  Created lazily inside the first forward they were bound
+        // after the two ttsamd.pipeline streams whenever that schedule ran first, and every later one-stream call paid 1.2-1.9 ms
+        // for its fork / join events (batch 1: 3.3 instead of 2.1 ms, tools/pipe_debug2.py).
+        if (e == hipSuccess && cfg->n_kernels == 3) {
+            for (auto& st : h->side)
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+            for (auto& ev : h->ev_done)
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            for (auto& st : h->side)
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(hifigan_touch_kernel, dim3(1), dim3(64), 0, st);
+                    e = hipGetLastError();
+                }
+            for (auto& st : h->side)
+                if (e == hipSuccess && st) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                set_error("hifigan_create: branch streams: %s", hipGetErrorString(e));
+                rc = TTSAMD_EHIP;
+            }
         }
     }
     if (rc != 0) {
@@ -401,6 +431,34 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                 void *Tb = Tbs[j % 3], *R = Rs[j % 3];
                 if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
                 const void* src = upso;
+                {
+                    // a k = 3 ResBlock whose three pairs fit the chained kernel goes out as ONE launch (bfo_chain.hip; bit-identical)
+                    const int li0 = (i * cfg.n_kernels + j) * cfg.n_dilations;
+                    int32_t dl[3] = {0, 0, 0};
+                    for (int m = 0; m < cfg.n_dilations && m < 3; ++m) dl[m] = cfg.resblock_dilations[j][m];
+                    if (bfo_chain_supported(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B)) {
+                        BfoChainParams cc;
+                        std::memset(&cc, 0, sizeof(cc));
+                        cc.x = src; cc.y = curo; cc.sum_in = curo;
+                        for (int m = 0; m < 3; ++m) {
+                            const ConvW &w1 = h->c1[li0 + m], &w2 = h->c2[li0 + m];
+                            cc.w1[m] = W16 + w1.wo_off; cc.w2[m] = W16 + w2.wo_off; cc.b1[m] = h->dev + w1.b_off; cc.b2[m] = h->dev + w2.b_off;
+                            cc.dil[m] = dl[m];
+                        }
+                        cc.lens = lens; cc.len_mul = mul; cc.L = L; cc.batch = B;
+                        cc.mode = cfg.n_kernels == 1 ? 0 : (j == 0 ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2));
+                        cc.div = (float)cfg.n_kernels; cc.in_slope = 0.1f; cc.mid_slope = 0.1f;
+                        cc.out_slope = j + 1 == cfg.n_kernels ? next_slope : 1.f;
+                        if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
+                        const double fl = 3 * 2.0 * (2.0 * h->c1[li0].cin * h->c1[li0].cin * 3) * mul;
+                        if (in_section) prof_add(fl); else prof_begin(st, fl);
+                        rc = bfo_launch_chain(h->c1[li0].cin, cc, st);
+                        if (!in_section) prof_end(st);
+                        HG_TRY(rc);
+                        if (multi) HG_CHECK_HIP(hipEventRecord(h->ev_done[j], st));
+                        continue;
+                    }
+                }
                 for (int m = 0; m < cfg.n_dilations; ++m) {
                     const int li = (i * cfg.n_kernels + j) * cfg.n_dilations + m;
                     const int d = cfg.resblock_dilations[j][m];
