@@ -731,8 +731,8 @@ VOCOS_FLOPS_PER_FRAME = 26.85e6      # MelVocos('22k'), conv / line
 
 def hifigan_octet_bytes_per_frame(h):
     """Algorithmic HBM bytes per mel frame of the HiFi-GAN conv launches on the bf16 octet engine: every
-    tensor crosses HBM as bf16; a fused c1 -> c2 pair (C <= 128) reads its input once and writes once; at C = 256 c1 and c2
-    are two launches (read + write, read + residual + write); the two accumulating last pairs of a stage re-read the sum."""
+    tensor crosses HBM as bf16; a fused c1 -> c2 pair (C <= 128) reads its input once and writes once, a whole k = 3 ResBlock
+    (three pairs) likewise; at C = 256 c1 and c2 are two launches (read + write, read + residual + write); the two accumulating last pairs of a stage re-read the sum."""
     c0 = h['upsample_initial_channel']
     by = 2.0 * (h['num_mels'] + c0)
     ch, mul = c0, 1
@@ -741,8 +741,9 @@ def hifigan_octet_bytes_per_frame(h):
         by += 2.0 * (ch * mul + (ch // 2) * mul * u)
         ch, mul = ch // 2, mul * u
         per_pair = 2.0 * (2 if ch <= 128 else 5) * ch * mul
-        for dil in h['resblock_dilation_sizes']:
-            by += len(dil) * per_pair
+        for k, dil in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+            # a k = 3 ResBlock at C <= 128 is ONE launch (bfo_chain.hip): one read + one write for its three pairs
+            by += per_pair if (k == 3 and ch <= 128 and len(dil) == 3) else len(dil) * per_pair
         by += 2.0 * (nk - 1) * ch * mul
     return by
 
