@@ -9,7 +9,7 @@ rows = defaultdict(lambda: [0, 0])
 conv_iv = []          # (start, end) of every MFMA conv launch: their UNION is the conv engine's busy time
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        if any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'convt_mfma', 'bfo_conv1d', 'bfo_convt')):
+        if any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'resblock_chain', 'convt_mfma', 'bfo_conv1d', 'bfo_convt')):
             conv_iv.append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
         key = (r['Kernel_Name'][:100], int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']),
                int(r['Grid_Size_Y']), int(r['Grid_Size_Z']), r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size'])

@@ -19,7 +19,7 @@ def dispatches(d, counter):
     rows = {}
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'convt_mfma', 'bfo_conv1d', 'bfo_convt')):
+            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'resblock_chain', 'convt_mfma', 'bfo_conv1d', 'bfo_convt')):
                 k = int(r['Dispatch_Id'])
                 name = r['Kernel_Name'].split('(')[0].replace('void ttsamd::', '')
                 g = None
@@ -59,7 +59,7 @@ def main():
             L = frames * len_mul if ragged else nout * batch          # valid positions summed over the batch
             if kind == 'fused_pair':
                 alg = 4.0 * cin * L * (2 + (mode != 0))
-            elif kind == 'bfo_pair':                                  # bf16 octet engine: bf16 tensors, one read + one write per pair
+            elif kind in ('bfo_pair', 'bfo_chain'):                   # bf16 octet engine: bf16 tensors, one read + one write per pair / chained ResBlock
                 alg = 2.0 * cin * L * (2 + (mode != 0))
             elif kind == 'bfo':
                 alg = 2.0 * (cin * L + cout * L * (1 + has_res + (mode != 0)))
