@@ -66,6 +66,12 @@ def main():
             b1, b2 = rnd(C), rnd(C)
             timeit(lambda: bfo.resblock_pair(x, w1, b1, w2, b2, k, d, y=y), 2 * 2.0 * C * C * k * L * B, 2 * 2.0 * C * L * B,
                    f'pair C={C} k={k} d={d} L={L}')
+        # the whole k = 3 ResBlock (three pairs, dilations 1 / 3 / 5) as one launch: FLOPs and bytes of the ALGORITHM (three pairs' FLOPs,
+        # one read + one write), so the line compares with three 'pair k=3' lines
+        ws = [[bfo.pack_weight(torch.randn(C, C, 3, generator=g) / np.sqrt(C * 3), device=dev) for _ in range(3)] for _ in range(2)]
+        bs = [[rnd(C) for _ in range(3)] for _ in range(2)]
+        timeit(lambda: bfo.resblock_chain(x, ws[0], bs[0], ws[1], bs[1], (1, 3, 5), y=y), 3 * 2 * 2.0 * C * C * 3 * L * B, 2 * 2.0 * C * L * B,
+               f'chain C={C} k=3 (3 pairs) L={L}')
         del x, y
     C, L = 256, T * 8
     x = bfo.pack(rnd(B, C, L), 0.1)
