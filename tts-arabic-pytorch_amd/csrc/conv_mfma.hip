@@ -792,7 +792,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
 #ifdef TTS_WITH_DIRECT   /* tools/conv_bench.hip only: A/B against tools/conv_direct_f32.hip (round 3, no gain: DESIGN.md §4) */
     {
         const char* de = getenv("TTSAMD_DIRECT");
-        if (!(de && de[0] == '0') && direct_supported(p)) return launch_direct(p, stream);
+        if (de && de[0] == '1' && direct_supported(p)) return launch_direct(p, stream);   // opt in: the tool's default is the product kernel
     }
 #endif
 #ifdef TTS_ONLY_K   /* kernel experiments: compile one kernel size only (tools/conv_bench, 10 s instead of 90 s) */
