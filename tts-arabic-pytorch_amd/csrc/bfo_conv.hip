@@ -226,6 +226,106 @@ __global__ __launch_bounds__(256) void bfo_splitk_reduce(const BfoConvParams p) 
     reinterpret_cast<uint4*>(p.y)[ent] = w;
 }
 
+// Split-K reduction + epilogue + LayerNorm in one launch (fp32 channel-first output): block = 32 positions x 8 channel groups as
+// layernorm_cf_octet_kernel, whose arithmetic it repeats on values summed exactly as bfo_splitk_reduce sums them -- the result
+// equals the two launches bit for bit.
+// CPG = channels per thread group = Cout / 8, a compile-time constant (a run-time bound on the unrolled loops puts every load
+// behind its own branch and its own vmcnt(0): 48 serial memory round trips)
+constexpr int LNO_MAXV_R = 64;
+template <int CPG>
+__global__ __launch_bounds__(256) void bfo_splitk_reduce_ln(const BfoConvParams p, float eps) {
+    __shared__ float red[8][32];
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int S = p.Lin, C = p.Cout;
+    const int t = blockIdx.x * 32 + tl;
+    const bool ok = t < S;
+    const int tc = ok ? t : 0;
+    int len = S;
+    if (p.lens && !p.out_all) len = min(len, (int)p.lens[b] * p.len_mul);
+    constexpr int cpg = CPG; const int c0 = g * cpg;
+    const int64_t per = (int64_t)p.batch * C * S;
+    const float* __restrict__ rp = (p.res_f32 ? p.res_f32 : p.splitk_ws) + ((int64_t)b * C + c0) * S + tc;   // no residual: any readable address
+    const bool has_res = p.res_f32 != nullptr, has_bias = p.bias != nullptr;
+    const float* __restrict__ bp = (has_bias ? p.bias : p.ln_g) + c0;
+    float* __restrict__ yb = p.y_f32 + ((int64_t)b * C + c0) * S + tc;
+    const float* __restrict__ lg = p.ln_g + c0;
+    const float* __restrict__ lb = p.ln_b + c0;
+    float v[CPG];
+#pragma unroll
+    for (int i = 0; i < CPG; ++i) v[i] = 0.f;
+    const bool live = tc < len;                      // past the conv's outputs: what the separate LayerNorm launch would have read
+    // slice by slice, all of the thread's channels per slice in flight at once; per element the sum runs in slice order from 0
+    // exactly as in bfo_splitk_reduce
+    // buffer loads: one per-lane offset + a scalar offset per (slice, channel) -- flat loads need a 64-bit address per load in
+    // flight and the compiler then keeps only two in flight (48 x ksplit memory round trips in pairs)
+    {
+        const bfo_i4 prs = bfo_rsrc(p.splitk_ws, (unsigned)(per * p.ksplit * 4));
+        const int vb = (int)((((int64_t)b * C + c0) * S + tc) * 4);
+        for (int ks = 0; ks < p.ksplit; ++ks) {
+            const int sb = (int)(ks * per * 4);
+            float tq[CPG];
+#pragma unroll
+            for (int i = 0; i < CPG; ++i) tq[i] = bfo_ld4f(prs, vb, sb + i * S * 4, 0);   // unconditional; discarded below when !live
+            __builtin_amdgcn_sched_barrier(0);            // all of the slice's loads in flight (left alone: two at a time)
+#pragma unroll
+            for (int i = 0; i < CPG; ++i) v[i] += tq[i];
+        }
+    }
+    const int bmask = has_bias ? -1 : 0, rmask = has_res ? -1 : 0, lmask = live ? -1 : 0;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPG; ++i) {
+        float x = 0.f;
+        if (i < cpg) {
+            // unconditional loads, selected with bit masks (a ?: lets the compiler sink each load into its own exec-masked branch)
+            const float bv = bp[i], rv = rp[(int64_t)i * S], old = yb[(int64_t)i * S];
+            const float a = v[i] + __builtin_bit_cast(float, __builtin_bit_cast(int, bv) & bmask);
+            const float yv = bfo_lrelu(a + __builtin_bit_cast(float, __builtin_bit_cast(int, rv) & rmask), p.out_slope);
+            x = __builtin_bit_cast(float, (__builtin_bit_cast(int, yv) & lmask) | (__builtin_bit_cast(int, old) & ~lmask));
+        }
+        v[i] = x;
+        sum += x;
+    }
+    red[g][tl] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][tl];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPG; ++i) {
+        const float d = (i < cpg) ? v[i] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+    }
+    red[g][tl] = sq;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][tl];
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+    if (!ok) return;
+    float m = 1.f;
+    if (p.ln_lens && t >= (int)p.ln_lens[b]) m = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPG; ++i)
+        if (i < cpg) {
+            v[i] = ((v[i] - mean) * rstd * lg[i] + lb[i]) * m;
+            yb[(int64_t)i * S] = v[i];
+        }
+    uint4* yo = reinterpret_cast<uint4*>(p.ln_octet);
+#pragma unroll
+    for (int o = 0; o < CPG / 8; ++o)
+        if (8 * o < cpg) {
+            uint4 w;
+            w.x = (unsigned)bfo_pk(v[8 * o], v[8 * o + 1]); w.y = (unsigned)bfo_pk(v[8 * o + 2], v[8 * o + 3]);
+            w.z = (unsigned)bfo_pk(v[8 * o + 4], v[8 * o + 5]); w.w = (unsigned)bfo_pk(v[8 * o + 6], v[8 * o + 7]);
+            yo[((int64_t)b * (C / 8) + c0 / 8 + o) * S + t] = w;
+        }
+}
+
 template <int K, int WM, int WN, int NT, bool OUT_F32>
 static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream) {
     BfoConvParams p = p_in;
@@ -261,10 +361,28 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream
     grid.y *= p.ksplit;
     hipLaunchKernelGGL((bfo_conv1d<K, WM, WN, NT, OUT_F32>), grid, dim3(256), G::LDS, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
+    const bool ln = p.ln_g != nullptr;
+    if (ln) TTS_REQUIRE(OUT_F32 && p.y_f32 && p.ln_b && p.ln_octet && p.Cout % 64 == 0 && p.Cout <= 8 * LNO_MAXV_R,
+                        "bfo conv: the LayerNorm epilogue needs the fp32 output and Cout %% 64 == 0, <= %d (Cout=%d)", 8 * LNO_MAXV_R, p.Cout);
+    const char* fle = getenv("TTSAMD_BFO_FUSED_LN");           // 0: reduction and LayerNorm as two launches (A/B, parity tests)
+    const bool fuse_ln = !(fle && fle[0] == '0') && (p.Cout == 256 || p.Cout == 384 || p.Cout == 512) &&
+                         (int64_t)p.batch * p.Cout * p.Lin * 4 * 4 < ((int64_t)1 << 31);      // 32-bit buffer offsets over <= 4 slices
     if (p.ksplit > 1) {
-        dim3 rg((p.Lin + 255) / 256, p.Cout / 8, p.batch);
-        hipLaunchKernelGGL(bfo_splitk_reduce, rg, dim3(256), 0, stream, p);
+        if (ln && fuse_ln) {
+            dim3 rg((p.Lin + 31) / 32, p.batch);
+            if (p.Cout == 384) hipLaunchKernelGGL(bfo_splitk_reduce_ln<48>, rg, dim3(256), 0, stream, p, 1e-5f);
+            else if (p.Cout == 256) hipLaunchKernelGGL(bfo_splitk_reduce_ln<32>, rg, dim3(256), 0, stream, p, 1e-5f);
+            else if (p.Cout == 512) hipLaunchKernelGGL(bfo_splitk_reduce_ln<64>, rg, dim3(256), 0, stream, p, 1e-5f);
+            else { set_error("bfo conv: LayerNorm epilogue is built for 256 / 384 / 512 channels (Cout=%d)", p.Cout); return TTSAMD_EINVAL; }
+        } else {
+            dim3 rg((p.Lin + 255) / 256, p.Cout / 8, p.batch);
+            hipLaunchKernelGGL(bfo_splitk_reduce, rg, dim3(256), 0, stream, p);
+        }
         TTS_CHECK_HIP(hipGetLastError());
+    }
+    if (ln && !(p.ksplit > 1 && fuse_ln)) {
+        return launch_layernorm_cf_octet(p.y_f32, p.y_f32, p.ln_octet, p.ln_g, p.ln_b, p.ln_lens, p.ln_lens != nullptr, p.batch, p.Cout,
+                                         p.Lin, stream);
     }
     return 0;
 }
@@ -487,6 +605,9 @@ __global__ __launch_bounds__(256) void bfo_unpack_kernel(const uint4* __restrict
 // octet bf16 entries: the input copy of the conv that follows (FastPitch under config 3).  Block = 32 positions x 8 channel groups;
 // group g owns the CONTIGUOUS channels [g C/8, (g+1) C/8) = C/64 whole octets, so its entries are complete in one thread.
 constexpr int LNO_MAXV = 64;
+// CPG_ = C / 8 as a compile-time constant (48: d_model 384, 32: the predictors' 256), or 0 = run-time bound: then every load sits
+// behind its own branch and vmcnt(0) (48 serial round trips: 10-12 us per launch at batch 1 against 5-6)
+template <int CPG_>
 __global__ __launch_bounds__(256) void layernorm_cf_octet_kernel(const float* __restrict__ x, float* __restrict__ y, uint4* __restrict__ yo,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const int64_t* __restrict__ lens, int apply_mask, int C, int S, float eps) {
@@ -495,12 +616,13 @@ __global__ __launch_bounds__(256) void layernorm_cf_octet_kernel(const float* __
     const int tl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int t = blockIdx.x * 32 + tl;
     const bool ok = t < S;
-    const int cpg = C / 8, c0 = g * cpg;
+    const int cpg = CPG_ ? CPG_ : C / 8, c0 = g * cpg;
+    constexpr int NV = CPG_ ? CPG_ : LNO_MAXV;
     const float* xb = x + ((int64_t)b * C + c0) * S + (ok ? t : 0);
-    float v[LNO_MAXV];
+    float v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LNO_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         v[i] = (i < cpg) ? xb[(int64_t)i * S] : 0.f;
         sum += v[i];
     }
@@ -513,7 +635,7 @@ __global__ __launch_bounds__(256) void layernorm_cf_octet_kernel(const float* __
     __syncthreads();
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < LNO_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const float d = (i < cpg) ? v[i] - mean : 0.f;
         sq = fmaf(d, d, sq);
     }
@@ -528,13 +650,13 @@ __global__ __launch_bounds__(256) void layernorm_cf_octet_kernel(const float* __
     if (apply_mask && lens && t >= (int)lens[b]) m = 0.f;
     float* yb = y + ((int64_t)b * C + c0) * S + t;
 #pragma unroll
-    for (int i = 0; i < LNO_MAXV; ++i)
+    for (int i = 0; i < NV; ++i)
         if (i < cpg) {
             v[i] = ((v[i] - mean) * rstd * gamma[c0 + i] + beta[c0 + i]) * m;
             yb[(int64_t)i * S] = v[i];
         }
 #pragma unroll
-    for (int o = 0; o < LNO_MAXV / 8; ++o)
+    for (int o = 0; o < NV / 8; ++o)
         if (8 * o < cpg) {
             uint4 w;
             w.x = (unsigned)bfo_pk(v[8 * o], v[8 * o + 1]); w.y = (unsigned)bfo_pk(v[8 * o + 2], v[8 * o + 3]);
@@ -548,7 +670,9 @@ int32_t launch_layernorm_cf_octet(const float* x, float* y, void* y_octet, const
     TTS_REQUIRE(C % 64 == 0 && C <= 8 * LNO_MAXV && y_octet, "layernorm (octet): C %% 64 must be 0 and C <= %d (C=%d)", 8 * LNO_MAXV, C);
     if (S <= 0 || B <= 0) return 0;
     dim3 grid((S + 31) / 32, B);
-    hipLaunchKernelGGL(layernorm_cf_octet_kernel, grid, dim3(256), 0, s, x, y, (uint4*)y_octet, gamma, beta, lens, apply_mask, C, S, eps);
+    if (C == 384) hipLaunchKernelGGL(layernorm_cf_octet_kernel<48>, grid, dim3(256), 0, s, x, y, (uint4*)y_octet, gamma, beta, lens, apply_mask, C, S, eps);
+    else if (C == 256) hipLaunchKernelGGL(layernorm_cf_octet_kernel<32>, grid, dim3(256), 0, s, x, y, (uint4*)y_octet, gamma, beta, lens, apply_mask, C, S, eps);
+    else hipLaunchKernelGGL(layernorm_cf_octet_kernel<0>, grid, dim3(256), 0, s, x, y, (uint4*)y_octet, gamma, beta, lens, apply_mask, C, S, eps);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }

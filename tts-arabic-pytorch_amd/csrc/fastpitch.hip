@@ -289,8 +289,11 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
         TTS_REQUIRE((int64_t)2 * (di + 2 * d + d_head) <= (int64_t)4 * di, "fastpitch: octet buffers do not fit the hidden buffer");
         TTS_TRY(bfo_launch_pack(x, B, d, S, 1.f, xo, s));
         BfoConvParams cp;
-        auto conv = [&](const PConv& c, const void* in, void* out_o, float* out_f, const float* res_f, float out_slope) -> int32_t {
+        // ln_g != nullptr: LayerNorm (masked with `lens`) over the fp32 result in place + its octet copy `ln_o` (BfoConvParams::ln_*)
+        auto conv = [&](const PConv& c, const void* in, void* out_o, float* out_f, const float* res_f, float out_slope,
+                        const float* ln_g = nullptr, const float* ln_b = nullptr, void* ln_o = nullptr) -> int32_t {
             std::memset(&cp, 0, sizeof(cp));
+            cp.ln_g = ln_g; cp.ln_b = ln_b; cp.ln_octet = ln_o; cp.ln_lens = ln_g ? lens : nullptr;
             cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
             cp.x = in; cp.y = out_o; cp.y_f32 = out_f; cp.res_f32 = res_f;
             cp.w = h->dev16 + c.wo_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
@@ -304,11 +307,9 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
         for (const FftLayer& l : layers) {
             TTS_TRY(conv(l.qkv, xo, nullptr, w.q, nullptr, 1.f));
             TTS_TRY(launch_attention_bf16(w.q, lens, B, d_head, S, scale, nullptr, s, ao));
-            TTS_TRY(conv(l.o_net, ao, nullptr, w.y, x, 1.f));
-            TTS_TRY(launch_layernorm_cf_octet(w.y, w.y, yo, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
+            TTS_TRY(conv(l.o_net, ao, nullptr, w.y, x, 1.f, h->dev + l.ln1_g, h->dev + l.ln1_b, yo));   // + LayerNorm 1 -> y, yo
             TTS_TRY(conv(l.ff0, yo, hid_o, nullptr, nullptr, 0.f));               // ReLU = leaky-relu with slope 0, applied by the producer
-            TTS_TRY(conv(l.ff2, hid_o, nullptr, x, w.y, 1.f));
-            TTS_TRY(launch_layernorm_cf_octet(x, x, xo, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
+            TTS_TRY(conv(l.ff2, hid_o, nullptr, x, w.y, 1.f, h->dev + l.ln2_g, h->dev + l.ln2_b, xo));  // + LayerNorm 2 -> x, xo
         }
         return 0;
     }
