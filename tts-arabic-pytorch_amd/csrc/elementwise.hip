@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
 // in registers between the mean, variance and normalise steps (1 read + 1 write of the tensor, 128 B
 // segments per wave-load); 4x more blocks than the kernel above, which matters at batch 1.
 constexpr int LN_TP = 32, LN_G = 8, LN_MAXV = 64;
+// NV_ = C / 8 as a compile-time constant (48: d_model 384, 32: the predictors' 256; C % 8 == 0, every thread owns exactly NV_
+// channels), or 0 = run-time bound: then each of the 64 predicated loads sits behind its own exec-masked branch and vmcnt(0)
+// (64 serial memory round trips: 12 us per launch at batch 1 against 5-6)
+template <int NV_>
 __global__ __launch_bounds__(256) void layernorm_cf_reg_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
@@ -167,12 +171,13 @@ __global__ __launch_bounds__(256) void layernorm_cf_reg_kernel(const float* __re
     const int t = blockIdx.x * LN_TP + tl;
     const bool ok = t < S;
     const float* xb = x + (int64_t)b * C * S + (ok ? t : 0);
-    float v[LN_MAXV];
+    constexpr int NV = NV_ ? NV_ : LN_MAXV;
+    float v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = g + LN_G * i;
-        v[i] = (c < C) ? xb[(int64_t)c * S] : 0.f;
+        v[i] = (NV_ || c < C) ? xb[(int64_t)c * S] : 0.f;
         sum += v[i];
     }
     red[g][tl] = sum;
@@ -184,8 +189,8 @@ __global__ __launch_bounds__(256) void layernorm_cf_reg_kernel(const float* __re
     __syncthreads();
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const float d = (g + LN_G * i < C) ? v[i] - mean : 0.f;
+    for (int i = 0; i < NV; ++i) {
+        const float d = (NV_ || g + LN_G * i < C) ? v[i] - mean : 0.f;
         sq = fmaf(d, d, sq);
     }
     red[g][tl] = sq;
@@ -199,9 +204,9 @@ __global__ __launch_bounds__(256) void layernorm_cf_reg_kernel(const float* __re
     if (apply_mask && lens && t >= (int)lens[b]) m = 0.f;
     float* yb = y + (int64_t)b * C * S + t;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = g + LN_G * i;
-        if (c < C) yb[(int64_t)c * S] = ((v[i] - mean) * rstd * gamma[c] + beta[c]) * m;
+        if (NV_ || c < C) yb[(int64_t)c * S] = ((v[i] - mean) * rstd * gamma[c] + beta[c]) * m;
     }
 }
 
@@ -210,7 +215,10 @@ int32_t launch_layernorm_cf(const float* x, float* y, const float* gamma, const 
     if (S <= 0 || B <= 0) return 0;
     if (C <= LN_G * LN_MAXV) {
         dim3 grid((S + LN_TP - 1) / LN_TP, B);
-        hipLaunchKernelGGL(layernorm_cf_reg_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
+        if (C == 384) hipLaunchKernelGGL(layernorm_cf_reg_kernel<48>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
+        else if (C == 256) hipLaunchKernelGGL(layernorm_cf_reg_kernel<32>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
+        else if (C == 512) hipLaunchKernelGGL(layernorm_cf_reg_kernel<64>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
+        else hipLaunchKernelGGL(layernorm_cf_reg_kernel<0>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
     } else {
         dim3 grid((S + 63) / 64, B);
         hipLaunchKernelGGL(layernorm_cf_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lens, apply_mask, C, S, eps);
