@@ -616,8 +616,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
     if (q >= n_out) return;
     const int64_t per = (int64_t)p.batch * p.Cout * p.Nout;
     const float* __restrict__ pp = p.splitk_ws + ((int64_t)b * p.Cout + co) * p.Nout + q;
+    // eight slices' loads in flight at a time (a plain `v += pp[ks * per]` loop waits for every load before the next one: up to
+    // ksplit serial memory round trips); the sum still runs in slice order
     float v = 0.f;
-    for (int ks = 0; ks < p.ksplit; ++ks) v += pp[ks * per];
+    for (int k0 = 0; k0 < p.ksplit; k0 += 8) {
+        float tq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tq[j] = pp[(int64_t)min(k0 + j, p.ksplit - 1) * per];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v = (k0 + j < p.ksplit) ? v + tq[j] : v;
+    }
     v += p.bias ? p.bias[co] : 0.f;
     if (p.relu_out == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     v = v * (p.scale ? p.scale[co] : 1.f) + (p.res ? p.res[(int64_t)b * p.r_bs + (int64_t)co * p.r_cs + q] : 0.f);
