@@ -191,11 +191,16 @@ __global__ __launch_bounds__(256) void bfo_splitk_reduce(const BfoConvParams p) 
     const float* pp = p.splitk_ws + ((int64_t)b * p.Cout + 8 * o) * L + t;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float a = 0.f;
-        for (int ks = 0; ks < p.ksplit; ++ks) a += pp[ks * per + (int64_t)e * L];
-        v[e] = a + (p.bias ? p.bias[8 * o + e] : 0.f);
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int ks = 0; ks < p.ksplit; ++ks) {                 // slice by slice, the eight channels' loads in flight together
+        float tq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tq[e] = pp[ks * per + (int64_t)e * L];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += tq[e];
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += p.bias ? p.bias[8 * o + e] : 0.f;
     if (p.y_f32) {
         float* yp = p.y_f32 + ((int64_t)b * p.Cout + 8 * o) * L + t;
         const float* rp = p.res_f32 ? p.res_f32 + ((int64_t)b * p.Cout + 8 * o) * L + t : nullptr;
