@@ -273,7 +273,7 @@ int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos
 // Block = QT = 16*RA queries of one utterance; key/value tiles of 64 streamed through LDS, the next
 // tile's 32 values per thread are already in flight (registers) while the current one is consumed.
 // Thread (ti = tid/16, tj = tid%16) owns score rows i0=RA*ti.. and score cols / out dims 4*tj..
-// RA = 4 (64 queries per block) when that already fills the chip, RA = 1 (16 queries) otherwise:
+// RA = 4 (64 queries per block) when that gives every CU a block, RA = 1 (16 queries) otherwise:
 // the arithmetic per (query, key) is the same in both, so the result does not depend on RA.
 // ------------------------------------------------------------------------------------
 constexpr int ATT_D = 64;
@@ -410,9 +410,16 @@ int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32
         const char* e = getenv("TTSAMD_BF16_ATTN");
         if (!(e && e[0] == '0')) return launch_attention_bf16(qkv, lens, B, D, S, scale, out, s);
     }
-    if ((int64_t)((S + 63) / 64) * B >= 1024) {
+    // 64 queries per block once that gives every CU a block (batch 32 x 450 frames: 78.14 -> 77.95 ms per step), 16 otherwise
+    // (batch 1 / 8: 4.60 / 21.94 ms against 4.80 / 22.14); TTSAMD_ATT_RA=1/2/4 forces the tile
+    const char* rae = getenv("TTSAMD_ATT_RA");
+    const int ra = rae ? atoi(rae) : ((int64_t)((S + 63) / 64) * B >= 256 ? 4 : 1);
+    if (ra == 4) {
         dim3 grid((S + 63) / 64, B);
         hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
+    } else if (ra == 2) {
+        dim3 grid((S + 31) / 32, B);
+        hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
     } else {
         dim3 grid((S + 15) / 16, B);
         hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
