@@ -738,7 +738,11 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
     auto blocks = [&](int co_blk, int nt_blk) -> int64_t {
         return (int64_t)((p.Nout + nt_blk - 1) / nt_blk) * (p.CoutP / co_blk) * p.n_phase * p.batch;
     };
-    static const int64_t want = [] { const char* e = getenv("TTSAMD_WANT_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)768; }();
+    static const int64_t want_env = [] { const char* e = getenv("TTSAMD_WANT_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)-1; }();
+    // blocks a launch should have: 3 per CU -- unless the whole problem is about one round of the smallest tiles (batch 1: 914 tiles
+    // of 64 x 64 for a stage-2 conv): then one block per CU of a LARGE tile (64 x 256: 230 blocks at 0.85 of the matrix peak) beats
+    // four of the small one (0.62): batch 1 5.04 -> 4.86 ms per call, measured with TTSAMD_WANT_BLOCKS=200 / 768
+    const int64_t want = want_env > 0 ? want_env : (blocks(64, 64) <= 1024 ? (int64_t)200 : (int64_t)768);
     const bool tiny = p.Nout <= 96;
 #ifdef TTS_FORCE_CFG   /* tile autotuning with tools/conv_bench.hip */
     switch (TTS_FORCE_CFG) {
