@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int a = 0; a < RA; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) sc[a][c] = 0.f;
+#pragma unroll 8
         for (int d = 0; d < ATT_D; ++d) {
             float qa[RA];
             if constexpr (RA == 4) {
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
         __syncthreads();
         // O[i0+a][d0+c] += sum_j P[i0+a][j] * V[d0+c][j], d0 = j0
+#pragma unroll 8
         for (int j = 0; j < 64; ++j) {
             float pa[RA], va[4];
 #pragma unroll
