@@ -692,8 +692,11 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     }
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
     const int n_chunks = p.Cin / G::KC;
-    if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < 320 && n_chunks >= 8) {
-        int64_t ks = std::min<int64_t>((640 + nblk - 1) / nblk, n_chunks / 4);
+    static const int sk_blocks = [] { const char* e = getenv("TTSAMD_SPLITK_BLOCKS"); return e ? atoi(e) : 320; }();
+    static const int sk_target = [] { const char* e = getenv("TTSAMD_SPLITK_TARGET"); return e ? atoi(e) : 640; }();
+    static const int sk_chunks = [] { const char* e = getenv("TTSAMD_SPLITK_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
+    if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < sk_blocks && n_chunks >= sk_chunks) {
+        int64_t ks = std::min<int64_t>((sk_target + nblk - 1) / nblk, n_chunks / 4);
         ks = std::min<int64_t>(ks, p.splitk_floats / per);
         if (ks >= 2) q.ksplit = (int)ks;
     }
