@@ -39,9 +39,15 @@ __global__ __launch_bounds__(256, 2) void convt_mfma_f32(const ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int kk = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z;
+    int b = blockIdx.z;
     const int co_blk0 = blockIdx.y * CO_BLK;
-    const int q0 = blockIdx.x * NT_BLK;
+    int q0 = blockIdx.x * NT_BLK;
+    if (p.compact) {   // ragged batch: dead blocks last (common.hpp: live_tile)
+        int tile = 0;
+        if (!live_tile(p.lens_out, p.len_out_mul, p.Nout, NT_BLK, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        b = __builtin_amdgcn_readfirstlane(b);
+        q0 = __builtin_amdgcn_readfirstlane(tile) * NT_BLK;
+    }
     int n_out = p.Nout;                                        // input positions that produce output
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
     if (q0 >= n_out) return;
@@ -202,7 +208,9 @@ static int32_t launch_convt_cfg(const ConvParams& p, hipStream_t stream) {
         attr_set[dev_id] = true;
     }
     dim3 grid((p.Nout + G::NT_BLK - 1) / G::NT_BLK, p.CoutP / G::CO_BLK, p.batch);
-    hipLaunchKernelGGL((convt_mfma_f32<U, MT, NTL, WM>), grid, dim3(256), lds, stream, p);
+    ConvParams q = p;
+    q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
+    hipLaunchKernelGGL((convt_mfma_f32<U, MT, NTL, WM>), grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }

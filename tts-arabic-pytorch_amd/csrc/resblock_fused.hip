@@ -35,6 +35,7 @@ struct FusedPairParams {
     int32_t len_mul, L, dil, batch;
     int32_t mode;          // 0: y = v   1: y = y + v   2: y = (y + v) / div
     float div, slope;
+    int32_t compact;       // set by the launcher: ragged batch, blocks take the lin-th LIVE tile (common.hpp: live_tile)
 };
 
 template <int K, int C>
@@ -67,8 +68,14 @@ __global__ __launch_bounds__(256, 2) void resblock_pair(const FusedPairParams p)
     constexpr int H = G::H, TS = G::TS, W1S = G::W1S, TSTR = G::TSTR;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int kk = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z;
-    const int q0 = blockIdx.x * TS;
+    int b = blockIdx.z;
+    int q0 = blockIdx.x * TS;
+    if (p.compact) {   // ragged batch: dead blocks last (common.hpp: live_tile)
+        int tile = 0;
+        if (!live_tile(p.lens, p.len_mul, p.L, TS, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        b = __builtin_amdgcn_readfirstlane(b);
+        q0 = __builtin_amdgcn_readfirstlane(tile) * TS;
+    }
     int len = p.L;
     if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
     if (q0 >= len) return;
@@ -355,6 +362,7 @@ int32_t launch_fused_pair(int32_t channels, const float* x, float* y, const floa
     p.w1 = reinterpret_cast<const float4*>(w1); p.w2 = reinterpret_cast<const float4*>(w2);
     p.b1 = b1; p.b2 = b2; p.lens = lens; p.len_mul = len_mul; p.L = L; p.dil = dil; p.batch = batch;
     p.mode = mode; p.div = div; p.slope = slope;
+    p.compact = compact_order(lens, batch) ? 1 : 0;
     if (channels == 64) return launch_fused_k<3, 64>(p, stream);
     switch (k) {
         case 3: return launch_fused_k<3, 32>(p, stream);
