@@ -45,7 +45,10 @@ namespace ttsamd {
 
 template <int K, int NT_BLK, int CO_BLK>
 struct Geo {
-    static constexpr int NOCT = OctsOf<K>::NOCT;
+    // octets (8 input channels) per chunk.  k = 3 on the 128 x 128 tile takes two: a one-octet chunk is 48 MFMAs per wave (1.3 us)
+    // between barriers; two halve the barriers and still leave two blocks per CU (FastPitch's 384 -> 1536 conv 121 -> 128 TFLOP/s,
+    // HiFi-GAN C = 128 k = 3 106 -> 108; the smaller k = 3 tiles lose 2-3 % with it: tools/conv_bench -DTTS_NOCT3=2)
+    static constexpr int NOCT = (K == 3 && NT_BLK == 128 && CO_BLK == 128) ? 2 : OctsOf<K>::NOCT;
     static constexpr int KC = 8 * NOCT;                       // input channels per chunk
     static constexpr int WS = NT_BLK + (K - 1) * DMAX;        // staged columns (one float4 each)
     static constexpr int XI = 2 * NOCT * WS;                  // X float4s per stage
@@ -765,7 +768,8 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
         const bool few_long = p.Cin >= 256 && p.CoutP <= p.Cin && !tiny && blocks(128, 128) < 4 * want;
         if (few_long && K == 3 && blocks(128, 64) >= want) return launch_cfg<K, 1, 2, 4, 1>(p, stream);  // 128 co x 64 t
         if (few_long && K >= 7 && blocks(64, 128) >= want) return launch_cfg<K, 1, 2, 2, 2>(p, stream);  //  64 co x 128 t
-        if (K < 11 && !tiny && blocks(128, 128) >= want) return launch_cfg<K, 2, 2, 2, 2>(p, stream);   // 128 co x 128 t
+        if (K < 11 && !tiny && blocks(128, 128) >= want && (K != 3 || p.Cin % 16 == 0))                 // (k = 3: 16-channel chunks)
+            return launch_cfg<K, 2, 2, 2, 2>(p, stream);                                                // 128 co x 128 t
         if (K == 11 && !tiny && blocks(64, 256) >= want) return launch_cfg<K, 2, 2, 1, 4>(p, stream);   //  64 co x 256 t
         // deep K, a few hundred tiles (FastPitch's second conv-FF conv, 1536 -> 384, at batch 7..13): 128 x 64 tiles with K split
         // (launch_cfg: < 320 tiles -> 2..4 slices) instead of twice as many 64 x 64 tiles that each walk all 96 chunks
