@@ -91,6 +91,82 @@ def cpu_baseline(fp_sd, hg_sd, tokens, seconds_budget=25.0):
     return out
 
 
+def _cpu_worker(job):
+    """One worker process of cpu_baseline_all_cores (spawned: never touches the GPU): its own copy of the synthetic weights,
+    `threads` intra-op threads, distinct utterances (rows first, first + stride, ... of the synthetic batch), timed for
+    `seconds` after one warm-up utterance.  Returns (samples, utterances, seconds)."""
+    first, stride, threads, tokens, seconds = job
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import tts_oracle as O
+    from ttsamd import synth
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    torch.set_num_threads(threads)
+    fw = O.to_torch(synth.fastpitch_state_dict())
+    hw = O.fold_weight_norm(synth.hifigan_state_dict())
+    ids = synth.synth_ids(first + 64 * stride + 1, tokens)
+    dur = synth.synth_durations(first + 64 * stride + 1, tokens)
+    with torch.inference_mode():
+        O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids[:1, :8], dur_tgt=dur[:1, :8])
+        t0 = time.perf_counter()
+        n_samples = n_utts = 0
+        row = first
+        while time.perf_counter() - t0 < seconds and n_utts < 64:
+            _, _, waves = O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids[row:row + 1], dur_tgt=dur[row:row + 1])
+            n_samples += int(waves[0].numel())
+            n_utts += 1
+            row += stride
+        return n_samples, n_utts, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(tokens, threads=8, seconds=12.0):
+    """Utterance-parallel CPU baseline on the WHOLE host: N = host_cpus // threads worker processes x `threads` intra-op threads,
+    each synthesising distinct utterances one at a time (utterances are independent, so this is how a CPU deployment of the
+    reference would use a many-core host; torch's intra-op pool alone stops scaling at ~8 threads on these per-utterance convs).
+    Aggregate = total samples / the slowest worker's time."""
+    import multiprocessing as mp
+    host = os.cpu_count() or 1
+    n = max(1, min(host // threads, 64))
+    ctx = mp.get_context('spawn')
+    t0 = time.perf_counter()
+    with ctx.Pool(n) as pool:
+        res = pool.map(_cpu_worker, [(w, n, threads, tokens, seconds) for w in range(n)])
+    wall = time.perf_counter() - t0
+    samples, utts, slowest = sum(r[0] for r in res), sum(r[1] for r in res), max(r[2] for r in res)
+    return {'value': samples / slowest, 'unit': 'audio samples/s', 'cores': n * threads, 'workers': n, 'threads_per_worker': threads,
+            'host_cpus': host, 'kind': 'port',
+            'sample': f'{utts} distinct utterances x {tokens} tokens over {n} worker processes x {threads} threads, '
+                      f'{slowest:.1f} s timed per worker ({wall:.1f} s incl. process start-up and weight synthesis)'}
+
+
+def _count_gpus():
+    """GPUs on this node WITHOUT initialising the HIP runtime in this process (the launcher / supervisor parents must never hold a
+    GPU context: they kill and restart their children): the KFD topology in sysfs (a node with simd_count > 0 is a GPU), narrowed
+    by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES; torch.cuda.device_count() only if sysfs is not there."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(',') if x.strip() != ''])
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = {}
+            with open(os.path.join(base, node, 'properties')) as f:
+                for ln in f:
+                    kv = ln.split()
+                    if len(kv) == 2:
+                        props[kv[0]] = kv[1]
+            if int(props.get('simd_count', '0')) <= 0:
+                continue                                        # a CPU node
+            minor = props.get('drm_render_minor')
+            # a container may see the whole host's topology but own only some of the render nodes
+            if minor is None or os.access(f'/dev/dri/renderD{minor}', os.R_OK | os.W_OK):
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return torch.cuda.device_count()
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` typed as is (no torch.distributed.run around it): start N ranks as child
     processes BEFORE anything in this process touches the GPU, relay rank 0's JSON line, fail if any child fails.
@@ -106,7 +182,7 @@ def _self_launch(args):
     once, never the caller's whole time-out."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()          # counts devices without initialising the HIP runtime
+    n_dev = _count_gpus()                      # sysfs: this process never initialises the HIP runtime
     base_env = dict(os.environ)
     if n_dev < args.gpus:
         base_env['TTSAMD_BENCH_ONE_DEVICE'] = '1'
@@ -172,87 +248,167 @@ def _self_launch(args):
 def _supervise_rank(args, rank, world):
     """A rank started by an EXTERNAL launcher (`python -m torch.distributed.run ... bench.py --gpus N`, what the driver uses)
     gets the same protection as the self-launched case: this process never touches the GPU; it runs the real rank as a child
-    process and watches it.  If the child stalls past the budget, dies, or ANY rank's supervisor on the node reports a failure
-    (a flag file keyed by the launcher's MASTER_PORT: one dead rank leaves its peers inside an unmatched collective), every
-    supervisor kills its child and starts a FRESH one with TTSAMD_DP_TRANSPORT=torch on a rendezvous of its own (rank 0's child
-    hosts a new TCPStore on MASTER_PORT + 1 + attempt: the launcher's store still holds the first attempt's keys).  The launcher
-    itself only ever sees the supervisors, which exit non-zero only when the second attempt failed too."""
+    process and watches it.  If the child stalls past the budget, dies, or ANY rank's supervisor on the node reports a failure,
+    every supervisor kills its child and starts a FRESH one with TTSAMD_DP_TRANSPORT=torch on a rendezvous of its own.  The
+    launcher itself only ever sees the supervisors, which exit non-zero only when the second attempt failed too.
+
+    The supervisors talk through files in the temp directory keyed by a per-RUN nonce (the launcher's TORCHELASTIC_RUN_ID, its
+    port and its pid: an earlier run on the same port can leave nothing behind that this one would read).  Each rank writes only
+    ITS OWN failure flag `<key>_a<attempt>_failed_r<rank>`, reads everybody's, and removes its own files when it exits: no
+    rank ever deletes a file another rank may just have written.  The retry's rendezvous port is probed free by rank 0's
+    supervisor (bind to port 0) and published in `<key>_retry_port`; the launcher's own store still holds the first attempt's keys."""
+    import glob
+    import socket
     import subprocess
     import tempfile
     import threading
     port0 = int(os.environ.get('MASTER_PORT', '29500'))
+    run_id = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
+    key = os.path.join(tempfile.gettempdir(), f'ttsamd_bench_{run_id}_{port0}_{os.getppid()}')
     budget = float(os.environ.get('TTSAMD_BENCH_WATCHDOG_S', 300.0 + 2.0 * (args.steps + args.warmup)))
-    why = None
-    for attempt in (0, 1):
-        flag = os.path.join(tempfile.gettempdir(), f'ttsamd_bench_{port0}_attempt{attempt}_failed')
-        if rank == 0 and os.path.exists(flag):
-            os.remove(flag)                                      # a stale flag of an earlier run on the same port
-        env = dict(os.environ, TTSAMD_BENCH_WORKER='1', TTSAMD_BENCH_ATTEMPT=str(attempt),
-                   TTSAMD_BENCH_INIT_TIMEOUT_S=str(int(budget) + 120))
-        if attempt == 1:
-            env.update(TTSAMD_DP_TRANSPORT='torch', MASTER_PORT=str(port0 + 2), TORCHELASTIC_USE_AGENT_STORE='False',
-                       TTSAMD_BENCH_FALLBACK_REASON=why or 'first attempt failed')
-        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                 stdout=subprocess.PIPE if rank == 0 else None)
-        lines = []
+    mine = []                                                    # files this supervisor wrote
 
-        def pump(stream=child.stdout):
-            for ln in iter(stream.readline, b''):
-                lines.append(ln.decode())
-        th = None
-        if rank == 0:
-            th = threading.Thread(target=pump, daemon=True)
-            th.start()
-        deadline, why, t_line = time.monotonic() + budget, None, None
-        while child.poll() is None:
-            time.sleep(0.5)
-            if rank == 0 and t_line is None and any(ln.startswith('{') for ln in lines):
-                t_line = time.monotonic()                        # the line is out: only teardown is left
-            if t_line is not None and time.monotonic() - t_line > 60:
-                break                                            # hung in teardown after a complete result: keep the result
-            if os.path.exists(flag):
-                why = 'another rank reported a failure'
-                break
-            if time.monotonic() > deadline:
-                why = f'no result within the watchdog budget of {budget:.0f} s'
-                break
-        if child.poll() is None:
-            child.kill()
-        rc = child.wait()
-        if th is not None:
-            th.join(timeout=5)
-        got = [ln for ln in lines if ln.startswith('{')]
-        ok = (why is None and rc == 0) or (rank == 0 and got and why is None)
-        if why is None and not ok:
-            why = f'rank {rank} exited with {rc}'
-        if not ok:
+    def put(path, text=''):
+        tmp = f'{path}.tmp{os.getpid()}'
+        try:
+            with open(tmp, 'w') as f:
+                f.write(text)
+            os.replace(tmp, path)                                # atomic: a reader never sees a half-written port
+            mine.append(path)
+        except OSError:
+            pass
+
+    def cleanup():
+        for path in mine:
             try:
-                open(flag, 'w').close()                          # tell the other supervisors
+                os.remove(path)
             except OSError:
                 pass
-            print(f'bench.py supervisor of rank {rank}: {why}' + ('; restarting on TTSAMD_DP_TRANSPORT=torch' if attempt == 0 else ''),
-                  file=sys.stderr)
-            continue
-        for ln in lines:
-            print(ln, end='', file=sys.stdout if ln.startswith('{') else sys.stderr)
-        sys.stdout.flush()
-        sys.exit(0)
+
+    why = None
+    try:
+        for attempt in (0, 1):
+            env = dict(os.environ, TTSAMD_BENCH_WORKER='1', TTSAMD_BENCH_ATTEMPT=str(attempt),
+                       TTSAMD_BENCH_INIT_TIMEOUT_S=str(int(budget) + 120))
+            if attempt == 1:
+                port_file = f'{key}_retry_port'
+                if rank == 0:
+                    with socket.socket() as sk:
+                        sk.bind(('127.0.0.1', 0))
+                        put(port_file, str(sk.getsockname()[1]))
+                t_wait = time.monotonic() + 60
+                while not os.path.exists(port_file) and time.monotonic() < t_wait:
+                    time.sleep(0.2)
+                try:
+                    with open(port_file) as f:
+                        retry_port = int(f.read())
+                except (OSError, ValueError):
+                    print(f'bench.py supervisor of rank {rank}: no retry port published by rank 0', file=sys.stderr)
+                    break
+                env.update(TTSAMD_DP_TRANSPORT='torch', MASTER_PORT=str(retry_port), TORCHELASTIC_USE_AGENT_STORE='False',
+                           TTSAMD_BENCH_FALLBACK_REASON=why or 'first attempt failed')
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                     stdout=subprocess.PIPE if rank == 0 else None)
+            lines = []
+
+            def pump(stream=child.stdout):
+                for ln in iter(stream.readline, b''):
+                    lines.append(ln.decode())
+            th = None
+            if rank == 0:
+                th = threading.Thread(target=pump, daemon=True)
+                th.start()
+            deadline, why, t_line = time.monotonic() + budget, None, None
+            while child.poll() is None:
+                time.sleep(0.5)
+                if rank == 0 and t_line is None and any(ln.startswith('{') for ln in lines):
+                    t_line = time.monotonic()                    # the line is out: only teardown is left
+                if t_line is not None and time.monotonic() - t_line > 60:
+                    break                                        # hung in teardown after a complete result: keep the result
+                if glob.glob(f'{key}_a{attempt}_failed_r*'):
+                    why = 'another rank reported a failure'
+                    break
+                if time.monotonic() > deadline:
+                    why = f'no result within the watchdog budget of {budget:.0f} s'
+                    break
+            if child.poll() is None:
+                child.kill()
+            rc = child.wait()
+            if th is not None:
+                th.join(timeout=5)
+            got = [ln for ln in lines if ln.startswith('{')]
+            ok = (why is None and rc == 0) or (rank == 0 and got and why is None)
+            if why is None and not ok:
+                why = f'rank {rank} exited with {rc}'
+            if not ok:
+                put(f'{key}_a{attempt}_failed_r{rank}')          # tell the other supervisors
+                print(f'bench.py supervisor of rank {rank}: {why}' + ('; restarting on TTSAMD_DP_TRANSPORT=torch' if attempt == 0 else ''),
+                      file=sys.stderr)
+                continue
+            for ln in lines:
+                print(ln, end='', file=sys.stdout if ln.startswith('{') else sys.stderr)
+            sys.stdout.flush()
+            # peers may still be polling for this attempt's flags: leave ours (there are none on success) and go
+            cleanup()
+            sys.exit(0)
+    finally:
+        if why is not None:
+            time.sleep(2.0)                                      # let the peers' 0.5 s polls see the flags before they go
+        cleanup()
     sys.exit(1)
 
 
-def _time_steps(step, steps, sync, barrier=None):
-    """K steps bracketed by barrier + synchronize on both sides -> seconds."""
+def _time_steps(step, steps, sync, barrier=None, tick=None):
+    """K steps bracketed by barrier + synchronize on both sides -> (seconds, last output, per-step ms list or None).
+    `tick()` (optional) records a HIP event on the stream the step's LAST launch went to and returns it: the differences between
+    consecutive events are the per-step times the median is taken over (no host synchronisation inside the timed region)."""
     if barrier:
         barrier()
     sync()
+    evs = [tick()] if tick else None
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
+        if tick:
+            evs.append(tick())
     sync()
     if barrier:
         barrier()
     sync()
-    return time.perf_counter() - t0, out
+    el = time.perf_counter() - t0
+    per_step = [a.elapsed_time(b) for a, b in zip(evs, evs[1:])] if tick else None
+    return el, out, per_step
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return None if n == 0 else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
+BF16_RIDGE_FLOP_PER_BYTE = 2500.0e12 / 8000.0e9      # 312.5: above it a bf16 launch sequence is bound by the matrix pipe, below by HBM
+
+
+def bf16_roofline(flops, byts, sec, extra=None):
+    """Roofline entry of a bf16 launch sequence: the bound is whichever roof the ALGORITHMIC intensity (FLOP / HBM byte) puts first.
+    With the fused pairs / chained ResBlocks the step sits at ~560 FLOP/B, above the 312.5 FLOP/B ridge: MFMA-bound, so `frac` is the
+    fraction of the 2.5 PFLOP/s dense bf16 peak; the HBM side rides along (and the other way round below the ridge)."""
+    tf = flops / sec / 1e12
+    gbs = byts / sec / 1e9
+    inten = flops / max(byts, 1.0)
+    hbm = {'hbm_achieved_gbs': gbs, 'hbm_peak_gbs': PEAK_HBM_GBS, 'hbm_frac': gbs / PEAK_HBM_GBS}
+    mf = {'mfma_achieved_tflops': tf, 'mfma_peak_tflops': 2500.0, 'mfma_frac': tf / 2500.0,
+          'mfma_sustained_tflops': BF16_MFMA_SUSTAINED_TFLOPS, 'mfma_frac_of_sustained': tf / BF16_MFMA_SUSTAINED_TFLOPS}
+    if inten >= BF16_RIDGE_FLOP_PER_BYTE:
+        r = {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0}
+    else:
+        r = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS}
+    r.update({'algorithmic_flop_per_byte': inten, 'ridge_flop_per_byte': BF16_RIDGE_FLOP_PER_BYTE})
+    r.update(hbm)
+    r.update(mf)
+    if extra:
+        r.update(extra)
+    return r
 
 
 def main():
@@ -374,9 +530,10 @@ def main():
     # step i.  Same work per step, same results; 79.4 -> 78.4 ms per step at B=32 (only FastPitch's non-conv kernels find idle CUs).
     from ttsamd.pipeline import FastPitchHifiGan
     if args.pipeline is None:
-        # default: bf16 on one GPU.  N > 1 stays on the one-stream schedule unless asked: two streams issuing the length exchange and
-        # the audio fan-in on one communicator has never run between distinct devices
-        args.pipeline = args.precision == 'bf16' and world == 1
+        # default: bf16 at every N, so that `--gpus N` runs the schedule the N = 1 line advertises.  At N > 1 the acoustic stream issues
+        # the length all-gather and the vocoder stream the audio fan-in, each on its OWN communicator (ttsamd.dp.Dp.comm / comm_audio):
+        # operations on one communicator would have to reach the device in the same order on every rank, which two streams do not promise
+        args.pipeline = args.precision == 'bf16'
     pipe_obj = []
 
     def get_pipe():
@@ -384,8 +541,21 @@ def main():
             pipe_obj.append(FastPitchHifiGan(fp, hg, dev))
         return pipe_obj[0]
 
+    def make_tick(pipe):
+        """event recorder on the stream a step's last launch goes to (the vocoder stream of the pipeline, else the caller's)"""
+        def tick():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(pipe.s_hg if pipe is not None else torch.cuda.current_stream(dev))
+            return ev
+        return tick
+
     def make_step(ids_, dur_, pipelined=None):
         pipe = get_pipe() if (args.pipeline if pipelined is None else pipelined) else None
+        step = _make_step(ids_, dur_, pipe)
+        step.tick = make_tick(pipe)
+        return step
+
+    def _make_step(ids_, dur_, pipe):
         if world == 1:
             if pipe is not None:
                 def step():
@@ -444,7 +614,7 @@ def main():
     lib = L.load()
     import ctypes
     lib.ttsamd_profile_enable(0 if os.environ.get("TTSAMD_BENCH_NO_EVENTS") else 1)
-    elapsed, (wave, dec_lens) = _time_steps(step, args.steps, sync, barrier)
+    elapsed, (wave, dec_lens), per_step = _time_steps(step, args.steps, sync, barrier, tick=step.tick)
     prof = (ctypes.c_double * 3)()
     L.check(lib.ttsamd_profile_read(prof), 'profile_read')
     lib.ttsamd_profile_enable(0)
@@ -489,31 +659,29 @@ def main():
         r = {'bound': 'mfma', 'achieved': ach, 'peak': PEAKS[prec], 'unit': 'TFLOP/s', 'frac': ach / PEAKS[prec],
              'basis': 'algorithmic conv FLOPs / wall time of the whole call (no per-launch events)'}
         if prec == 'bf16':
-            gbs = byts / sec / 1e9
-            r = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                 'mfma_achieved_tflops': ach, 'mfma_peak_tflops': PEAKS[prec], 'mfma_frac': ach / PEAKS[prec],
-                 'mfma_sustained_tflops': BF16_MFMA_SUSTAINED_TFLOPS, 'mfma_frac_of_sustained': ach / BF16_MFMA_SUSTAINED_TFLOPS,
-                 'basis': 'algorithmic HBM bytes (and conv FLOPs) / wall time of the whole call (no per-launch events)'}
+            r = bf16_roofline(flops, byts, sec, {'basis': 'algorithmic conv FLOPs (and HBM bytes) / wall time of the whole call '
+                                                          '(no per-launch events)'})
         return r
 
-    def small_config(b, prec=None, name=None, pipelined=False):
+    def small_config(b, prec=None, name=None, pipelined=False, inputs=None):
         """Batch-b sub-result (north star: batch 1 / 8 / 32): same step function, own warm-up, timed WITHOUT the
         per-launch events (they cost a B=1 call 17 %); its roofline figure is algorithmic work over the call's
         WALL time — launch gaps and the three-stream overlap included — so it can never exceed what ran."""
         prec = prec or args.precision
         set_precision(prec)
         try:
-            ids_b, dur_b = ids[:b].contiguous(), dur[:b].contiguous()
+            ids_src, dur_src = inputs if inputs is not None else (ids, dur)
+            ids_b, dur_b = ids_src[:b].contiguous(), dur_src[:b].contiguous()
             st = make_step(ids_b, dur_b, pipelined)
             for _ in range(5):
                 st()
             sync()
             n = max(args.steps, 20)
-            el, (_, dl) = _time_steps(st, n, sync)
+            el, (_, dl), ps = _time_steps(st, n, sync, tick=st.tick)
         finally:
             set_precision(args.precision)
         fr = int(dl.sum().item())
-        out_c = {'batch': b, 'ms_per_step': el / n * 1e3, 'value': fr * hop * n / el, 'unit': 'audio samples/s',
+        out_c = {'batch': b, 'ms_per_step': el / n * 1e3, 'ms_per_step_median': _median(ps), 'value': fr * hop * n / el, 'unit': 'audio samples/s',
                  'rtf': el / (fr * hop * n / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': prec,
                  'roofline': wall_roofline(prec, step_flops(b, fr), step_bytes_bf16(b, fr), el / n)}
         out_c['schedule'] = ('two HIP streams: FastPitch of step i+1 under HiFi-GAN of step i (ttsamd.pipeline)' if pipelined
@@ -545,14 +713,12 @@ def main():
                       'streams overlap)')
         if args.precision == 'bf16':
             byts = args.steps * step_bytes_bf16(B, frames)
-            gbs = byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
-            roof = {'bound': 'hbm', 'kernel': 'bf16 octet engine (bfo_resblock_pair + bfo_conv1d + bfo_convt; HiFi-GAN, FastPitch FFT blocks and predictors) + conv1d_mfma_bf16 for the remaining FastPitch convs',
-                    'kernel_time_basis': time_basis, 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                    'mfma_achieved_tflops': achieved, 'mfma_peak_tflops': peak, 'mfma_frac': achieved / peak,
-                    'mfma_sustained_tflops': BF16_MFMA_SUSTAINED_TFLOPS, 'mfma_frac_of_sustained': achieved / BF16_MFMA_SUSTAINED_TFLOPS,
-                    'mfma_sustained_note': 'register-only v_mfma_f32_32x32x16_bf16 loop on random data, power-managed clock 1.72-1.78 GHz '
-                                           '(tools/mfma_peak_bench.hip, profiles/r3/mfma_sustained_peak.txt); the 2.5 PFLOP/s peak needs 2.4 GHz',
-                    'algorithmic_bytes_per_step': byts / args.steps}
+            roof = bf16_roofline(flops, byts, max(conv_ms, 1e-9) * 1e-3, {
+                'kernel': 'bf16 octet engine (bfo_resblock_pair / _chain + bfo_conv1d + bfo_convt; HiFi-GAN, FastPitch FFT blocks and predictors) + conv1d_mfma_bf16 for the remaining FastPitch convs',
+                'kernel_time_basis': time_basis,
+                'mfma_sustained_note': 'register-only v_mfma_f32_32x32x16_bf16 loop on random data, power-managed clock 1.72-1.78 GHz '
+                                       '(tools/mfma_peak_bench.hip, profiles/r3/mfma_sustained_peak.txt); the 2.5 PFLOP/s peak needs 2.4 GHz',
+                'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
                     'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
@@ -567,7 +733,10 @@ def main():
             'metric': 'audio samples/sec (FastPitch+HiFi-GAN, synthetic 64-phoneme inputs)',
             'value': samples / elapsed, 'unit': 'audio samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak',
+            'ms_per_step': elapsed / args.steps * 1e3, 'ms_per_step_median': _median(per_step),
+            'ms_per_step_note': 'ms_per_step (and value) = wall time of the K timed steps / K, as the contract prescribes; the median is over '
+                                'the K per-step intervals between HIP events recorded after each step\'s last launch (rank 0)',
+            'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak',
             'vs_baseline': None, 'dtype': {'f32': 'f32', 'bf16': 'bf16', 'bf16x3': 'f32 via split-bf16 (3x bf16 MFMA, fp32 accumulate)'}[args.precision], 'data': 'synthetic (ids, forced durations, random-init weights)',
             'rtf': elapsed / (samples / SAMPLE_RATE),
             'config': {'workload': f'FastPitch+HiFi-GAN, synthetic {Lt}-phoneme x batch{B} per GPU, {prec_name}, '
@@ -593,6 +762,10 @@ def main():
             out['d2h'] = d2h_probe(wave, dec_lens, hop)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(fp_sd, hg_sd, Lt)
+            try:
+                out['cpu_baseline']['all_cores'] = cpu_baseline_all_cores(Lt)
+            except Exception as e:                               # noqa: BLE001
+                out['cpu_baseline']['all_cores'] = {'error': str(e)[:300]}
         elif world > 1:
             out['cpu_baseline'] = None
         print(json.dumps(out))
@@ -641,6 +814,21 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
     res.append(c3)
     for b_small in (8, 1):                          # north star: batch 1 / 8 / 32 -- the bf16 configuration at the small batches too
         res.append(small_config(b_small, prec='bf16', name=f'C3 at batch {b_small}: FastPitch+HiFi-GAN, synthetic 64-phoneme, bf16 MFMA'))
+    # C3 at its REAL size on one GPU: all 256 utterances of the 8-GPU configuration = the N = 1 point of its strong-scaling curve
+    # (`bench.py --gpus N --batch 256 --scaling strong --precision bf16` gives the other points)
+    try:
+        b_full = 256
+        ids256 = torch.from_numpy(synth.synth_ids(b_full, ids.shape[1])).to(dev)
+        dur256 = torch.from_numpy(synth.synth_durations(b_full, ids.shape[1])).to(dev)
+        c3f = small_config(b_full, prec='bf16', pipelined=True, inputs=(ids256, dur256),
+                           name='C3 at its full size on ONE GPU (N = 1 point of the strong-scaling curve): FastPitch+HiFi-GAN, synthetic '
+                                '64-phoneme x batch256, bf16 MFMA')
+        c3f['ms_per_step_one_stream'] = small_config(b_full, prec='bf16', inputs=(ids256, dur256))['ms_per_step']
+        res.append(c3f)
+        del ids256, dur256
+    except Exception as e:                                       # noqa: BLE001
+        res.append({'config': 'C3 at batch 256 on one GPU', 'error': str(e)[:300]})
+    torch.cuda.empty_cache()
     n = max(args.steps, 10)
     hgf = hifigan_flops_per_frame(HIFIGAN_CONFIG)
     # ---- C4
@@ -679,7 +867,16 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
                     'unit': 'audio samples/s', 'rtf': el / (fr * hop / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': 'f32',
                     'ms_tacotron2': el_t * 1e3, 'us_per_decoder_step': el_t / frames_t * 1e6,
                     'parity': 'unpinned (torchaudio Tacotron2 is not in the reference tree; SURVEY §8c)',
-                    'roofline': wall_roofline('f32', flops, 0.0, el)})
+                    # two parts with two different bounds: the decoder is a 448-step recurrence whose step is a chain of cross-XCD
+                    # hand-offs (latency: MI355X_MICROARCH.md hand-off price list), the vocoder is the MFMA conv engine
+                    'roofline': dict(wall_roofline('f32', hgf * fr, 0.0, max(el - el_t, 1e-9)),
+                                     what='HiFi-GAN part only: conv FLOPs / (whole call - Tacotron2 alone)'),
+                    'decoder': {'bound': 'latency (dependent cross-XCD hand-offs inside one persistent launch)',
+                                'us_per_step': el_t / frames_t * 1e6, 'handoffs_per_step': TACO_HANDOFFS_PER_STEP,
+                                'handoff_us': 3.5, 'floor_us_per_step': TACO_HANDOFFS_PER_STEP * 3.5,
+                                'frac_of_floor': TACO_HANDOFFS_PER_STEP * 3.5 / (el_t / frames_t * 1e6),
+                                'lstm_tflops': lstm * fr / el_t / 1e12,
+                                'note': 'ms_tacotron2 also holds the encoder, the postnet and the host stop test (once per call)'}})
         del taco
     except Exception as e:                                       # noqa: BLE001  (a sub-result must not take the headline line down)
         res.append({'config': 'C4 Tacotron2 + HiFi-GAN', 'error': str(e)[:300]})
@@ -723,6 +920,88 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
                     'dtype': 'f32', 'roofline': wall_roofline('f32', flops, 0.0, el)})
     except Exception as e:                                       # noqa: BLE001
         res.append({'config': 'C5 FastPitch 4-speaker + MelVocos', 'error': str(e)[:300]})
+    # ---- C2 with the denoiser on (SURVEY §8d secondary: denoise = 0.005, the default of FastPitch2Wave.tts)
+    try:
+        from vocoder.hifigan.denoiser import Denoiser
+
+        class _Voc:                                              # what Denoiser needs of a vocoder: a device and a call
+            device = dev
+
+            def __call__(self, mel):
+                return hg.forward(mel)
+
+            def to(self, d):
+                return self
+        den = Denoiser(_Voc())
+
+        def c2d():
+            mel, dl, *_ = fp.infer(ids, dur_tgt=dur)
+            wave = hg.forward(mel, dl)
+            return den.forward_batch(wave, dl * hop, 0.005, nsamples_min=513), dl
+        for _ in range(3):
+            c2d()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            _, dl = c2d()
+        sync()
+        el = (time.perf_counter() - t0) / n
+        fr = int(dl.sum().item())
+        res.append({'config': f'C2 with denoise=0.005 (Denoiser: STFT -> spectral subtraction -> ISTFT after the vocoder), batch {B}, fp32',
+                    'batch': B, 'ms_per_step': el * 1e3, 'value': fr * hop / el, 'unit': 'audio samples/s',
+                    'rtf': el / (fr * hop / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': 'f32',
+                    'parity': 'denoiser unpinned at the torchaudio boundary (golden made with a torch.stft stand-in; SURVEY §8c)'})
+    except Exception as e:                                       # noqa: BLE001
+        res.append({'config': 'C2 with denoise=0.005', 'error': str(e)[:300]})
+    # ---- C1: the reference's own case (inference.py:55-58) -- the 100 lines of data/infer_text.txt through FastPitch2Wave.tts
+    try:
+        res += c1_configs(dev)
+    except Exception as e:                                       # noqa: BLE001
+        res.append({'config': 'C1 FastPitch2Wave.tts on the 100 infer_text lines', 'error': str(e)[:300]})
+    return res
+
+
+TACO_HANDOFFS_PER_STEP = 6           # csrc/tacotron2.hip: dependent cross-CU hand-offs of one decoder step in the dataflow schedule
+
+
+def c1_configs(dev):
+    """BASELINE config 1 on the GPU: the 100 committed lines of the reference's data/infer_text.txt (tests/golden/infer_text_lines.json,
+    35-268 tokens each) through the drop-in `FastPitch2Wave.tts(list, batch_size=...)` -- Arabic text in, CPU waves out, i.e.
+    tokenisation, FastPitch with PREDICTED durations (synthetic weights: ~7 frames per token), HiFi-GAN, denoiser as asked and the
+    device -> host copies are all inside the timed call (the reference's plumbing, models/fastpitch/networks.py:352-435)."""
+    import tempfile
+    import text
+    from ttsamd import synth
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    from models.fastpitch import FastPitch2Wave
+    with open(os.path.join(REPO, 'tests', 'golden', 'infer_text_lines.json'), encoding='utf-8') as f:
+        lines = json.load(f)
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        fp_sd = {k: torch.from_numpy(v.copy()) for k, v in synth.fastpitch_state_dict().items()}
+        torch.save({'model': fp_sd, 'config': dict(NET_CONFIG), 'symbols': list(text.symbols)}, os.path.join(d, 'fp.pth'))
+        torch.save({'generator': {k: torch.from_numpy(v.copy()) for k, v in synth.hifigan_state_dict().items()}}, os.path.join(d, 'hg.pth'))
+        with open(os.path.join(d, 'config.json'), 'w') as f:
+            json.dump(HIFIGAN_CONFIG, f)
+        model = FastPitch2Wave(os.path.join(d, 'fp.pth'), vocoder_sd=os.path.join(d, 'hg.pth'),
+                               vocoder_config=os.path.join(d, 'config.json')).to(dev)
+    for bs, denoise in ((1, 0.0), (32, 0.0), (1, 0.005)):
+        model.tts(lines[:4], batch_size=bs, denoise=denoise)                      # warm-up (engines, workspaces)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            waves = model.tts(lines, batch_size=bs, denoise=denoise)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        el = sorted(ts)[1]
+        ns = int(sum(w.numel() for w in waves))
+        res.append({'config': f'C1 FastPitch2Wave.tts(100 lines of infer_text.txt, batch_size={bs}, denoise={denoise}), text in -> CPU waves out, fp32',
+                    'batch': bs, 'ms_total': el * 1e3, 'ms_per_utterance': el * 1e3 / len(lines), 'value': ns / el, 'unit': 'audio samples/s',
+                    'rtf': el / (ns / SAMPLE_RATE), 'samples': ns, 'utterances': len(lines), 'dtype': 'f32',
+                    'timing': 'median of 3 whole calls, host wall time incl. tokenisation and the device -> host copies',
+                    'schedule': 'three HIP streams over the chunks of the list (FastPitch2Wave._tts_list_pipelined): tokenise + FastPitch of chunk '
+                                'k+1 under vocoder + denoiser of chunk k, D2H on a third stream'})
     return res
 
 

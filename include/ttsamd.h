@@ -105,6 +105,11 @@ typedef struct ttsamd_tagger_cfg {
 } ttsamd_tagger_cfg;
 
 const char* ttsamd_last_error(void);
+/* ABI revision of this header.  Bumped whenever a struct gains a field or an argument changes meaning (2: ttsamd_tacotron2_cfg
+ * gained decoder_early_stopping, ttsamd_profile_read's third value became the number of timed sections; 3: ttsamd_dp_* may be
+ * bound twice per process, one communicator per stream).  ttsamd_version() returns the value the library was BUILT with: a caller
+ * compiled against another revision must refuse to run (ttsamd/lib.py does). */
+#define TTSAMD_ABI_VERSION 3
 int32_t ttsamd_version(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
 int32_t ttsamd_device_ok(void);

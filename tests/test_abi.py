@@ -15,7 +15,8 @@ def test_header_symbols_exported():
     handle = lib.load()
     for name in declared:
         assert getattr(handle, name) is not None
-    assert handle.ttsamd_version() >= 1
+    # one ABI revision in the header, the binding and the built library (a mismatch must fail at load, not corrupt a struct)
+    assert int(re.search(r'#define TTSAMD_ABI_VERSION (\d+)', hdr).group(1)) == lib.ABI_VERSION == handle.ttsamd_version()
 
 
 def test_no_gpu_fails_loudly():

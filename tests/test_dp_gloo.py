@@ -83,6 +83,13 @@ def _worker(rank, world, port, tmpdir):
                     assert w.shape == ((g + 1) * 10,) and bool((w == g + 1).all())
             else:
                 assert out is None
+        # two channels: the fan-in travels on its own process group, so the length exchange of the NEXT batch may be issued
+        # while a batch's audio is still on its way (the two-stream schedule of ttsamd.pipeline at world > 1)
+        assert dpx.group_audio is not None and dpx.group_audio is not dist.group.WORLD
+        nxt = dpx.exchange_lens(lens + 1, b_cap=4)
+        out = dpx.gather_audio(wave, lens, all_lens=all_lens)
+        assert nxt[0].tolist() == [3, 11, 21, 31, 0] and nxt[1].tolist() == [2, 41, 51, 0, 0]
+        assert (out is None) == (rank != 0) and (rank != 0 or [w.numel() for w in out] == [10, 20, 30, 40, 50])
         ptr = dpx._recv.buf.data_ptr() if rank == 0 else dpx._pack.buf.data_ptr()
         dpx.gather_audio(wave, lens, all_lens=all_lens)
         assert ptr == (dpx._recv.buf.data_ptr() if rank == 0 else dpx._pack.buf.data_ptr()), 'steady state must not reallocate'

@@ -10,6 +10,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import BF16_MEL_TOL, BF16_WAVE_TOL
+
 pytestmark = pytest.mark.gpu
 
 
@@ -253,7 +255,7 @@ def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T):
     ref = torch.from_numpy(gd['wave']).reshape(-1)
     err, err_old = float((wave - ref).abs().max()), float((wave_old - ref).abs().max())
     print(f'T={T}: octet engine wave max-abs {err:.2e}, round-2 bf16 engine {err_old:.2e}')
-    assert err < 4e-2 and err_old < 4e-2
+    assert err < BF16_WAVE_TOL and err_old < BF16_WAVE_TOL
 
 
 def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch):
@@ -289,7 +291,7 @@ def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch
         worst_b = max(worst_b, float((mel_b[i, :, :n] - mel32[i, :, :n]).abs().max()))
     print(f'bf16 attention vs fp32 attention (both under bf16 GEMMs): {worst_ab:.2e}; vs the fp32 engine: {worst_a:.2e} (fp32 attention: {worst_b:.2e})')
     assert bool(torch.isfinite(mel_a).all())
-    assert worst_a < 6e-2 and worst_ab < 4e-2
+    assert worst_a < BF16_MEL_TOL and worst_ab < 4e-2
 
 
 def test_split_k_small_batch(dev, synth_weights, monkeypatch):
@@ -336,4 +338,4 @@ def test_split_k_small_batch(dev, synth_weights, monkeypatch):
     e_ab, e_a = float((mel_a - mel_b).abs().max()), float((mel_a - mel32).abs().max())
     w_ab, w_a = float((wave_a - wave_b).abs().max()), float((wave_a - wave32).abs().max())
     print(f'split K vs un-split: mel {e_ab:.2e}, wave {w_ab:.2e}; vs fp32: mel {e_a:.2e}, wave {w_a:.2e}')
-    assert e_a < 6e-2 and w_a < 4e-2 and e_ab < 2e-2 and w_ab < 2e-2
+    assert e_a < BF16_MEL_TOL and w_a < BF16_WAVE_TOL and e_ab < 2e-2 and w_ab < 2e-2

@@ -65,7 +65,7 @@ from ttsamd.engine import FastPitchEngine, HifiGanEngine
 dev = torch.device('cuda:0'); torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 dpx = dp.Dp(dev)
-assert dpx.transport == 'rccl' and dpx.comm is not None
+assert dpx.transport == 'rccl' and dpx.comm is not None and dpx.comm_audio is not None      # one communicator per channel
 hg_sd = synth.hifigan_state_dict()
 hg = HifiGanEngine(hg_sd, device=dev)
 mel = torch.randn(2, 80, 9, device=dev)
@@ -142,6 +142,30 @@ def _worker(rank, world, port, tmpdir):
                 assert float((w[i, :int(n[i])] - got[i]).abs().max()) < WAVE_TOL
         else:
             assert views is None
+        # the TWO-STREAM schedule at world > 1 (what `bench.py --gpus N --precision bf16` runs): FastPitch of step i + 1 with its
+        # length all-gather on the acoustic stream, HiFi-GAN of step i with its audio fan-in on the vocoder stream, the two
+        # exchanges on their own channels (Dp.comm / Dp.comm_audio).  Three steps in flight, every step's gathered audio ==
+        # the one-stream result above, bit for bit.
+        from ttsamd.pipeline import FastPitchHifiGan
+        pipe = FastPitchHifiGan(fp, hg, dev)
+        ids_d, dur_d = torch.from_numpy(ids[lo:hi]).to(dev), torch.from_numpy(dur[lo:hi]).to(dev)
+        kept = []
+
+        def vocode(mel_, dec_lens_):
+            wave_ = hg.forward(mel_, dec_lens_)
+            samples_ = state['all'].copy()
+            samples_[:, 1:] *= hg.hop
+            flat, al = dpx.gather_flat(wave_, dec_lens_ * hg.hop, all_lens=samples_)
+            if flat is not None:
+                kept.append(flat.clone())                   # the receive buffer is reused by the next step
+            return wave_
+        for _ in range(3):
+            pipe.submit(ids_d, vocode=vocode, dur_tgt=dur_d, lens_hook=hook)
+        pipe.join()
+        torch.cuda.synchronize()
+        if rank == 0:
+            ref_flat = torch.cat(got)
+            assert len(kept) == 3 and all(torch.equal(k, ref_flat) for k in kept)
         with open(os.path.join(tmpdir, f'ok{rank}'), 'w') as f:
             f.write('ok')
     finally:

@@ -158,7 +158,7 @@ def test_hifigan_ragged_batch_matches_unbatched(dev, synth_weights, hifigan_engi
         assert float(wave[b, 256 * n:].abs().max()) == 0.0 if n < 23 else True
 
 
-@pytest.mark.parametrize('mode,tol', [('f32', WAVE_TOL), ('bf16', 4e-2)])
+@pytest.mark.parametrize('mode,tol', [('f32', WAVE_TOL), ('bf16', 8e-3)])
 def test_hifigan_ragged_fused_kernels_vs_oracle(dev, synth_weights, monkeypatch, mode, tol):
     """The fused c1 -> c2 pair and the all-phase transposed-conv kernels, FORCED ON, against the oracle on a ragged batch
     whose utterances end inside a fused tile's halo: fp32 resblock_pair tiles hold 252 / 248 / 244 outputs at C = 32 (252 at
@@ -399,7 +399,7 @@ def test_denoiser_strong_setting(dev, golden, hifigan_engine):
 # ---------------------------------------------------------------------------------------
 # bf16 MFMA modes (BASELINE config 3): stated tolerances, measured against the fp32 oracle
 # ---------------------------------------------------------------------------------------
-BF16_MEL_TOL, BF16_WAVE_TOL = 6e-2, 4e-2        # plain bf16 operands (8-bit mantissa) through ~75 convs
+from conftest import BF16_MEL_TOL, BF16_WAVE_TOL   # noqa: E402  (plain bf16 operands: stated in tests/conftest.py)
 X3_MEL_TOL, X3_WAVE_TOL = 1e-3, 1e-4            # split bf16 keeps the fp32 north-star tolerances
 
 

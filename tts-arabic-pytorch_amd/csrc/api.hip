@@ -148,7 +148,7 @@ using namespace ttsamd;
 extern "C" {
 
 const char* ttsamd_last_error(void) { return g_err.c_str(); }
-int32_t ttsamd_version(void) { return 1; }
+int32_t ttsamd_version(void) { return TTSAMD_ABI_VERSION; }
 
 int32_t ttsamd_device_ok(void) {
     int n = 0;

@@ -224,7 +224,8 @@ static int32_t bfo_launch_chain_nt(const BfoChainParams& p, hipStream_t stream) 
 // k = 3 ResBlock (three pairs) in one launch: C = 32 / 64 / 128, dilations within the LDS row's halo.  TTSAMD_BFO_CHAIN=0 keeps the
 // three pair launches (measured: batch 32 11.63 -> 11.32 ms per step, batch 8 4.38 -> 4.21, batch 1 2.09 -> 1.97).
 bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch) {
-    static const bool off = [] { const char* e = getenv("TTSAMD_BFO_CHAIN"); return e && e[0] == '0'; }();
+    const char* ce = getenv("TTSAMD_BFO_CHAIN");               // read per call, like the other schedule switches: tests and A/B runs flip it
+    const bool off = ce && ce[0] == '0';
     (void)batch;
     if (off || k != 3 || n_pairs != 3 || !(channels == 32 || channels == 64 || channels == 128)) return false;
     for (int m = 0; m < 3; ++m)

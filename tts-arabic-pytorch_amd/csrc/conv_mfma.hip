@@ -666,8 +666,9 @@ static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_
 // Dead blocks last (live_tile, conv_mfma_common.hpp): default for every ragged launch; TTSAMD_COMPACT=0 restores the plain
 // (time tile, co tile, utterance) grid.
 bool compact_order(const void* lens, int batch) {
-    static const bool on = [] { const char* e = getenv("TTSAMD_COMPACT"); return !(e && e[0] == '0'); }();
-    return on && lens != nullptr && batch > 1;
+    if (lens == nullptr || batch <= 1) return false;
+    const char* e = getenv("TTSAMD_COMPACT");                  // read per call (a dozen ns next to a launch): tests and A/B runs flip it
+    return !(e && e[0] == '0');
 }
 
 bool tile_major_order(const ConvParams& p, unsigned n_tiles) {

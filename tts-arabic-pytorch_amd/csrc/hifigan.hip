@@ -33,7 +33,7 @@ struct HifiGan {
     int hop = 1;
     int64_t max_cl = 0;  // max over stages of C * (L / T)
     bool bfo_ok = false; // every layer fits the bf16 octet engine (config 3 path, hifigan_forward_bfo)
-    // small batches: the three ResBlocks of a stage run on three streams (guarded by mu, created on first use)
+    // the three ResBlocks of a stage run on three streams (created and first dispatched in hifigan_create; guarded by mu)
     mutable std::mutex mu;
     mutable hipStream_t side[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_fork = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
@@ -148,6 +148,8 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
     blob.resize(align_up((int64_t)blob.size(), 64));
     return get_bias(tm, base, cout, blob, cw.b_off);
 }
+
+void hifigan_destroy(HifiGan* h);
 
 __global__ void hifigan_touch_kernel() {}   // first dispatch of a branch stream (hifigan_create)
 
@@ -280,9 +282,7 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
         }
     }
     if (rc != 0) {
-        if (h->dev) (void)hipFree(h->dev);
-        if (h->dev16) (void)hipFree(h->dev16);
-        delete h;
+        hifigan_destroy(h);            // blobs, branch streams and events alike
         return rc;
     }
     *out = h;
@@ -333,11 +333,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     hipStream_t bs[3] = {s, s, s};
     if (multi) {
         lk.lock();
-        if (!h->ev_fork) {
-            for (auto& st : h->side) TTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            TTS_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            for (auto& e : h->ev_done) TTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
+        TTS_REQUIRE(h->ev_fork && h->side[0] && h->side[1], "hifigan_forward: the branch streams were not created (hifigan_create)");
         bs[1] = h->side[0];
         bs[2] = h->side[1];
     }

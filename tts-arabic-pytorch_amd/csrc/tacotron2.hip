@@ -53,7 +53,7 @@ struct Taco2 {
     // persistent decoder: after a hand-off time-out (the 256 blocks were not co-resident: another stream held CUs) the next
     // `persist_skip` calls go straight to the graph path instead of paying the 80 ms spin again; doubles up to 256 on every
     // further time-out, resets on the first success
-    mutable int persist_skip = 0, persist_backoff = 0;
+    mutable int persist_skip = 0, persist_backoff = 0, persist_launch_failures = 0;
     mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mutable hipEvent_t ev_in = nullptr;
     mutable hipStream_t loop_stream = nullptr;   // capture is not allowed on the legacy default stream torch hands us
@@ -1962,8 +1962,17 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
                     set_error("tacotron2_infer: launching the persistent decoder failed: %s", hipGetErrorString(le));
                     return TTSAMD_EHIP;
                 }
-                fprintf(stderr, "ttsamd: tacotron2 persistent decoder could not be launched (%s), using the graph path\n", hipGetErrorString(le));
-                h->persist_skip = 1 << 30;                               // this device / partitioning will not change under us
+                // hipErrorCooperativeLaunchTooLarge can be transient (another stream held CUs at that moment): same bounded back-off
+                // as a hand-off time-out; anything else (LDS opt-in rejected, no cooperative launch on this partitioning) is permanent
+                if (le == hipErrorCooperativeLaunchTooLarge) {
+                    h->persist_backoff = std::min(256, std::max(8, 2 * h->persist_backoff));
+                    h->persist_skip = h->persist_backoff;
+                } else {
+                    h->persist_skip = 1 << 30;
+                }
+                ++h->persist_launch_failures;
+                fprintf(stderr, "ttsamd: tacotron2 persistent decoder could not be launched (%s), using the graph path%s\n", hipGetErrorString(le),
+                        le == hipErrorCooperativeLaunchTooLarge ? " (retrying after a back-off)" : " for the life of this handle");
                 tail[0] = -1;
             } else {
             TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.tail_o + 256, sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -6,7 +6,9 @@ inside the model, only
                only rank 0 reads and packs the checkpoint) or `Dp.broadcast_state_dict` (one flat tensor);
   C2 per call: all-gather of the per-utterance lengths (`Dp.exchange_lens`), then a fan-in of the PACKED
                ragged audio (valid samples only) to rank 0 (`Dp.gather_audio`): world-1 independent
-               point-to-point transfers over the xGMI links, no ring, no reduction.
+               point-to-point transfers over the xGMI links, no ring, no reduction.  The two exchanges run on
+               two channels (one communicator / process group each), so the two-stream schedule of
+               ttsamd.pipeline may issue them from its two streams.
 Transports:
   'rccl'  — libttsamd's `ttsamd_dp_*` entry points (include/ttsamd.h; RCCL bound inside the library, device
             pointers in, nothing torch-specific), bootstrapped with a 128-byte id that rank 0 publishes
@@ -66,21 +68,34 @@ class Dp:
             transport = 'rccl' if (self.backend == 'nccl' and self.device.type == 'cuda') else 'torch'
         assert transport in ('rccl', 'torch')
         self.transport = transport
-        self.comm = None
+        # TWO channels, so that the two exchanges of a call may be issued from two streams (ttsamd.pipeline: the length
+        # all-gather of batch i + 1 on the acoustic stream while the audio fan-in of batch i is still queued behind its
+        # vocoder on the other one).  Operations on ONE communicator must reach the device in the same order on every
+        # rank, which two streams do not promise; each channel by itself is used from one stream at a time, in host order.
+        #   comm / default group       : C1 weight broadcasts and the C2a length all-gather
+        #   comm_audio / group_audio   : the C2b packed audio fan-in
+        self.comm = self.comm_audio = None
+        self.group_audio = None
         self.host_staged = self.backend == 'gloo' and self.device.type == 'cuda'
         if transport == 'rccl':
             from . import lib as L
             self._L, self._lib = L, L.load()
-            ident = (C.c_char * 128)()
+            idents = [(C.c_char * 128)(), (C.c_char * 128)()]
             if self.rank == 0:
-                L.check(self._lib.ttsamd_dp_unique_id(ident), 'dp_unique_id')
-            box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0)            # 128 bytes through the rendezvous store
-            ident = (C.c_char * 128).from_buffer_copy(box[0])
-            comm = C.c_void_p()
+                for ident in idents:
+                    L.check(self._lib.ttsamd_dp_unique_id(ident), 'dp_unique_id')
+            box = [bytes(ident) for ident in idents]
+            dist.broadcast_object_list(box, src=0)            # 2 x 128 bytes through the rendezvous store
+            comms = []
             with torch.cuda.device(self.device):
-                L.check(self._lib.ttsamd_dp_init(self.rank, self.world, ident, C.byref(comm)), 'dp_init')
-            self.comm = comm
+                for raw in box:
+                    comm = C.c_void_p()
+                    L.check(self._lib.ttsamd_dp_init(self.rank, self.world, (C.c_char * 128).from_buffer_copy(raw), C.byref(comm)),
+                            'dp_init')
+                    comms.append(comm)
+            self.comm, self.comm_audio = comms
+        else:
+            self.group_audio = dist.new_group(backend=self.backend)      # every rank calls this (collective)
         st = self.device if not self.host_staged else torch.device('cpu')
         self._lens_send = _Grow(torch.int64, self.device)
         self._lens_recv = _Grow(torch.int64, self.device)
@@ -91,9 +106,11 @@ class Dp:
         self._stage_recv = _Grow(torch.float32, st, pin=True) if self.host_staged else None
 
     def close(self):
-        if self.comm is not None:
-            self._lib.ttsamd_dp_destroy(self.comm)
-            self.comm = None
+        for name in ('comm_audio', 'comm'):
+            comm = getattr(self, name, None)
+            if comm is not None:
+                self._lib.ttsamd_dp_destroy(comm)
+                setattr(self, name, None)
 
     def __del__(self):
         try:
@@ -235,7 +252,7 @@ class Dp:
             off = (C.c_int64 * self.world)(*offsets.tolist())
             with torch.cuda.device(self.device):
                 self._L.check(self._lib.ttsamd_dp_gather_audio(
-                    self.comm, self._ptr(packed) if mine else C.c_void_p(0),
+                    self.comm_audio, self._ptr(packed) if mine else C.c_void_p(0),
                     self._ptr(recv) if recv is not None else C.c_void_p(0), cnt, off, dst, self._stream()), 'dp_gather_audio')
         else:
             self._gather_torch(packed, recv, counts, offsets, dst)
@@ -266,7 +283,7 @@ class Dp:
             if self.rank == dst:
                 flat = self._slot_recv.get(cap * self.world)
                 slots = [flat[r * cap:(r + 1) * cap] for r in range(self.world)]
-            dist.gather(send, slots, dst=dst)
+            dist.gather(send, slots, dst=dst, group=self.group_audio)
             if self.rank == dst:
                 for r in range(self.world):
                     c = int(counts[r])
@@ -281,14 +298,14 @@ class Dp:
             send, rbuf = packed, recv
         if self.rank == dst:
             rbuf[int(offsets[dst]):int(offsets[dst]) + mine] = send
-            reqs = [dist.irecv(rbuf[int(offsets[r]):int(offsets[r] + counts[r])], src=r)
+            reqs = [dist.irecv(rbuf[int(offsets[r]):int(offsets[r] + counts[r])], src=r, group=self.group_audio)
                     for r in range(self.world) if r != dst and counts[r] > 0]
             for q in reqs:
                 q.wait()
             if self.host_staged:
                 recv[:total].copy_(rbuf[:total])
         elif mine > 0:
-            dist.send(send, dst=dst)
+            dist.send(send, dst=dst, group=self.group_audio)
 
 
 # ---- module-level conveniences (default Dp per process) --------------------------------

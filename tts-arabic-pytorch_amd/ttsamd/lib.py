@@ -112,6 +112,7 @@ SYMBOLS = {
 }
 
 _lib = None
+ABI_VERSION = 3            # == TTSAMD_ABI_VERSION of include/ttsamd.h (struct layouts and argument meanings of this binding)
 
 
 def load():
@@ -131,6 +132,10 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    got = lib.ttsamd_version()
+    if got != ABI_VERSION:
+        raise TtsAmdError(f'{LIB_PATH} was built from another revision of include/ttsamd.h (library ABI {got}, this binding '
+                          f'{ABI_VERSION}): rebuild it with `make -C tts-arabic-pytorch_amd/csrc`')
     _lib = lib
     return lib
 
