@@ -253,6 +253,16 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
                       int32_t lin, float in_slope, int32_t relu_out, float* y, float* packed,
                       void* stream);
 
+/* One c1 -> c2 pair of a ResBlock1 (vocoder/hifigan/models.py:46-53) in exact fp32, intermediate in LDS:
+ *   v = x + conv1d(lrelu(conv1d(lrelu(x, slope), w1, dilation dil) + b1, slope), w2) + b2;  y = v | y + v | (y + v) / div  (mode 0 | 1 | 2)
+ * x, y [B][C][L] (y != x), w1 / w2 [C][C][K] (torch layout, DEVICE), lens int64 [B] or NULL (valid length lens[b] * len_mul:
+ * every conv pads at the true edge).  variant 1: first-generation kernel (weights through an LDS ring; C = 32, or C = 64 with
+ * k = 3), 2 / 3: second generation (weights from L2 into a register queue, raw window; 256- / 128-column blocks; C = 32 / 64 /
+ * 128, k = 3 / 7 / 11).  `packed` must hold 2 * C * C * K floats of scratch for the two re-laid-out weight tensors. */
+int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
+                             int32_t channels, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L,
+                             int32_t batch, int32_t mode, float div, float slope, int32_t variant, float* packed, void* stream);
+
 /* ---- bf16 octet engine (BASELINE config 3), kernel-level entries used by the parity tests and the roofline bench.
  *      Activations are [B][C/8][L][8] bf16 ("octet" layout: one 16-byte entry = 8 channels of one position = one lane's B
  *      operand of v_mfma_f32_32x32x16_bf16), stored PRE-ACTIVATED: a = leaky_relu(x, slope of the consumer).  Replaces

@@ -352,6 +352,44 @@ def vocos_forward(w, mel, cfg, denoise=0.0, bias_vec=None, dtype=torch.float32):
     return y / env
 
 
+def hifigan_forward_ragged(w, mel, lens, cfg, dtype=torch.float32):
+    """The reference's per-utterance vocoder loop (models/fastpitch/networks.py:340-345: `Generator.forward` on each exact-length
+    mel) restated on ONE padded batch: mel [B,80,T_max], lens [B] -> wave [B, 256*T_max] (zeros past 256*lens[b]).
+    Before every conv the positions at or past the utterance's own length (lens[b] x upsampling so far) are set to zero, which is
+    exactly what the conv's zero padding shows it in the unbatched call -- every valid output is the same sum of
+    the same products as `hifigan_forward(mel[b, :, :lens[b]])`; only the library's choice of algorithm for the larger shape can
+    differ (tests/test_oracle_golden.py pins the two to each other).  One shape per layer for the whole batch: the full-size GPU
+    checks run it once instead of once per distinct length."""
+    W = {k: v.to(dtype) for k, v in w.items()}
+    x = _t(mel, dtype)
+    lens = torch.as_tensor(lens, device=x.device).to(torch.int64)
+    nk = len(cfg['resblock_kernel_sizes'])
+
+    def masked(t, mul):
+        m = torch.arange(t.shape[-1], device=t.device)[None, None, :] < (lens * mul)[:, None, None]
+        return t * m
+    mul = 1
+    x = F.conv1d(masked(x, mul), W['conv_pre.weight'], W['conv_pre.bias'], padding=3)
+    for i, (u, k) in enumerate(zip(cfg['upsample_rates'], cfg['upsample_kernel_sizes'])):
+        x = F.conv_transpose1d(masked(F.leaky_relu(x, LRELU_SLOPE), mul), W[f'ups.{i}.weight'], W[f'ups.{i}.bias'], stride=u,
+                               padding=(k - u) // 2)
+        mul *= u
+        xs = None
+        for j, (kk, dil) in enumerate(zip(cfg['resblock_kernel_sizes'], cfg['resblock_dilation_sizes'])):
+            r = i * nk + j
+            y = x
+            for m, d in enumerate(dil):
+                xt = F.conv1d(masked(F.leaky_relu(y, LRELU_SLOPE), mul), W[f'resblocks.{r}.convs1.{m}.weight'],
+                              W[f'resblocks.{r}.convs1.{m}.bias'], dilation=d, padding=_get_padding(kk, d))
+                xt = F.conv1d(masked(F.leaky_relu(xt, LRELU_SLOPE), mul), W[f'resblocks.{r}.convs2.{m}.weight'],
+                              W[f'resblocks.{r}.convs2.{m}.bias'], padding=_get_padding(kk, 1))
+                y = xt + y
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = F.conv1d(masked(F.leaky_relu(x), mul), W['conv_post.weight'], W['conv_post.bias'], padding=3)
+    return masked(torch.tanh(x), mul)[:, 0]
+
+
 # --------------------------------------------------------------------------------------
 # The whole .tts_batch-equivalent (used for goldens and as bench.py's cpu_baseline)
 # --------------------------------------------------------------------------------------

@@ -148,3 +148,23 @@ def test_vocos_22k(golden):
     for T in (1, 5, 33):
         assert maxabs(O.vocos_forward(w, g[f'mel_T{T}'], VOCOS_22K_CONFIG, bias_vec=bias), g[f'wave_T{T}']) < 1e-6
         assert maxabs(O.vocos_forward(w, g[f'mel_T{T}'], VOCOS_22K_CONFIG, denoise=0.3, bias_vec=bias), g[f'wave_dn_T{T}']) < 1e-6
+
+
+def test_ragged_batched_vocoder_oracle_equals_the_per_utterance_loop(synth_weights):
+    """`hifigan_forward_ragged` (one padded batch, zero at and past each utterance's own edge before every conv) against the
+    reference's plumbing, `hifigan_forward` on each exact-length mel: same sums of the same products at every valid sample.  The
+    full-size GPU checks use the batched form (one shape per layer instead of one per distinct length)."""
+    import torch
+    import tts_oracle as O
+    from ttsamd.config import HIFIGAN_CONFIG
+    w = O.fold_weight_norm(synth_weights['hifigan'])
+    rng = np.random.default_rng(5)
+    lens = [9, 1, 4, 7]
+    mel = (rng.standard_normal((4, 80, 9)) * 1.5 - 4.0).astype(np.float32)
+    mel[1, :, 1:] = 123.0                       # garbage past an utterance's end must not reach its samples
+    with torch.inference_mode():
+        got = O.hifigan_forward_ragged(w, mel, lens, HIFIGAN_CONFIG)
+        for b, n in enumerate(lens):
+            ref = O.hifigan_forward(w, mel[b, :, :n], HIFIGAN_CONFIG)[0]
+            assert float((got[b, :256 * n] - ref).abs().max()) < 2e-6, b
+            assert n == 9 or float(got[b, 256 * n:].abs().max()) == 0.0

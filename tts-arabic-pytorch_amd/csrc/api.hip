@@ -350,6 +350,36 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
     return rc;
 }
 
+int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
+                             int32_t channels, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L,
+                             int32_t batch, int32_t mode, float div, float slope, int32_t variant, float* packed, void* stream) {
+    TTS_REQUIRE(x && y && w1 && b1 && w2 && b2 && packed && channels % 32 == 0 && k >= 1 && batch >= 1 && L >= 1 && len_mul >= 1 &&
+                mode >= 0 && mode <= 2, "resblock_pair: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)channels * k * channels;
+    for (int i = 0; i < 2; ++i) {
+        hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, i == 0 ? w1 : w2, channels,
+                           channels, k, channels, packed + i * n);
+        TTS_CHECK_HIP(hipGetLastError());
+    }
+    const double fl = 2.0 * (2.0 * channels * channels * k);
+    int32_t rc;
+    prof_begin(s, fl);
+    if (variant == 1) {
+        rc = launch_fused_pair(channels, x, y, packed, b1, packed + n, b2, k, dil, lens, len_mul, L, batch, mode, div, slope, s);
+    } else if (variant == 2 || variant == 3) {
+        rc = launch_fused_pair2(channels, x, y, packed, b1, packed + n, b2, k, dil, lens, len_mul, L, batch, mode, div, slope,
+                                variant == 2 ? 2 : 1, s);
+    } else if (variant == -1) {
+        rc = 0;                                    // the two weight re-layout launches only (tools/fused_pair_bench.py subtracts them)
+    } else {
+        set_error("resblock_pair: variant %d (1: first generation, 2 / 3: second generation with 256- / 128-column blocks)", variant);
+        rc = TTSAMD_EINVAL;
+    }
+    prof_end(s);
+    return rc;
+}
+
 int32_t ttsamd_set_precision(int32_t precision) {
     TTS_REQUIRE(precision >= 0 && precision <= 2, "set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA, 2 = split-bf16 MFMA");
     g_precision = precision;

@@ -120,6 +120,12 @@ bool fused_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, c
 int32_t launch_fused_pair(int32_t channels, const float* x, float* y, const float* w1, const float* b1, const float* w2,
                           const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
                           int32_t mode, float div, float slope, hipStream_t stream);
+// Second generation of the fused pair (resblock_fused2.hip): weights from L2 into a register queue, raw window, 5 barriers per
+// block; C = 32 / 64 / 128 at k = 3 / 7 / 11; ntw = 2: 256-column blocks, 1: 128-column blocks.
+bool fused_pair2_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y, int32_t ntw);
+int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const float* w1, const float* b1, const float* w2,
+                           const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
+                           int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream);
 // Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]
 void pack_conv_weight(const float* w, int cout, int cin, int k, float* out);
 // torch ConvTranspose1d [Cin][Cout][Kt] (Kt = 2u, stride u, padding p) -> [u][Cin][2][CoutP]

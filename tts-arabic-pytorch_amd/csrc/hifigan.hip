@@ -15,6 +15,10 @@
 
 namespace ttsamd {
 
+// default routing of the second-generation fused pair (fused2_choice below), set from same-box A/B runs of the bench workload
+constexpr unsigned kFused2Mask = 0x05F;       // C = 32: k = 3 / 7 / 11; C = 64: k = 3 / 7; C = 128: k = 3
+constexpr unsigned kFused2MaskN1 = 0x040;     // 128-column blocks: C = 128, k = 3 (two blocks per CU)
+
 struct ConvW {
     int64_t w_off = 0, b_off = 0;  // float offsets into the device weight blob
     int64_t w16_off = 0, w_n = 0;  // bf16 planes (hi, lo) in the uint16 blob; packed element count
@@ -59,6 +63,31 @@ static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
         if (!(bfo_env && bfo_env[0] == '0')) return (int64_t)B * T >= 8192;
     }
     return true;
+}
+
+// Which ResBlock pairs of the fp32 engine go out as ONE launch of the second-generation fused kernel (resblock_fused2.hip), and with
+// which block width: 0 = not this pair, 2 = 256-column blocks, 1 = 128-column blocks.  Bit 3 * ci + ki of the masks, ci = 0 / 1 / 2
+// for C = 32 / 64 / 128, ki = 0 / 1 / 2 for k = 3 / 7 / 11.  TTSAMD_FUSED2=0 turns the kernel off, TTSAMD_FUSED2_MASK / _MASK_N1 (hex)
+// replace the defaults (A/B runs and the forced-kernel parity tests); all read per call.
+static int fused2_choice(int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y, int64_t columns) {
+    const char* e = std::getenv("TTSAMD_FUSED2");
+    if (e && e[0] == '0') return 0;
+    const int ci = channels == 32 ? 0 : (channels == 64 ? 1 : (channels == 128 ? 2 : -1));
+    const int ki = k == 3 ? 0 : (k == 7 ? 1 : (k == 11 ? 2 : -1));
+    if (ci < 0 || ki < 0) return 0;
+    unsigned mask = kFused2Mask, mask_n1 = kFused2MaskN1;
+    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK")) mask = (unsigned)std::strtoul(m, nullptr, 16);
+    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK_N1")) mask_n1 = (unsigned)std::strtoul(m, nullptr, 16);
+    const unsigned bit = 1u << (3 * ci + ki);
+    if (!(mask & bit)) return 0;
+    // small problems (batch 1 ... 4): 256-column blocks leave most of the 256 CUs without a block; 128-column blocks double the grid
+    int ntw = (mask_n1 & bit) ? 1 : 2;
+    if (ntw == 2 && columns / 252 < 2 * 256 && !std::getenv("TTSAMD_FUSED2_MASK_N1")) ntw = 1;
+    if (!fused_pair2_supported(channels, k, dil, L, x, y, ntw)) {
+        ntw = 3 - ntw;
+        if (!fused_pair2_supported(channels, k, dil, L, x, y, ntw)) return 0;
+    }
+    return ntw;
 }
 
 using TensorMap = std::map<std::string, const ttsamd_tensor*>;
@@ -554,15 +583,18 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     const bool last = m + 1 == cfg.n_dilations;
                     float* dst = last ? cur : (src == R ? Tb : R);
                     const ConvW &w1 = h->c1[li], &w2 = h->c2[li];
-                    if (fused_ok && w1.cin == w1.cout && w2.cin == w1.cin && w2.cout == w1.cin && w1.k == w2.k &&
-                        fused_pair_supported(w1.cin, w1.k, d, L, src, dst)) {
+                    const bool square = w1.cin == w1.cout && w2.cin == w1.cin && w2.cout == w1.cin && w1.k == w2.k;
+                    const int ntw2 = (fused_ok && square) ? fused2_choice(w1.cin, w1.k, d, L, src, dst, (int64_t)B * L) : 0;
+                    if (ntw2 != 0 || (fused_ok && square && fused_pair_supported(w1.cin, w1.k, d, L, src, dst))) {
                         const int mode = !last ? 0 : (cfg.n_kernels == 1 ? 0 : (j == 0 ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2)));
                         if (multi && last && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
                         const double fl = 2.0 * (2.0 * w1.cin * w1.cin * w1.k) * mul;
                         if (in_section) prof_add(fl); else prof_begin(st, fl);
-                        const int32_t frc = launch_fused_pair(w1.cin, src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
-                                                                  h->dev + w2.b_off, w1.k, d, lens, mul, L, B, mode,
-                                                                  (float)cfg.n_kernels, 0.1f, st);
+                        const int32_t frc = ntw2 != 0
+                            ? launch_fused_pair2(w1.cin, src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
+                                                 h->dev + w2.b_off, w1.k, d, lens, mul, L, B, mode, (float)cfg.n_kernels, 0.1f, ntw2, st)
+                            : launch_fused_pair(w1.cin, src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
+                                                h->dev + w2.b_off, w1.k, d, lens, mul, L, B, mode, (float)cfg.n_kernels, 0.1f, st);
                         if (!in_section) prof_end(st);
                         HG_TRY(frc);
                         if (multi && last) HG_CHECK_HIP(hipEventRecord(h->ev_done[j], st));

@@ -427,6 +427,28 @@ def conv1d(x, w, bias=None, lens=None, dilation=1, in_slope=1.0, relu_out=False)
     return y
 
 
+def resblock_pair(x, w1, b1, w2, b2, dil, lens=None, len_mul=1, y=None, mode=0, div=1.0, slope=0.1, variant=2):
+    """Kernel-level entry (parity tests / roofline bench): one fused c1 -> c2 pair of a ResBlock1 in exact fp32,
+    v = x + conv1d(lrelu(conv1d(lrelu(x), w1, dilation=dil) + b1), w2) + b2; y = v | y + v | (y + v) / div (mode 0 | 1 | 2)."""
+    lib = _require_gpu()
+    x = x.contiguous().float()
+    w1, w2, b1, b2 = (t.contiguous().float() for t in (w1, w2, b1, b2))
+    B, Cc, Lx = x.shape
+    k = w1.shape[2]
+    assert tuple(w1.shape) == tuple(w2.shape) == (Cc, Cc, k)
+    if y is None:
+        assert mode == 0
+        y = torch.zeros_like(x)
+    if lens is not None:
+        lens = lens.to(device=x.device, dtype=torch.int64).contiguous()
+    packed = torch.empty(2 * Cc * Cc * k, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(lib.ttsamd_resblock_pair(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), Cc, k, int(dil), _ptr(lens),
+                                         int(len_mul), Lx, B, int(mode), float(div), float(slope), int(variant), _ptr(packed),
+                                         _stream()), 'resblock_pair')
+    return y
+
+
 def length_regulate(enc, reps, t_max):
     lib = _require_gpu()
     enc = enc.contiguous().float()
