@@ -422,9 +422,9 @@ def main():
     ap.add_argument('--no-small', action='store_true', help='skip the batch 1 / batch 8 sub-results (N=1 only)')
     ap.add_argument('--pipeline', action='store_true', default=None,
                     help='two HIP streams (ttsamd.pipeline): FastPitch of step i+1 under HiFi-GAN of step i, same work and same '
-                         'results per step.  fp32: +0.6 ... 1.3 %% at B=32 (the conv engine is busy either way), so the default is '
-                         'the one-stream schedule; bf16: 12.5 -> 10.6 ms per step (FastPitch is 18 %% of that step and mostly '
-                         'launch- and latency-bound), so --precision bf16 pipelines by default')
+                         'results per step (bit-identical).  The default at every precision and every N: fp32 +2 %% at B=32 (the conv '
+                         'engine is busy either way), bf16 11.2 -> 9.8 ms per step (FastPitch is 18 %% of that step and mostly '
+                         'launch- and latency-bound)')
     ap.add_argument('--no-pipeline', dest='pipeline', action='store_false', help='force the one-stream schedule')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='N > 1: weak = --batch utterances PER RANK (default); strong = --batch utterances in total, B/N per rank '
@@ -530,10 +530,11 @@ def main():
     # step i.  Same work per step, same results; 79.4 -> 78.4 ms per step at B=32 (only FastPitch's non-conv kernels find idle CUs).
     from ttsamd.pipeline import FastPitchHifiGan
     if args.pipeline is None:
-        # default: bf16 at every N, so that `--gpus N` runs the schedule the N = 1 line advertises.  At N > 1 the acoustic stream issues
+        # default: every precision, every N (fp32 B=32: 78.1 -> 76.7 ms per step, bf16: 11.2 -> 9.8), so that `--gpus N` runs the schedule
+        # the N = 1 line advertises; --no-pipeline gives the one-stream schedule.  At N > 1 the acoustic stream issues
         # the length all-gather and the vocoder stream the audio fan-in, each on its OWN communicator (ttsamd.dp.Dp.comm / comm_audio):
         # operations on one communicator would have to reach the device in the same order on every rank, which two streams do not promise
-        args.pipeline = args.precision == 'bf16'
+        args.pipeline = True
     pipe_obj = []
 
     def get_pipe():
@@ -753,9 +754,9 @@ def main():
                                     'lengths rides in the step\'s one host synchronisation')
         if world == 1 and not args.no_small and B > 8:
             out['configs'] = [small_config(1), small_config(8)]
-            if args.precision == 'f32' and not args.pipeline and B == 32:
-                out['configs'].append(small_config(B, pipelined=True, name='C2 (this line\'s workload) on the two-stream schedule: FastPitch of '
-                                                                          'step i+1 under HiFi-GAN of step i, same work and results per step'))
+            if args.precision == 'f32' and args.pipeline and B == 32:
+                out['configs'].append(small_config(B, pipelined=False, name='C2 (this line\'s workload) on the ONE-stream schedule: every '
+                                                                           'launch of a step on the caller\'s stream, same work and results'))
             if not args.no_extra:
                 out['configs'] += extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync)
         if world == 1 and not args.no_extra:

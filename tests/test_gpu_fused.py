@@ -41,7 +41,7 @@ def test_resblock_pair_kernel_vs_float64(C, k, dil, variant):
     g = torch.Generator().manual_seed(1000 * C + 10 * k + dil)
     # block outputs: 256 - (k-1) & ~3 (variant 1 / 2), 128 - (k-1) & ~3 (variant 3): lengths around one and two blocks, one
     # utterance ending inside the halo of a block edge, one shorter than the kernel, one empty
-    ts = ((256 if variant != 3 else 128) - (k - 1)) & ~3
+    ts = ((128 if variant == 3 else 256) - (k - 1)) & ~3
     lens = [2 * ts + 8, ts + 4, ts - 4, ts, 4, 0, 3 * ts - 12]
     Lx = max(lens)
     x = torch.randn(len(lens), C, Lx, generator=g)

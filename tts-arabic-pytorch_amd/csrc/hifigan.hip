@@ -17,7 +17,8 @@ namespace ttsamd {
 
 // default routing of the second-generation fused pair (fused2_choice below), set from same-box A/B runs of the bench workload
 constexpr unsigned kFused2Mask = 0x05F;       // C = 32: k = 3 / 7 / 11; C = 64: k = 3 / 7; C = 128: k = 3
-constexpr unsigned kFused2MaskN1 = 0x040;     // 128-column blocks: C = 128, k = 3 (two blocks per CU)
+constexpr unsigned kFused2MaskN1 = 0x048;     // 128-column blocks: C = 128, k = 3 (two blocks per CU) and C = 64, k = 3 (four)
+constexpr int64_t kFused2SmallColumns = 2 * 256 * 252;   // batch x positions under which a stage counts as a small problem
 
 struct ConvW {
     int64_t w_off = 0, b_off = 0;  // float offsets into the device weight blob
@@ -79,10 +80,18 @@ static int fused2_choice(int32_t channels, int32_t k, int32_t dil, int32_t L, co
     if (const char* m = std::getenv("TTSAMD_FUSED2_MASK")) mask = (unsigned)std::strtoul(m, nullptr, 16);
     if (const char* m = std::getenv("TTSAMD_FUSED2_MASK_N1")) mask_n1 = (unsigned)std::strtoul(m, nullptr, 16);
     const unsigned bit = 1u << (3 * ci + ki);
+    // small problems (batch 1 ... 4: under two rounds of 256-column blocks).  Measured (tools/f2_small.sh): every pair as ONE launch of
+    // 128-column blocks -- half the launches of the un-fused engine -- is SLOWER there (batch 1: 5.27 vs 5.04 ms per step, batch 4: 13.35
+    // vs 12.88; batch 8 equal): the un-fused engine's 64 x 64 tiles with split K put 3-4x more blocks on the chip.  So small problems
+    // keep the un-fused engine; TTSAMD_FUSED2_SMALL=1 routes them through the fused kernel for A/B runs.
+    const char* se = std::getenv("TTSAMD_FUSED2_SMALL");
+    const bool small = columns < (int64_t)kFused2SmallColumns && !std::getenv("TTSAMD_FUSED2_MASK");
+    if (small) {
+        if (!(se && se[0] == '1')) return 0;
+        mask = 0x1ff; mask_n1 = 0x1ff;
+    }
     if (!(mask & bit)) return 0;
-    // small problems (batch 1 ... 4): 256-column blocks leave most of the 256 CUs without a block; 128-column blocks double the grid
     int ntw = (mask_n1 & bit) ? 1 : 2;
-    if (ntw == 2 && columns / 252 < 2 * 256 && !std::getenv("TTSAMD_FUSED2_MASK_N1")) ntw = 1;
     if (!fused_pair2_supported(channels, k, dil, L, x, y, ntw)) {
         ntw = 3 - ntw;
         if (!fused_pair2_supported(channels, k, dil, L, x, y, ntw)) return 0;

@@ -18,6 +18,8 @@
 //     every k, C = 128 fits at all (one block of 256 columns, or two of 128 columns at k = 3 / 7).
 // Tile: 4 waves side by side along time, each C rows x (32 NTW) columns; NB = 128 NTW columns per block of which
 // TS = (NB - (k - 1)) & ~3 are stored (the (k - 1) / 2-column halo of the intermediate is recomputed by the neighbour).
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "conv_mfma_common.hpp"
@@ -36,6 +38,8 @@ struct FusedPair2Params {
     int32_t mode;          // 0: y = v   1: y = y + v   2: y = (y + v) / div
     float div, slope;
     int32_t compact;       // ragged batch: blocks take the lin-th LIVE tile (common.hpp: live_tile)
+    int32_t exp;           // -DTTS_F2_EXP builds only (timing experiments, results wrong): TTSAMD_F2_EXP bit 0 no window loads,
+                           // 1 no phase A, 2 no phase B, 3 no output stores
 };
 
 template <int K, int C, int NTW>
@@ -53,17 +57,15 @@ struct Fused2Geo {
     static constexpr int UO = NOCT * MPO <= 640 ? NOCT : (4 * MPO <= 640 ? 4 : 2);
     static_assert(NOCT % UO == 0 && (UO * K) % PF == 0, "unrolled body of the group loop");
     // resident blocks per CU the register budget is declared for (the LDS window decides at run time whether they fit)
-    static constexpr int WAVES = (C == 128 && NTW == 2) ? 1 : 2;
+    static constexpr int WAVES = (C == 128 && NTW == 2) ? 1 : (C == 32 ? 4 : 2);
     static size_t lds_bytes(int dil) { return (size_t)2 * NOCT * (NB + (K - 1) * dil) * sizeof(float4); }
 };
 
-// leaky_relu(v, slope) for 0 < slope <= 1 as max(v, v * slope): one multiply and ONE v_max_f32 (fmaxf adds a canonicalising
-// v_max(v, v) per operand on this target); a NaN input stays a NaN either way
+// leaky_relu(v, slope) for 0 < slope <= 1 as max(v, v * slope): one multiply and ONE v_med3_f32(v, v * slope, +inf) -- fmaxf adds a
+// canonicalising v_max(v, v) per operand on this target, and an inline-asm v_max is opaque to hipcc's hazard padding in front of the
+// MFMA that reads it.  A NaN input stays a NaN either way.
 __device__ __forceinline__ float lrelu_max(const float v, const float slope) {
-    const float m = v * slope;
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
-    return r;
+    return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff());
 }
 
 // One conv of the pair on one wave: acc[mt][j] += sum over the NG = (C/8) K groups g = (octet o, tap t) of
@@ -147,6 +149,15 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
     int len = p.L;
     if (p.lens) len = min(len, (int)p.lens[b] * p.len_mul);
     if (q0 >= len) return;
+#ifdef TTS_F2_EXP
+    if (p.exp & 16) {      // desynchronise the co-resident blocks of the first round: the second block of every CU starts (exp >> 8) us late
+        const unsigned lin0 = blockIdx.z * gridDim.x + blockIdx.x;
+        if (lin0 >= 256 && lin0 < 512) {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)(p.exp >> 8) * 100) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#endif
     const int dil = p.dil, L = p.L;
     const int pad1 = H * dil;
     const int W1 = NB + (K - 1) * dil;                         // staged columns = row stride of the window
@@ -166,32 +177,31 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
         for (int mt = 0; mt < MT; ++mt) aq[g][mt] = wl1[g * 2 * C + 32 * mt];
 
     // ---- the window: entry e = (o, kk_e, col), four scalar loads (consecutive lanes = consecutive positions), zero outside
-    // the utterance, written raw.  Batches of four entries per thread keep 16 loads in flight.
+    // the utterance, written raw.  ALL of a thread's loads go out before its first LDS write (nothing else is live yet: up to
+    // 4 NE registers): one memory round trip for the whole window instead of one per batch of entries.
     {
+        constexpr int NE = (2 * NOCT * (NB + (K - 1) * DMAX) + 255) / 256;     // entries per thread at the widest dilation
         const int n_ent = 2 * NOCT * W1;
+        float v[NE][4];
+        int eo[NE];
+        bool ok[NE];
         int okk = 0, col = tid;
         while (col >= W1) { col -= W1; ++okk; }
-        for (int e0 = tid; e0 < n_ent; e0 += 4 * 256) {
-            float v[4][4];
-            int eo[4];
-            bool ok[4], in[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int pos = x0 + col;
-                in[u] = e0 + 256 * u < n_ent;
-                ok[u] = in[u] && pos >= 0 && pos < len;
-                const int okc = min(okk, 2 * NOCT - 1);
-                const float* src = xb + (int64_t)((okc >> 1) * 8 + (okc & 1)) * L + min(max(pos, 0), max(len - 1, 0));
+        for (int u = 0; u < NE; ++u) {
+            const int pos = x0 + col;
+            const int okc = min(okk, 2 * NOCT - 1);
+            ok[u] = pos >= 0 && pos < len;
+            eo[u] = tid + 256 * u < n_ent ? okc * W1 + col : -1;
+            const float* src = xb + (int64_t)((okc >> 1) * 8 + (okc & 1)) * L + min(max(pos, 0), max(len - 1, 0));
 #pragma unroll
-                for (int pc = 0; pc < 4; ++pc) v[u][pc] = src[(int64_t)2 * pc * L];
-                eo[u] = okc * W1 + col;
-                col += 256;
-                while (col >= W1) { col -= W1; ++okk; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (in[u]) Xs[eo[u]] = ok[u] ? make_float4(v[u][0], v[u][1], v[u][2], v[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int pc = 0; pc < 4; ++pc) v[u][pc] = src[(int64_t)2 * pc * L];
+            col += 256;
+            while (col >= W1) { col -= W1; ++okk; }
         }
+#pragma unroll
+        for (int u = 0; u < NE; ++u)
+            if (eo[u] >= 0) Xs[eo[u]] = ok[u] ? make_float4(v[u][0], v[u][1], v[u][2], v[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
@@ -207,6 +217,9 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
             for (int j = 0; j < NTW; ++j) acc[mt][j][r] = bv;
         }
 
+#ifdef TTS_F2_EXP
+    if (!(p.exp & 2))
+#endif
     conv_phase2<K, C, NTW, true>(acc, aq, Xs + kk * W1 + colw, W1, dil, wl1, wl2, slope);
 
     // ---- residual out of the window (raw x, exact): register r of tile (mt, j) is channel 32mt + (r&3) + 8(r>>2) + 4kk at
@@ -274,6 +287,9 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
     }
     __syncthreads();
 
+#ifdef TTS_F2_EXP
+    if (!(p.exp & 4))
+#endif
     conv_phase2<K, C, NTW, false>(acc2, aq, Xs + kk * TSTR + colw, TSTR, 1, wl2, wl2, slope);
 
     // ---- epilogue: + b2 [, / div], transposed through LDS (the intermediate is dead after the barrier), float4 row stores
@@ -307,6 +323,9 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
             for (int e = 0; e < 4; ++e) vv[e] = vv[e] / div;
         }
         float* yp = yb + (int64_t)ch * L + q;
+#ifdef TTS_F2_EXP
+        if ((p.exp & 8) && vv[0] != 12345.678f) continue;
+#endif
         if (q + 3 < len) {
             *reinterpret_cast<float4*>(yp) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         } else {
@@ -316,6 +335,7 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
         }
     }
 }
+
 
 template <int K, int C, int NTW>
 static int32_t launch_fused2_k(const FusedPair2Params& p, hipStream_t stream) {
@@ -359,6 +379,9 @@ int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const flo
     p.b1 = b1; p.b2 = b2; p.lens = lens; p.len_mul = len_mul; p.L = L; p.dil = dil; p.batch = batch;
     p.mode = mode; p.div = div; p.slope = slope;
     p.compact = compact_order(lens, batch) ? 1 : 0;
+#ifdef TTS_F2_EXP
+    if (const char* e = getenv("TTSAMD_F2_EXP")) p.exp = atoi(e);
+#endif
 #define TTS_F2(KK, CC, NN) if (k == KK && channels == CC && ntw == NN) return launch_fused2_k<KK, CC, NN>(p, stream);
     TTS_F2(3, 32, 2) TTS_F2(7, 32, 2) TTS_F2(11, 32, 2)
     TTS_F2(3, 64, 2) TTS_F2(7, 64, 2) TTS_F2(11, 64, 2)
