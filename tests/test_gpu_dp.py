@@ -194,7 +194,7 @@ def test_bench_watchdog_restarts_stalled_or_dead_ranks(fault):
     """The parent of a self-launched N > 1 run is the ranks' watchdog: a rank that never reaches the rendezvous (rank 0 then
     blocks for gloo's 30-minute default) or dies must cost the watchdog budget ONCE -- every child is killed, fresh ranks
     start on the torch.distributed transport, and the line says why."""
-    env = dict(os.environ, TTSAMD_BENCH_WATCHDOG_S='60')
+    env = dict(os.environ, TTSAMD_BENCH_WATCHDOG_S='30')
     env[fault] = '1'
     t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
@@ -216,7 +216,7 @@ def test_bench_under_torch_distributed_run(fault):
     Every rank the launcher starts is a supervisor that runs the real rank as a child process (bench.py::_supervise_rank): with no
     fault ONE json line comes out; with a stalled or a dead rank the supervisors agree through a flag file, kill their children
     and restart them once on the torch transport with a rendezvous of their own -- the launcher never sees a failure."""
-    env = dict(os.environ, TTSAMD_BENCH_WATCHDOG_S='60')
+    env = dict(os.environ, TTSAMD_BENCH_WATCHDOG_S='30')
     if fault:
         env[fault] = '1'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',

@@ -16,6 +16,8 @@ from conftest import MEL_TOL, WAVE_TOL, BF16_MEL_TOL, BF16_WAVE_TOL, GOLDEN
 pytestmark = pytest.mark.gpu
 
 B, LT = 32, 64
+T_PAD = 576     # every oracle vocoder call of this file sees mels padded to [32, 80, T_PAD]: MIOpen compiles a kernel per distinct shape
+                # on a fresh box, so the B = 32 fixture and the eight chunks of the 256-utterance test share one set
 
 
 @pytest.fixture(scope='module')
@@ -32,7 +34,8 @@ def workload(synth_weights):
         mel_ref, lens_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids_np, dur_tgt=torch.from_numpy(dur_np).to(dev))
         # the per-utterance vocoder loop as ONE padded batch (oracle/tts_oracle.py: hifigan_forward_ragged, pinned to the loop by
         # tests/test_oracle_golden.py): one shape per layer instead of 32 distinct lengths through MIOpen's per-shape search
-        wave_ref = O.hifigan_forward_ragged(hw, mel_ref, lens_ref, HIFIGAN_CONFIG)
+        assert mel_ref.shape[2] <= T_PAD
+        wave_ref = O.hifigan_forward_ragged(hw, torch.nn.functional.pad(mel_ref, (0, T_PAD - mel_ref.shape[2])), lens_ref, HIFIGAN_CONFIG)
         waves_ref = [wave_ref[b, :256 * int(lens_ref[b])] for b in range(B)]
     torch.cuda.synchronize()
     # the GPU-resident checker itself against the host oracle on one utterance (the longest: batch-independent)
@@ -187,11 +190,13 @@ def test_config3_full_size_256_utterances_bf16(synth_weights):
     dl = dec_lens.cpu().numpy()
     assert np.array_equal(dl, np.asarray(lens_ref.cpu())) and int(dl.sum()) == int(dur_np.sum())      # exact
     worst_mel = worst_wave = 0.0
-    for c0 in range(0, b_full, 64):                                             # the oracle's vocoder in chunks of 64 utterances
-        sl = slice(c0, c0 + 64)
+    assert mel_ref.shape[2] <= T_PAD
+    mel_pad = torch.nn.functional.pad(mel_ref, (0, T_PAD - mel_ref.shape[2]))
+    for c0 in range(0, b_full, B):                                              # the oracle's vocoder in chunks of 32 utterances
+        sl = slice(c0, c0 + B)
         with torch.inference_mode(), torch.device(dev):
-            ref = O.hifigan_forward_ragged(hw, mel_ref[sl], lens_ref[sl], HIFIGAN_CONFIG)
-        for b in range(c0, min(c0 + 64, b_full)):
+            ref = O.hifigan_forward_ragged(hw, mel_pad[sl], lens_ref[sl], HIFIGAN_CONFIG)
+        for b in range(c0, min(c0 + B, b_full)):
             n = int(dl[b])
             worst_mel = max(worst_mel, float((mel[b, :, :n] - mel_ref[b, :, :n]).abs().max()))
             worst_wave = max(worst_wave, float((wave[b, :256 * n] - ref[b - c0, :256 * n]).abs().max()))
@@ -228,7 +233,7 @@ def test_config1_all_100_lines_batch_size_1(synth_weights, tmp_path):
     waves = model.tts(lines, batch_size=1, denoise=0)
     assert len(waves) == len(lines) == 100 and all(w.device.type == 'cpu' and w.dim() == 1 for w in waves)
     # the oracle: FastPitch per line on the HOST (batch of one, exact length: what batch_size = 1 means; 100 distinct lengths would each
-    # cost a per-shape solver search on the GPU), the vocoder as padded batches of 25 lines on the GPU (hifigan_forward_ragged)
+    # cost a per-shape kernel compilation on the GPU), the vocoder as four padded batches of 25 lines of ONE shape on the GPU (hifigan_forward_ragged)
     fw = O.to_torch(synth_weights['fastpitch'])
     hw = {k: v.to(dev) for k, v in O.fold_weight_norm(synth_weights['hifigan']).items()}
     torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -242,10 +247,10 @@ def test_config1_all_100_lines_batch_size_1(synth_weights, tmp_path):
         assert float(torch.minimum(frac, 1.0 - frac).min()) > 1e-4, f'line {i}: a predicted duration sits on a rounding boundary'
         mels.append(mel_ref[0, :, :int(lens_ref[0])])
     worst = 0.0
-    order = sorted(range(len(lines)), key=lambda i: mels[i].shape[1])           # similar lengths share a padded batch
+    order = list(range(len(lines)))
+    t_max = max(m.shape[1] for m in mels)                                       # ONE shape for all four chunks (see T_PAD)
     for c0 in range(0, len(order), 25):
         idx = order[c0:c0 + 25]
-        t_max = max(mels[i].shape[1] for i in idx)
         batch = torch.zeros(len(idx), 80, t_max)
         for r, i in enumerate(idx):
             batch[r, :, :mels[i].shape[1]] = mels[i]

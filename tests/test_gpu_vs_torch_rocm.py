@@ -4,10 +4,10 @@ tokens, fp32, forced durations).  The torch side is oracle/tts_oracle.py (the re
 pinned by tests/test_oracle_golden.py) with its tensors on the GPU; /root/reference itself does not exist on
 the GPU box.  Two variants: the reference's own plumbing (batched FastPitch, vocoder looped per utterance,
 models/fastpitch/networks.py:340-345) and a batched vocoder call on the padded mel, which is what a user
-tuning the reference for throughput would do.  The COMPARISON always runs (same waves on both sides, timings printed and
-written to gpurun_out/torch_rocm_baseline.json: tests/test_gpu_fullsize.py, which runs before this file, has already paid
-MIOpen's first-use kernel compilation); the timing ASSERTION and the MIOpen find-mode variant stay opt-in
-(TTSAMD_TORCH_GPU_BASELINE=1): a shared box must not fail the suite on a noisy clock."""
+tuning the reference for throughput would do.  A MEASUREMENT, not a parity test: it costs three minutes (MIOpen compiles a kernel
+per distinct utterance length on a fresh box), so it runs only with TTSAMD_TORCH_GPU_BASELINE=1 -- profiles/collect.sh sets it and
+keeps gpurun_out/torch_rocm_baseline.json with the round's evidence; the same env var also turns on the timing assertion and the
+MIOpen find-mode variant."""
 import json
 import os
 import time
@@ -19,6 +19,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.skipif(os.environ.get('TTSAMD_TORCH_GPU_BASELINE') != '1', reason='measurement, opt-in: TTSAMD_TORCH_GPU_BASELINE=1')
 def test_hip_path_beats_pytorch_rocm_on_the_same_gpu(synth_weights):
     import tts_oracle as O
     from ttsamd import synth
