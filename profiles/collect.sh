@@ -1,26 +1,26 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r2'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r4'
 # bench line (with cpu_baseline and the batch-1 / batch-8 sub-results), rocprofv3 kernel stats of the same command,
 # FETCH_SIZE / WRITE_SIZE calibration on known-bytes kernels, separate PMC passes, the other precisions and configs.
 set -u
-R=${1:-r3}
+R=${1:-r4}
 O=gpurun_out/collect_$R
 mkdir -p $O
 export TMPDIR=/tmp
 python3 bench.py > $O/final_bench_line.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-small --no-extra > $O/stats.log 2>&1
 # one-stream schedule: per-launch durations that do not overlap (per-instantiation TFLOP/s table)
-TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-small --no-extra > $O/stats1.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --no-pipeline --steps 5 --warmup 2 --no-cpu-baseline --no-small --no-extra > $O/stats1.log 2>&1
 # (the PMC passes below run the one-stream schedule: dispatch order = the library's launch log order)
 # counter calibration: every kernel of tools/bin/traffic_calib moves exactly 1 GiB
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -- tools/bin/traffic_calib > $O/cal.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_write -- tools/bin/traffic_calib >> $O/cal.log 2>&1
 python3 profiles/traffic_calib.py $O/cal_fetch $O/cal_write > $O/traffic_calib.json
 rm -f $O/conv_log.csv
-TTSAMD_HIFIGAN_STREAMS=0 TTSAMD_CONV_LOG=$O/conv_log.csv rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/pmc_fetch.log 2>&1
-TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/pmc_write.log 2>&1
-TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/pmc_mfma.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 TTSAMD_CONV_LOG=$O/conv_log.csv rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --no-pipeline --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/pmc_fetch.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --no-pipeline --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/pmc_write.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --no-pipeline --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/pmc_mfma.log 2>&1
 FRAMES=$(python3 -c "import json;print(json.load(open('$O/final_bench_line.json'))['config']['frames_per_step_rank0'])")
 python3 profiles/traffic_from_pmc.py $O/pmc_fetch $O/pmc_write $O/conv_log.csv $FRAMES $O/traffic_calib.json > $O/traffic.json
 for p in bf16x3 bf16; do python3 bench.py --precision $p --no-cpu-baseline --no-extra > $O/${p}_bench_line.json 2>> $O/bench.err; done
@@ -43,6 +43,10 @@ python3 tools/bfo_bench.py --json $O/bfo_layers.json > $O/bfo_layers.txt 2>> $O/
 rm -rf $O/bstats $O/bstats1 $O/bpmc_fetch $O/bpmc_write $O/bpmc_mfma
 python3 bench.py --gpus 2 --no-cpu-baseline > $O/dp2_one_device_bench_line.json 2>> $O/bench.err
 python3 tools/taco_bench.py > $O/taco_b8.json 2>> $O/bench.err
+# round 4: the fused ResBlock pair kernels of the fp32 engine one launch at a time, the device-count probe, the torch-ROCm baseline (opt-in test)
+python3 tools/fused_pair_bench.py > $O/fused_pair_layers.txt 2>> $O/bench.err
+python3 tools/devcount_probe.py > $O/devcount_probe.txt 2>&1
+TTSAMD_TORCH_GPU_BASELINE=1 python3 -m pytest tests/test_gpu_vs_torch_rocm.py -m gpu -q > $O/torch_rocm_baseline.log 2>&1; cp gpurun_out/torch_rocm_baseline.json $O/ 2>/dev/null
 python3 profiles/summarize.py $(ls $O/stats/*/*kernel_trace.csv | head -1) > $O/by_grid.txt
 python3 profiles/summarize.py $(ls $O/stats1/*/*kernel_trace.csv | head -1) > $O/by_grid_one_stream.txt
 python3 profiles/pmc_summarize.py $O/pmc_mfma > $O/pmc_mfma_by_kernel.txt

@@ -57,7 +57,7 @@ def main():
             kind = log[i][0]
             K, cin, cout, nout, batch, has_res, mode, len_mul, ragged, n_phase = map(int, log[i][1:])
             L = frames * len_mul if ragged else nout * batch          # valid positions summed over the batch
-            if kind == 'fused_pair':
+            if kind.startswith('fused_pair'):                          # resblock_pair / resblock_pair2 (256- and 128-column blocks)
                 alg = 4.0 * cin * L * (2 + (mode != 0))
             elif kind in ('bfo_pair', 'bfo_chain'):                   # bf16 octet engine: bf16 tensors, one read + one write per pair / chained ResBlock
                 alg = 2.0 * cin * L * (2 + (mode != 0))
