@@ -29,3 +29,26 @@ def test_fastpitch_flops_per_utterance():
     attn = 6 * (2 * 2 * 64 * 448) * 448 + 6 * (2 * 2 * 64 * 64) * 64   # QK^T and PV, 1 head of 64, both stacks
     assert abs((conv + attn) / 1e9 - 22.88) < 0.05
     assert abs(dec / 1e6 - 43.71) < 0.02 and abs(enc / 1e6 - 46.60) < 0.02
+
+
+def test_bf16_roofline_bound_follows_the_algorithmic_intensity():
+    """`roofline.bound` of a bf16 launch sequence is whichever roof the algorithmic FLOP / HBM-byte ratio puts first (ridge =
+    2.5 PFLOP/s / 8 TB/s = 312.5): the fused-pair step (562 FLOP/B) is MFMA-bound and `frac` is the MFMA fraction; a layer-wise
+    step (137 FLOP/B) is HBM-bound and `frac` is the HBM fraction.  Both sides always ride along."""
+    b = _bench()
+    r = b.bf16_roofline(9.53e12, 16.95e9, 10e-3)
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - 953.0 / 2500.0) < 1e-6
+    assert abs(r['hbm_frac'] - 1695.0 / 8000.0) < 1e-6 and abs(r['algorithmic_flop_per_byte'] - 562.2) < 0.5
+    r = b.bf16_roofline(9.53e12, 9.53e12 / 137.0, 10e-3)
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['hbm_frac']) < 1e-12
+    assert abs(r['mfma_frac'] - 953.0 / 2500.0) < 1e-6
+
+
+def test_median_and_gpu_count_helpers(tmp_path, monkeypatch):
+    b = _bench()
+    assert b._median([3.0, 1.0, 2.0]) == 2.0 and b._median([4.0, 1.0, 2.0, 3.0]) == 2.5 and b._median([]) is None
+    # the launcher parents count GPUs without the HIP runtime: the visibility variables win over the topology
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,3')
+    assert b._count_gpus() == 2
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert b._count_gpus() == 0

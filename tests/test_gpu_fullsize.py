@@ -137,17 +137,22 @@ def test_config4_full_size_tacotron2_448_steps():
     with torch.inference_mode():
         mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=frames, seed=7)
     eng = Tacotron2Engine(sd, cfg, device=dev)
-    for mode in ('2', '0'):                                                    # persistent dataflow decoder, then the hipGraph path
+    # persistent dataflow decoder in ONE segment (the default: 512 steps per launch), in five segments of 96 steps (launch after launch,
+    # region 0 and the per-thread state handed over: what a decoder_max_step = 3000 call does), then the hipGraph path
+    for mode, seg in (('2', None), ('2', '96'), ('0', None)):
         os.environ['TTSAMD_TACO_PERSISTENT'] = mode
+        if seg:
+            os.environ['TTSAMD_TACO_SEG'] = seg
         try:
             mel, mel_lens, al = eng.infer(tok.to(dev), sids.to(dev), lens.to(dev), max_step=frames, dropout_seed=7)
         finally:
             os.environ.pop('TTSAMD_TACO_PERSISTENT', None)
+            os.environ.pop('TTSAMD_TACO_SEG', None)
         assert mel.shape == (bt, 80, frames) and mel_lens.cpu().tolist() == np.asarray(lens_ref).tolist() == [frames] * bt
         em = float((mel.cpu() - mel_ref).abs().max())
         ea = float((al.cpu() - al_ref).abs().max())
         ea32 = float((al.cpu()[:, :32] - al_ref[:, :32]).abs().max())
-        print(f'full-size config 4 (TTSAMD_TACO_PERSISTENT={mode}): mel max-abs {em:.2e}, alignments max-abs {ea32:.2e} over the first 32 '
+        print(f'full-size config 4 (TTSAMD_TACO_PERSISTENT={mode}, segment {seg or 512}): mel max-abs {em:.2e}, alignments max-abs {ea32:.2e} over the first 32 '
               f'steps, {ea:.2e} over all {frames}')
         # the attention weights feed back into themselves (cumulative location term) and into both LSTMs: fp32 rounding
         # differences between two correct implementations grow along the 448-step trajectory (measured 2.8e-3 at the end

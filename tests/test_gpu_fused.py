@@ -114,3 +114,28 @@ def test_hifigan_every_pair_on_the_second_generation_kernel_vs_oracle(synth_weig
         err = float((wave[b, :256 * n] - ref.reshape(-1)).abs().max())
         assert err < WAVE_TOL, (mask_n1, b, err)
         assert n == 19 or float(wave[b, 256 * n:].abs().max()) == 0.0
+
+
+def test_resblock_pair_entry_rejects_what_it_cannot_run():
+    """C-ABI error behaviour of the kernel-level entry: an unknown variant, a geometry no instantiation covers, x == y (the halo of
+    a neighbouring block would read what this block wrote) and a length that is not a multiple of 4 return an error code with a
+    message instead of launching anything."""
+    from ttsamd.engine import resblock_pair
+    from ttsamd.lib import TtsAmdError
+    dev = torch.device('cuda:0')
+    x = torch.randn(1, 64, 64, device=dev)
+    w = torch.randn(64, 64, 3, device=dev)
+    b = torch.zeros(64, device=dev)
+    with pytest.raises(TtsAmdError, match='variant'):
+        resblock_pair(x, w, b, w, b, 1, variant=9)
+    with pytest.raises(TtsAmdError, match='unsupported geometry'):
+        resblock_pair(x, torch.randn(64, 64, 5, device=dev), b, torch.randn(64, 64, 5, device=dev), b, 1, variant=2)      # k = 5
+    with pytest.raises(TtsAmdError, match='unsupported geometry'):
+        resblock_pair(x, w, b, w, b, 7, variant=2)                                                                          # dilation > 5
+    with pytest.raises(TtsAmdError, match='unsupported geometry'):
+        resblock_pair(x, w, b, w, b, 1, y=x, variant=3)                                                                     # in place
+    with pytest.raises(TtsAmdError, match='unsupported geometry'):
+        resblock_pair(x[:, :, :62].contiguous(), w, b, w, b, 1, variant=2)                                                  # L % 4 != 0
+    with pytest.raises(TtsAmdError, match='unsupported geometry'):
+        resblock_pair(torch.randn(1, 128, 64, device=dev), torch.randn(128, 128, 3, device=dev), torch.zeros(128, device=dev),
+                      torch.randn(128, 128, 3, device=dev), torch.zeros(128, device=dev), 1, variant=1)                     # first generation: C <= 64

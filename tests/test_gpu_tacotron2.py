@@ -297,6 +297,35 @@ def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch, mode):
     assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL
 
 
+@pytest.mark.parametrize('mode', ['1', '2'])
+def test_tacotron2_persistent_decoder_segments(dev, monkeypatch, mode):
+    """The persistent decoder as SEGMENTS of 8 steps, one cooperative launch each (the arena holds one segment; region 0 of a segment is
+    the previous segment's last region, the per-thread cell states / cumulative attention / stop flags travel through the state buffer):
+    utterances stop at steps 12 / 27 / 5 / 21 of 40, i.e. in segments 1 / 3 / 0 / 2, the loop ends inside segment 3 and the fifth
+    launch never happens.  Same trajectory as the oracle, as the one-segment run and -- prenet dropout on -- bit for bit as itself."""
+    import taco_oracle as T
+    from ttsamd.engine import Tacotron2Engine
+    cfg, sd = _weights(gate_bias=-20.0)
+    tok, lens = _tokens(4, 19, 9)
+    sids = torch.tensor([0, 3, 7, 39])
+    stops = [12, 27, 5, 21]
+    sd = _gate_for_stops(cfg, sd, tok, sids, lens, stops, max_step=40, seed=4)
+    mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=40, seed=4)
+    eng = Tacotron2Engine(sd, cfg, device=dev)
+    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
+    mel_one, lens_one, al_one = eng.infer(tok, sids, lens, max_step=40, dropout_seed=4)
+    monkeypatch.setenv('TTSAMD_TACO_SEG', '8')
+    mel, mel_lens, al = eng.infer(tok, sids, lens, max_step=40, dropout_seed=4)
+    mel2, _, _ = eng.infer(tok, sids, lens, max_step=40, dropout_seed=4)
+    assert mel_lens.cpu().tolist() == stops == lens_one.cpu().tolist() and mel.shape == mel_ref.shape
+    assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL
+    assert torch.equal(mel, mel_one) and torch.equal(al, al_one) and torch.equal(mel, mel2)
+    # workspace: one segment of regions, not max_step + 1 (the wrapper's decoder_max_step = 3000 was 0.5-0.9 GB)
+    monkeypatch.delenv('TTSAMD_TACO_SEG')
+    nb = eng.lib.ttsamd_tacotron2_workspace_bytes(eng.handle, 8, 256, 3000)
+    assert nb < 150 * (1 << 20) + 8 * 512 * 3000 * 4 * 2 + 64 * (1 << 20), nb     # arena + the two postnet buffers [8][512][3000] + the rest
+
+
 def test_tacotron2_persistent_decoder_geometries(dev, monkeypatch):
     """The default (persistent, dataflow) decoder against the graph path over the corners of its residency plan: the largest
     token count (256: LDS 155-159 KB per block), both memory dims, odd batch sizes, one step, and back-to-back calls of

@@ -397,7 +397,10 @@ static int32_t bfo_launch_conv_k(const BfoConvParams& p, hipStream_t stream) {
     // short sequences (FastPitch encoder: 64 tokens per utterance): 64-column tiles instead of 256
     // ... and for small grids: with 256-column tiles a batch-1 decoder conv is 2 column tiles
     const int64_t blocks8 = (int64_t)((p.Lin + 255) / 256) * ((p.Cout + 127) / 128) * p.batch;
-    const bool narrow = p.Cout >= 128 && (p.Lin <= 96 || blocks8 < 48);
+    // (a grid of 256-column tiles under one block per CU -- FastPitch's 1536 -> 384 conv at batch 32 is 192 blocks -- takes the 64-column
+    // tiles too: bf16 one-stream step 11.89 -> 11.57 ms, two-stream unchanged; round 3 had the threshold at 48 blocks)
+    static const int64_t narrow_blocks = [] { const char* e = getenv("TTSAMD_BFO_NARROW_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
+    const bool narrow = p.Cout >= 128 && (p.Lin <= 96 || blocks8 < narrow_blocks);
     if (p.y_f32) {
         if (narrow) return bfo_launch_conv_cfg<K, 4, 1, 2, true>(p, stream);
         if (p.Cout >= 128) return bfo_launch_conv_cfg<K, 4, 1, 8, true>(p, stream);

@@ -763,6 +763,8 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
         case 7: if (p.CoutP % 128 == 0) return launch_cfg<K, 2, 1, 2, 2>(p, stream); break;  // 128 co x 64 t, 2x1 tiles per wave
     }
 #endif
+    // (measured and not kept, round 4: a 96 co x 128 t tile for FastPitch's second conv-FF conv -- 1536 -> 384, exactly two blocks per CU
+    // instead of 2.6-2.8 of the 128 x 64 tile -- runs the step in 77.83 vs 77.82 ms: tools/ab_tile96.sh)
     if (p.CoutP % 128 == 0) {
         // deep-K layers on short sequences (HiFi-GAN stage 1: C = 256, 8 positions per frame) have few, long blocks;
         // a launch is then 2-4 rounds of blocks and its tail costs 15-19 %: finer tiles pay there

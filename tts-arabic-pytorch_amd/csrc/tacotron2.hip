@@ -695,8 +695,15 @@ __global__ void taco_advance_kernel(int* step_base, int n) { *step_base += n; }
 struct TacoPersist {
     const float *pre1, *att_wih, *att_whh, *att_b, *dec_wih, *dec_whh, *dec_b, *wq, *loc_fold, *v, *pm, *memory, *projx_w, *projx_b;
     const int64_t* lens;
-    float* xch;                 // (max_step + 1) regions of `step_floats`, then the barrier slots / error flag / step count
+    float* xch;                 // (segment length + 1) regions of `step_floats`, then the barrier slots / error flag / step count
     int64_t tail_o;             // float offset of the tail (slots [256], err, steps)
+    // The loop runs in SEGMENTS of at most TACO_SEG steps, one cooperative launch each (steps [s0, s1) of max_step): the arena holds one
+    // segment (82 MB instead of 0.5-0.9 GB at the wrapper's decoder_max_step = 3000), region 0 of a later segment is the last region of
+    // the one before (copied between the launches, where every XCD's L2 is coherent again -- a ring INSIDE a launch is not possible with
+    // L2-cached first reads: a reused slot can sit in a reader XCD's L2 with its old, valid-looking content), and the per-thread state the
+    // kernel keeps in registers across steps (cell states, cumulative attention, stop flags, frame counts) goes through `state`.
+    int s0, s1;
+    float* state;               // [256 blocks][256 threads][8]: c_att, c_dec, cum, fin, mlen
     int step_floats, Lp, PTp;   // region size; padded row / tile strides (multiples of 32 floats = one 128-byte line)
     float *mel_out, *align_out;
     int32_t* mel_lens;
@@ -908,6 +915,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
     int fin = 0, mlen = 0;
     unsigned epoch = 0;
     int steps = p.max_step;
+    float* stp = p.state + ((int64_t)bid * 256 + tid) * 8;
+    if (p.s0 > 0) {                                                  // a later segment: what the previous launch left in its registers
+        c_att = stp[0]; c_dec = stp[1]; cum = stp[2];
+        fin = __builtin_bit_cast(int, stp[3]); mlen = __builtin_bit_cast(int, stp[4]);
+    }
     const int n4 = b4 < B ? min((int)p.lens[b4], L) : 0;
     __syncthreads();
 
@@ -985,11 +997,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
     taco_i4 rs0;
     TACO_RSRC(rs0, p.xch)
     TACO_ATT_EARLY(rs0, p.xch)                                       // step 0: zero state
-    for (int s = 0; s < p.max_step; ++s) {
-        float* curw = p.xch + (int64_t)(s + 1) * p.step_floats;
+    for (int s = p.s0; s < p.s1; ++s) {
+        float* curw = p.xch + (int64_t)(s - p.s0 + 1) * p.step_floats;
         taco_i4 rs, rq;                                              // this step's region (stores, fresh reads); the previous step's
         TACO_RSRC(rs, curw)
-        TACO_RSRC(rq, p.xch + (int64_t)s * p.step_floats)
+        TACO_RSRC(rq, p.xch + (int64_t)(s - p.s0) * p.step_floats)
 #ifdef TP_TIMING
         unsigned fst[20];
         int fsi = 0;
@@ -1419,9 +1431,9 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #undef TACO_LD4
 #undef TACO_LD1
     } else {
-    for (int s = 0; s < p.max_step; ++s) {
-        const float* prv = p.xch + (int64_t)s * p.step_floats;      // what step s - 1 left (region 0: zeros)
-        float* curw = p.xch + (int64_t)(s + 1) * p.step_floats;     // what this step produces
+    for (int s = p.s0; s < p.s1; ++s) {
+        const float* prv = p.xch + (int64_t)(s - p.s0) * p.step_floats;      // what step s - 1 left (region 0: zeros, or the previous segment's last region)
+        float* curw = p.xch + (int64_t)(s - p.s0 + 1) * p.step_floats;       // what this step produces
         const float* cur = curw;
 #ifdef TP_TIMING
         unsigned tstamp[13];
@@ -1747,6 +1759,8 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #endif
     }
     }   // barrier schedule
+    stp[0] = c_att; stp[1] = c_dec; stp[2] = cum;                    // for the next segment (if any)
+    stp[3] = __builtin_bit_cast(float, fin); stp[4] = __builtin_bit_cast(float, mlen);
     if (bid == 0 && tid == 0) *reinterpret_cast<int32_t*>(p.xch + p.tail_o + 320) = steps;
 }
 #undef XST
@@ -1768,11 +1782,19 @@ struct TWs {
     float *x0, *x1, *xproj, *memory, *pm, *pre, *pq, *energy, *att_h[2], *att_c, *dec_h[2], *dec_c, *aw, *aw_cum, *ctx, *dec_in;
     float *post0, *post1;
     int32_t *finished, *step;
-    // persistent decoder: exchange arena of (Tcap + 1) per-step regions + tail (barrier slots, error flag, step count)
+    // persistent decoder: exchange arena of (segment + 1) per-step regions + tail (barrier slots, error flag, step count)
     float* xch;
     int64_t xch_floats, tail_o;
-    int step_floats, Lp, PTp;
+    int step_floats, Lp, PTp, seg;
+    float* pstate;              // persistent decoder: per-thread state carried from one segment's launch to the next
 };
+
+// steps per launch of the persistent decoder = regions of its exchange arena (TTSAMD_TACO_SEG: tests drive several segments on short runs)
+static int taco_segment_steps() {
+    const char* e = getenv("TTSAMD_TACO_SEG");
+    const int v = e ? atoi(e) : 512;
+    return std::max(8, v);
+}
 
 static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
     const ttsamd_tacotron2_cfg& c = h->cfg;
@@ -1798,9 +1820,11 @@ static void tcarve(const Taco2* h, Arena& a, int B, int L, int Tcap, TWs& w) {
     w.PTp = (int)align_up(((int64_t)std::min(B, 8) * L + 15) / 16, 32);
     w.step_floats = taco_region_floats(w.Lp, w.PTp);
     const bool persist_geo = taco_persistent_wanted() && B <= 8 && L <= 256;   // (taco_decoder_persistent's residency plan; else no arena)
-    w.tail_o = persist_geo ? (int64_t)(Tcap + 1) * w.step_floats : 0;
+    w.seg = std::min(Tcap, taco_segment_steps());
+    w.tail_o = persist_geo ? (int64_t)(w.seg + 1) * w.step_floats : 0;
     w.xch_floats = w.tail_o + 384;
     w.xch = a.take<float>(w.xch_floats);
+    w.pstate = a.take<float>(persist_geo ? (int64_t)256 * 256 * 8 : 0);
     w.post0 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
     w.post1 = a.take<float>((int64_t)B * c.postnet_embedding_dim * Tcap);
     w.step = a.take<int32_t>(1);
@@ -1945,39 +1969,49 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             const void* fn = flow ? (M == 512 ? (const void*)taco_decoder_persistent<512, true> : (const void*)taco_decoder_persistent<640, true>)
                                   : (M == 512 ? (const void*)taco_decoder_persistent<512, false> : (const void*)taco_decoder_persistent<640, false>);
             std::lock_guard<std::mutex> lock(h->mu);
-            if (flow)    // every word a consumer may poll starts as the sentinel 0xFFFFFFFF
-                TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0xFF, (size_t)w.tail_o * sizeof(float), s));
-            TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0, (size_t)w.step_floats * sizeof(float), s));                 // region 0: the zero initial state
-            TTS_CHECK_HIP(hipMemsetAsync(w.xch + w.tail_o, 0, 384 * sizeof(float), s));                        // barrier slots, error flag, step count
+            q.state = w.pstate;
             void* args[] = {&q};
             const double t0 = now_us();
-            // LDS opt-in or cooperative launch rejected (another partitioning / device, hipErrorCooperativeLaunchTooLarge): the
-            // graph path below still works, so only an explicit request turns this into an error
-            hipError_t le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (le == hipSuccess) le = hipLaunchCooperativeKernel(fn, dim3(256), dim3(256), args, (unsigned)lds, s);
             int32_t tail[2] = {0, 0};                                   // err_o and steps_o are 64 floats apart: two copies
-            if (le != hipSuccess) {
-                (void)hipGetLastError();
-                if (explicit_req) {
-                    set_error("tacotron2_infer: launching the persistent decoder failed: %s", hipGetErrorString(le));
-                    return TTSAMD_EHIP;
+            // one cooperative launch per segment of at most w.seg steps (TacoPersist: why); a whole bench-size decode (448 steps) is one
+            for (int s0 = 0; s0 < max_step; s0 += w.seg) {
+                q.s0 = s0;
+                q.s1 = std::min(max_step, s0 + w.seg);
+                if (s0 > 0)    // region 0 of this segment = what the last step of the previous one produced
+                    TTS_CHECK_HIP(hipMemcpyAsync(w.xch, w.xch + (int64_t)w.seg * w.step_floats, (size_t)w.step_floats * sizeof(float),
+                                                 hipMemcpyDeviceToDevice, s));
+                if (flow)    // every word a consumer may poll starts as the sentinel 0xFFFFFFFF (regions 1 ... of this segment)
+                    TTS_CHECK_HIP(hipMemsetAsync(w.xch + w.step_floats, 0xFF, (size_t)(w.tail_o - w.step_floats) * sizeof(float), s));
+                if (s0 == 0) TTS_CHECK_HIP(hipMemsetAsync(w.xch, 0, (size_t)w.step_floats * sizeof(float), s));    // region 0: the zero initial state
+                TTS_CHECK_HIP(hipMemsetAsync(w.xch + w.tail_o, 0, 384 * sizeof(float), s));                        // barrier slots, error flag, step count
+                // LDS opt-in or cooperative launch rejected (another partitioning / device, hipErrorCooperativeLaunchTooLarge): the
+                // graph path below still works, so only an explicit request turns this into an error
+                hipError_t le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (le == hipSuccess) le = hipLaunchCooperativeKernel(fn, dim3(256), dim3(256), args, (unsigned)lds, s);
+                if (le != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (explicit_req) {
+                        set_error("tacotron2_infer: launching the persistent decoder failed: %s", hipGetErrorString(le));
+                        return TTSAMD_EHIP;
+                    }
+                    // hipErrorCooperativeLaunchTooLarge can be transient (another stream held CUs at that moment): same bounded back-off
+                    // as a hand-off time-out; anything else (LDS opt-in rejected, no cooperative launch on this partitioning) is permanent
+                    if (le == hipErrorCooperativeLaunchTooLarge) {
+                        h->persist_backoff = std::min(256, std::max(8, 2 * h->persist_backoff));
+                        h->persist_skip = h->persist_backoff;
+                    } else {
+                        h->persist_skip = 1 << 30;
+                    }
+                    ++h->persist_launch_failures;
+                    fprintf(stderr, "ttsamd: tacotron2 persistent decoder could not be launched (%s), using the graph path%s\n", hipGetErrorString(le),
+                            le == hipErrorCooperativeLaunchTooLarge ? " (retrying after a back-off)" : " for the life of this handle");
+                    tail[0] = -1;
+                    break;
                 }
-                // hipErrorCooperativeLaunchTooLarge can be transient (another stream held CUs at that moment): same bounded back-off
-                // as a hand-off time-out; anything else (LDS opt-in rejected, no cooperative launch on this partitioning) is permanent
-                if (le == hipErrorCooperativeLaunchTooLarge) {
-                    h->persist_backoff = std::min(256, std::max(8, 2 * h->persist_backoff));
-                    h->persist_skip = h->persist_backoff;
-                } else {
-                    h->persist_skip = 1 << 30;
-                }
-                ++h->persist_launch_failures;
-                fprintf(stderr, "ttsamd: tacotron2 persistent decoder could not be launched (%s), using the graph path%s\n", hipGetErrorString(le),
-                        le == hipErrorCooperativeLaunchTooLarge ? " (retrying after a back-off)" : " for the life of this handle");
-                tail[0] = -1;
-            } else {
-            TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.tail_o + 256, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            TTS_CHECK_HIP(hipMemcpyAsync(&tail[1], w.xch + w.tail_o + 320, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            TTS_CHECK_HIP(hipStreamSynchronize(s));
+                TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.tail_o + 256, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                TTS_CHECK_HIP(hipMemcpyAsync(&tail[1], w.xch + w.tail_o + 320, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                TTS_CHECK_HIP(hipStreamSynchronize(s));
+                if (tail[0] != 0 || tail[1] < q.s1) break;              // a time-out, or every utterance's gate fired inside this segment
             }
             if (dbg) fprintf(stderr, "[taco] persistent decoder: %.0f us for %d steps (%zu B of LDS per block)\n", now_us() - t0, (int)tail[1], lds);
             if (tail[0] != 0) {
@@ -2001,7 +2035,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
             }
             if (const char* dump = done ? getenv("TTSAMD_TACO_DUMP") : nullptr) {   // debugging aid: the region the last step produced
                 std::vector<float> hx((size_t)w.step_floats);
-                TTS_CHECK_HIP(hipMemcpy(hx.data(), w.xch + (int64_t)steps * w.step_floats, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
+                TTS_CHECK_HIP(hipMemcpy(hx.data(), w.xch + (int64_t)(steps - (steps > 0 ? (steps - 1) / w.seg * w.seg : 0)) * w.step_floats, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
                 if (FILE* f = fopen(dump, "wb")) {
                     const int32_t hdr[8] = {B, L, M, steps, w.Lp, w.PTp, w.step_floats, 0};
                     fwrite(hdr, sizeof(hdr), 1, f);
