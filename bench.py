@@ -118,6 +118,31 @@ def _cpu_worker(job):
         return n_samples, n_utts, time.perf_counter() - t0
 
 
+def _usable_cpus():
+    """Cores this process may actually use: the affinity mask and the cgroup CPU quota (cpu.max / cfs_quota) cap what os.cpu_count()
+    reports -- a 256-thread host behind a 32-core quota runs 256 threads SLOWER than 32 (the thread sweep of cpu_baseline shows it)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                     # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()
+            if q != 'max':
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:   # cgroup v1
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
 def cpu_baseline_all_cores(tokens, threads=8, seconds=12.0):
     """Utterance-parallel CPU baseline on the WHOLE host: N = host_cpus // threads worker processes x `threads` intra-op threads,
     each synthesising distinct utterances one at a time (utterances are independent, so this is how a CPU deployment of the
@@ -125,7 +150,9 @@ def cpu_baseline_all_cores(tokens, threads=8, seconds=12.0):
     Aggregate = total samples / the slowest worker's time."""
     import multiprocessing as mp
     host = os.cpu_count() or 1
-    n = max(1, min(host // threads, 64))
+    usable, quota = _usable_cpus()
+    eff = int(min(usable, quota)) if quota else usable
+    n = max(1, min(eff // threads, 64))
     ctx = mp.get_context('spawn')
     t0 = time.perf_counter()
     with ctx.Pool(n) as pool:
@@ -133,7 +160,7 @@ def cpu_baseline_all_cores(tokens, threads=8, seconds=12.0):
     wall = time.perf_counter() - t0
     samples, utts, slowest = sum(r[0] for r in res), sum(r[1] for r in res), max(r[2] for r in res)
     return {'value': samples / slowest, 'unit': 'audio samples/s', 'cores': n * threads, 'workers': n, 'threads_per_worker': threads,
-            'host_cpus': host, 'kind': 'port',
+            'host_cpus': host, 'usable_cpus': usable, 'cgroup_cpu_quota': quota, 'kind': 'port',
             'sample': f'{utts} distinct utterances x {tokens} tokens over {n} worker processes x {threads} threads, '
                       f'{slowest:.1f} s timed per worker ({wall:.1f} s incl. process start-up and weight synthesis)'}
 

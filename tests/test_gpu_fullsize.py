@@ -237,20 +237,23 @@ def test_config1_all_100_lines_batch_size_1(synth_weights, tmp_path):
                            vocoder_config=str(tmp_path / 'config.json')).to(dev)
     waves = model.tts(lines, batch_size=1, denoise=0)
     assert len(waves) == len(lines) == 100 and all(w.device.type == 'cpu' and w.dim() == 1 for w in waves)
-    # the oracle: FastPitch per line on the HOST (batch of one, exact length: what batch_size = 1 means; 100 distinct lengths would each
-    # cost a per-shape kernel compilation on the GPU), the vocoder as four padded batches of 25 lines of ONE shape on the GPU (hifigan_forward_ragged)
-    fw = O.to_torch(synth_weights['fastpitch'])
+    # the oracle: FastPitch per line (batch of one, exact length: what batch_size = 1 means), the vocoder as four padded batches of 25 lines of ONE shape on the GPU (hifigan_forward_ragged)
+    import time
+    fw = {k: v.to(dev) for k, v in O.to_torch(synth_weights['fastpitch']).items()}
     hw = {k: v.to(dev) for k, v in O.fold_weight_norm(synth_weights['hifigan']).items()}
-    torch.set_num_threads(min(32, torch.get_num_threads()))
     mels, n_tok = [], []
-    for i in range(len(lines)):
-        ids = np.asarray(g['flat'][g['offsets'][i]:g['offsets'][i + 1]], np.int64)[None]
-        n_tok.append(ids.shape[1])
-        with torch.inference_mode():
-            mel_ref, lens_ref, dur_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids)
-        frac = (dur_ref.reshape(-1).double() + 0.5) % 1.0
-        assert float(torch.minimum(frac, 1.0 - frac).min()) > 1e-4, f'line {i}: a predicted duration sits on a rounding boundary'
-        mels.append(mel_ref[0, :, :int(lens_ref[0])])
+    t0 = time.time()
+    # ATen's own conv kernels (MIOpen off): 100 distinct lengths would otherwise each cost a per-shape kernel compilation on a fresh box
+    with torch.backends.cudnn.flags(enabled=False):
+        for i in range(len(lines)):
+            ids = np.asarray(g['flat'][g['offsets'][i]:g['offsets'][i + 1]], np.int64)[None]
+            n_tok.append(ids.shape[1])
+            with torch.inference_mode(), torch.device(dev):
+                mel_ref, lens_ref, dur_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids)
+            frac = (dur_ref.reshape(-1).double() + 0.5) % 1.0
+            assert float(torch.minimum(frac, 1.0 - frac).min()) > 1e-4, f'line {i}: a predicted duration sits on a rounding boundary'
+            mels.append(mel_ref[0, :, :int(lens_ref[0])].cpu())
+    t_fp = time.time() - t0
     worst = 0.0
     order = list(range(len(lines)))
     t_max = max(m.shape[1] for m in mels)                                       # ONE shape for all four chunks (see T_PAD)
@@ -266,5 +269,6 @@ def test_config1_all_100_lines_batch_size_1(synth_weights, tmp_path):
             n = 256 * int(lens_c[r])
             assert waves[i].numel() == n, (i, waves[i].numel(), n)
             worst = max(worst, float((waves[i] - ref[r, :n]).abs().max()))
-    print(f'config 1, 100 lines ({min(n_tok)}-{max(n_tok)} tokens), batch_size 1: wave max-abs {worst:.2e} (tol {WAVE_TOL})')
+    print(f'config 1, 100 lines ({min(n_tok)}-{max(n_tok)} tokens), batch_size 1: wave max-abs {worst:.2e} (tol {WAVE_TOL}); '
+          f'oracle FastPitch {t_fp:.1f} s, whole oracle {time.time() - t0:.1f} s')
     assert worst < WAVE_TOL
