@@ -2,8 +2,9 @@
 (config 2: 32 utterances x 64 tokens, forced durations) and config 3's per-GPU share in its bf16 modes.
 
 The checker is oracle/tts_oracle.py — the restatement of the reference pinned to the real reference by
-tests/test_oracle_golden.py — run with its tensors ON THE GPU (torch-ROCm: MIOpen / rocBLAS fp32), because on
-the host it needs ~1 s per utterance.  It follows the reference's plumbing exactly: FastPitch on the padded
+tests/test_oracle_golden.py — run with its tensors ON THE GPU, because on the host it needs ~1 s per utterance; with MIOpen
+switched OFF (`torch.backends.cudnn.flags(enabled=False)`: ATen's own conv kernels + rocBLAS): on a fresh box MIOpen compiles a
+kernel per distinct shape — 123 s for the first vocoder call of a new shape against 1.5 s, same results to 1.6e-6.  It follows the reference's plumbing exactly: FastPitch on the padded
 batch, then the vocoder looped per utterance on exact-length mels (models/fastpitch/networks.py:334-345).
 Tolerances (BASELINE.json north_star): mel 1e-3, wave 1e-4 max-abs, dec_lens exact; bf16 operands have their own
 stated tolerances (tests/conftest.py)."""
@@ -30,7 +31,7 @@ def workload(synth_weights):
     ids_np, dur_np = synth.synth_ids(B, LT), synth.synth_durations(B, LT)
     fw = {k: v.to(dev) for k, v in O.to_torch(synth_weights['fastpitch']).items()}
     hw = {k: v.to(dev) for k, v in O.fold_weight_norm(synth_weights['hifigan']).items()}
-    with torch.inference_mode(), torch.device(dev):
+    with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
         mel_ref, lens_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids_np, dur_tgt=torch.from_numpy(dur_np).to(dev))
         # the per-utterance vocoder loop as ONE padded batch (oracle/tts_oracle.py: hifigan_forward_ragged, pinned to the loop by
         # tests/test_oracle_golden.py): one shape per layer instead of 32 distinct lengths through MIOpen's per-shape search
@@ -97,7 +98,7 @@ def test_config5_full_batch_every_utterance(synth_weights):
     fp, voc = FastPitchEngine(sd4, cfg4, device=dev), VocosEngine(vw, device=dev)
     worst_mel = worst_wave = 0.0
     for spk in (1, 3):
-        with torch.inference_mode(), torch.device(dev):
+        with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
             mel_ref, lens_ref, *_ = O.fastpitch_infer(fw, cfg4, ids_np, dur_tgt=torch.from_numpy(dur_np).to(dev), speaker=spk)
         mel, dec_lens, *_ = fp.infer(torch.from_numpy(ids_np).to(dev), dur_tgt=torch.from_numpy(dur_np).to(dev), speaker=spk)
         wave = voc.forward(mel, dec_lens)
@@ -107,7 +108,7 @@ def test_config5_full_batch_every_utterance(synth_weights):
         for b in range(B):
             n = int(dl[b])
             worst_mel = max(worst_mel, float((mel[b, :, :n] - mel_ref[b, :, :n]).abs().max()))
-            with torch.inference_mode(), torch.device(dev):
+            with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
                 ref = O.vocos_forward(vwd, mel_ref[b:b + 1, :, :n], VOCOS_22K_CONFIG)[0]
             worst_wave = max(worst_wave, float((wave[b, :256 * n] - ref).abs().max()))
             assert n * 256 == wave.shape[1] or float(wave[b, 256 * n:].abs().max()) == 0.0
@@ -190,7 +191,7 @@ def test_config3_full_size_256_utterances_bf16(synth_weights):
         set_precision('f32')
     fw = {k: v.to(dev) for k, v in O.to_torch(synth_weights['fastpitch']).items()}
     hw = {k: v.to(dev) for k, v in O.fold_weight_norm(synth_weights['hifigan']).items()}
-    with torch.inference_mode(), torch.device(dev):
+    with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
         mel_ref, lens_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids_np, dur_tgt=dur)
     dl = dec_lens.cpu().numpy()
     assert np.array_equal(dl, np.asarray(lens_ref.cpu())) and int(dl.sum()) == int(dur_np.sum())      # exact
@@ -199,7 +200,7 @@ def test_config3_full_size_256_utterances_bf16(synth_weights):
     mel_pad = torch.nn.functional.pad(mel_ref, (0, T_PAD - mel_ref.shape[2]))
     for c0 in range(0, b_full, B):                                              # the oracle's vocoder in chunks of 32 utterances
         sl = slice(c0, c0 + B)
-        with torch.inference_mode(), torch.device(dev):
+        with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
             ref = O.hifigan_forward_ragged(hw, mel_pad[sl], lens_ref[sl], HIFIGAN_CONFIG)
         for b in range(c0, min(c0 + B, b_full)):
             n = int(dl[b])
@@ -243,16 +244,14 @@ def test_config1_all_100_lines_batch_size_1(synth_weights, tmp_path):
     hw = {k: v.to(dev) for k, v in O.fold_weight_norm(synth_weights['hifigan']).items()}
     mels, n_tok = [], []
     t0 = time.time()
-    # ATen's own conv kernels (MIOpen off): 100 distinct lengths would otherwise each cost a per-shape kernel compilation on a fresh box
-    with torch.backends.cudnn.flags(enabled=False):
-        for i in range(len(lines)):
-            ids = np.asarray(g['flat'][g['offsets'][i]:g['offsets'][i + 1]], np.int64)[None]
-            n_tok.append(ids.shape[1])
-            with torch.inference_mode(), torch.device(dev):
-                mel_ref, lens_ref, dur_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids)
-            frac = (dur_ref.reshape(-1).double() + 0.5) % 1.0
-            assert float(torch.minimum(frac, 1.0 - frac).min()) > 1e-4, f'line {i}: a predicted duration sits on a rounding boundary'
-            mels.append(mel_ref[0, :, :int(lens_ref[0])].cpu())
+    for i in range(len(lines)):
+        ids = np.asarray(g['flat'][g['offsets'][i]:g['offsets'][i + 1]], np.int64)[None]
+        n_tok.append(ids.shape[1])
+        with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
+            mel_ref, lens_ref, dur_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids)
+        frac = (dur_ref.reshape(-1).double() + 0.5) % 1.0
+        assert float(torch.minimum(frac, 1.0 - frac).min()) > 1e-4, f'line {i}: a predicted duration sits on a rounding boundary'
+        mels.append(mel_ref[0, :, :int(lens_ref[0])].cpu())
     t_fp = time.time() - t0
     worst = 0.0
     order = list(range(len(lines)))
@@ -263,7 +262,7 @@ def test_config1_all_100_lines_batch_size_1(synth_weights, tmp_path):
         for r, i in enumerate(idx):
             batch[r, :, :mels[i].shape[1]] = mels[i]
         lens_c = torch.tensor([mels[i].shape[1] for i in idx])
-        with torch.inference_mode(), torch.device(dev):
+        with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
             ref = O.hifigan_forward_ragged(hw, batch.to(dev), lens_c.to(dev), HIFIGAN_CONFIG).cpu()
         for r, i in enumerate(idx):
             n = 256 * int(lens_c[r])
