@@ -724,12 +724,14 @@ def main():
         achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes per conv launch: OFFLINE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (profiles/rN/traffic.json; gpurun forbids mixing PMC with the timed run), newest round first
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_alg = None, None, None
         if B == 32 and Lt == 64 and world == 1:
             for rnd in ('r4', 'r3', 'r2', 'r1'):
                 try:
                     with open(os.path.join(REPO, 'profiles', rnd, 'traffic.json' if args.precision == 'f32' else f'traffic_{args.precision}.json')) as f:
-                        traffic = json.load(f)['bytes_per_conv_launch_corrected']
+                        tj = json.load(f)
+                    traffic = tj['bytes_per_conv_launch_corrected']
+                    traffic_alg = tj.get('algorithmic_bytes_per_conv_launch')
                     traffic_src = f'offline PMC pass, profiles/{rnd}/' + ('traffic.json' if args.precision == 'f32' else f'traffic_{args.precision}.json')
                     break
                 except (OSError, KeyError):
@@ -752,6 +754,7 @@ def main():
                     'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
+                     'traffic_algorithmic': traffic_alg, 'traffic_ratio': (traffic / traffic_alg) if (traffic and traffic_alg) else None,
                      'launches': int(n_launch), 'sections': int(n_sections),
                      'avg_section_ms': conv_ms / max(1.0, n_sections), 'avg_launch_ms': conv_ms / max(1.0, n_launch),
                      'launch_note': 'a section = one event pair = a single launch or a fork..join group of up to 18 concurrent '
