@@ -107,9 +107,9 @@ typedef struct ttsamd_tagger_cfg {
 const char* ttsamd_last_error(void);
 /* ABI revision of this header.  Bumped whenever a struct gains a field or an argument changes meaning (2: ttsamd_tacotron2_cfg
  * gained decoder_early_stopping, ttsamd_profile_read's third value became the number of timed sections; 3: ttsamd_dp_* may be
- * bound twice per process, one communicator per stream).  ttsamd_version() returns the value the library was BUILT with: a caller
+ * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument).  ttsamd_version() returns the value the library was BUILT with: a caller
  * compiled against another revision must refuse to run (ttsamd/lib.py does). */
-#define TTSAMD_ABI_VERSION 3
+#define TTSAMD_ABI_VERSION 4
 int32_t ttsamd_version(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
 int32_t ttsamd_device_ok(void);
@@ -298,7 +298,7 @@ int32_t ttsamd_bfo_resblock_pair(const void* x, const void* w1, const float* b1,
 int32_t ttsamd_bfo_resblock_chain(const void* x, const void* const* w1, const float* const* b1, const void* const* w2,
                                   const float* const* b2, const int32_t* dilations, const void* sum_in, const int64_t* lens,
                                   int32_t len_mul, int32_t batch, int32_t channels, int32_t len, int32_t mode, float div,
-                                  float in_slope, float mid_slope, float out_slope, void* y, void* stream);
+                                  float in_slope, float mid_slope, float out_slope, void* y, void* stream, int32_t k);
 /* wave[b][t] = tanh(bias + conv7(x)); x = 32-channel octet tensor already activated with slope 0.01 (models.py:123-125) */
 int32_t ttsamd_bfo_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul,
                              int32_t batch, int32_t channels, int32_t len, float* wave, int64_t wave_stride, void* stream);

@@ -105,19 +105,22 @@ def test_resblock_pair(dev, monkeypatch, C, k, dil, L, mode, out_slope, small_ti
         assert torch.equal(got[i, :, n:], before[i, :, n:]), 'positions past the utterance must stay untouched'
 
 
-@pytest.mark.parametrize('C,L,mode,out_slope,B', [(128, 700, 0, 1.0, 3), (64, 900, 1, 1.0, 3), (32, 1500, 2, 0.1, 3), (128, 300, 2, 0.01, 70)])
-def test_resblock_chain_equals_three_pairs_bit_for_bit(dev, C, L, mode, out_slope, B):
-    """The whole k = 3 ResBlock in one launch (bfo_chain.hip) against three fused-pair launches of the same weights: identical bits
-    (the chained kernel rounds the tensor between two pairs exactly where the pair launch rounds it for HBM).  Ragged batch: an
-    utterance ending inside the 24-column halo of a 232-column tile, one shorter than a tile, (last case) more than 64 utterances."""
+@pytest.mark.parametrize('C,L,mode,out_slope,B,k', [(128, 700, 0, 1.0, 3, 3), (64, 900, 1, 1.0, 3, 3), (32, 1500, 2, 0.1, 3, 3), (128, 300, 2, 0.01, 70, 3),
+                                                    (64, 900, 0, 1.0, 3, 7), (32, 1500, 1, 1.0, 3, 7), (64, 700, 2, 0.01, 70, 7), (32, 1300, 2, 0.1, 5, 7)])
+def test_resblock_chain_equals_three_pairs_bit_for_bit(dev, monkeypatch, C, L, mode, out_slope, B, k):
+    """The whole ResBlock in one launch (bfo_chain.hip; k = 3, and k = 7 at C <= 64) against three fused-pair launches of the same
+    weights: identical bits (the chained kernel rounds the tensor between two pairs exactly where the pair launch rounds it for HBM).
+    Ragged batch: an utterance ending inside the halo of a tile (24 of 256 / 512 columns at k = 3, 72 at k = 7), one shorter than a
+    tile, (one case each) more than 64 utterances."""
     from ttsamd import bfo
-    g = torch.Generator().manual_seed(C + L + mode)
+    monkeypatch.setenv('TTSAMD_BFO_CHAIN7', '1')
+    g = torch.Generator().manual_seed(C + L + mode + k)
     dils = (1, 3, 5)
     x = torch.randn(B, C, L, generator=g) * 1.5
-    ws = [[torch.randn(C, C, 3, generator=g) / np.sqrt(C * 3) for _ in range(3)] for _ in range(2)]
+    ws = [[torch.randn(C, C, k, generator=g) / np.sqrt(C * k) for _ in range(3)] for _ in range(2)]
     bs = [[torch.randn(C, generator=g) * 0.3 for _ in range(3)] for _ in range(2)]
     s_raw = torch.randn(B, C, L, generator=g)
-    ts = {128: 256, 64: 256, 32: 512}[C] - 24
+    ts = {128: 256, 64: 256, 32: 512}[C] - (k - 1) * 12
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2] = L, min(L, ts + 5), max(1, min(L, ts) - 9)
     lens_d = lens.to(dev)
@@ -129,13 +132,13 @@ def test_resblock_chain_equals_three_pairs_bit_for_bit(dev, C, L, mode, out_slop
     for m in range(3):
         last = m == 2
         y = (so.clone() if mode != 0 else torch.full_like(xo, 0x4242)) if last else torch.zeros_like(xo)
-        bfo.resblock_pair(t, w1p[m], b1d[m], w2p[m], b2d[m], 3, dils[m], lens=lens_d, sum_in=y if (last and mode != 0) else None,
+        bfo.resblock_pair(t, w1p[m], b1d[m], w2p[m], b2d[m], k, dils[m], lens=lens_d, sum_in=y if (last and mode != 0) else None,
                           mode=mode if last else 0, div=3.0, out_slope=out_slope if last else 0.1, y=y)
         t = y
     ref = t
     y = so.clone() if mode != 0 else torch.full_like(xo, 0x4242)
     bfo.resblock_chain(xo, w1p, b1d, w2p, b2d, dils, lens=lens_d, sum_in=y if mode != 0 else None, mode=mode, div=3.0,
-                       out_slope=out_slope, y=y)
+                       out_slope=out_slope, y=y, k=k)
     torch.cuda.synchronize()
     assert torch.equal(y, ref)
 
@@ -292,6 +295,32 @@ def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch
     print(f'bf16 attention vs fp32 attention (both under bf16 GEMMs): {worst_ab:.2e}; vs the fp32 engine: {worst_a:.2e} (fp32 attention: {worst_b:.2e})')
     assert bool(torch.isfinite(mel_a).all())
     assert worst_a < BF16_MEL_TOL and worst_ab < 4e-2
+
+
+def test_hifigan_bf16_chained_resblocks_change_no_bit(dev, synth_weights, monkeypatch):
+    """The generator's launch schedule is a routing choice, not a numeric one: three pair launches per ResBlock, the k = 3 ResBlocks
+    chained, the k = 7 ResBlocks of the C = 32 / 64 stages chained as well (the default below 1.5 M columns) -- the same waveform bits on
+    a ragged batch."""
+    from ttsamd.engine import HifiGanEngine, set_precision
+    rng = np.random.default_rng(5)
+    lens = torch.tensor([23, 1, 9, 16])
+    mel = torch.from_numpy((rng.standard_normal((4, 80, 23)) * 1.5 - 4.0).astype(np.float32)).to(dev)
+    set_precision('bf16')
+    try:
+        hg = HifiGanEngine(synth_weights['hifigan'], device=dev)
+        waves = []
+        for chain, chain7 in (('0', '0'), ('1', '0'), ('1', '1')):
+            monkeypatch.setenv('TTSAMD_BFO_CHAIN', chain)
+            monkeypatch.setenv('TTSAMD_BFO_CHAIN7', chain7)
+            waves.append(hg.forward(mel, lens.to(dev)).cpu())
+        monkeypatch.delenv('TTSAMD_BFO_CHAIN')
+        monkeypatch.delenv('TTSAMD_BFO_CHAIN7')
+        waves.append(hg.forward(mel, lens.to(dev)).cpu())
+    finally:
+        set_precision('f32')
+    assert float(waves[0].abs().max()) > 1e-3
+    for w in waves[1:]:
+        assert torch.equal(w, waves[0])
 
 
 def test_split_k_small_batch(dev, synth_weights, monkeypatch):

@@ -52,13 +52,14 @@ struct BfoChainParams {
     const void* x;         // [B][C/8][L][8] bf16, activated with in_slope: input of the first pair
     void* y;               // output of the LAST pair, same layout; must not alias x
     const void* sum_in;    // mode != 0: running ResBlock sum, RAW bf16 (may alias y)
-    const void* w1[3];     // packed bf16 [C/16][3][2][C][8] per pair
+    const void* w1[3];     // packed bf16 [C/16][k][2][C][8] per pair
     const void* w2[3];
     const float* b1[3];
     const float* b2[3];
     const int64_t* lens;
     int32_t len_mul, L, batch;
     int32_t dil[3];        // dilation of each pair's first conv
+    int32_t k;             // kernel size of the six convs: 3 (C = 32 / 64 / 128) or 7 (C = 32 / 64)
     int32_t mode;          // applied to the last pair's output, as BfoPairParams::mode
     float div;
     float in_slope;        // activation x is stored with AND the one between the pairs (0.1)
@@ -103,7 +104,7 @@ struct BfoConvParams {
 // kernel-level launchers (bfo_pair.hip, bfo_conv.hip)
 bool bfo_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L);
 int32_t bfo_launch_pair(int32_t channels, int32_t k, const BfoPairParams& p, hipStream_t s);
-// a whole k = 3 ResBlock in one launch (bfo_chain.hip); TTSAMD_BFO_CHAIN=0: three pair launches
+// a whole k = 3 (or, C <= 64, k = 7) ResBlock in one launch (bfo_chain.hip); TTSAMD_BFO_CHAIN=0: three pair launches
 bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch);
 int32_t bfo_launch_chain(int32_t channels, const BfoChainParams& p, hipStream_t s);
 int32_t bfo_launch_conv(const BfoConvParams& p, hipStream_t s);

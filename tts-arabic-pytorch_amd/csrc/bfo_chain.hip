@@ -18,9 +18,15 @@
 
 namespace ttsamd {
 
-template <int C, int NT_>
+// the k = 7 ResBlock of the C = 32 / 64 stages as one launch: by default only when the padded batch holds at most this many columns
+// (same-box A/B, bf16 one-stream step: batch 1 2.382 -> 2.349 ms, batch 8 4.674 -> 4.623, batch 32 11.66 -> 11.74 -- at k = 7 the
+// chain's halo is 72 of 256 / 512 columns and its LDS leaves one block per CU, so on a full chip the saved round trips do not pay
+// for the recomputed columns; what is left is the launch count, which shows where the launches are short).  profiles/r4/ab_chain7.txt
+constexpr int64_t kBfoChain7MaxColumns = 1536 * 1024;
+
+template <int C, int NT_, int K_>
 struct BfoChainGeo {
-    static constexpr int K = 3, NP = 3;
+    static constexpr int K = K_, NP = 3, H = (K_ - 1) / 2;
     static constexpr int NO = C / 8, NH = C / 16;
     static constexpr int WM = C / 32, WN = 4 / WM;
     static constexpr int NT = NT_;
@@ -28,20 +34,20 @@ struct BfoChainGeo {
     static constexpr int WS = NCOLS + (K - 1) * BFO_DMAX;   // LDS entries per octet row (as the pair kernel)
     static constexpr int NE = NO * WS;
     static constexpr int NXI = (NE + 255) / 256;
-    static constexpr int PH = C <= 64 ? 4 : 2;              // 16-channel groups the weight ring runs ahead (as the k = 3 pairs)
+    static constexpr int PH = K_ <= 3 ? (C <= 64 ? 4 : 2) : 1;   // 16-channel groups the weight ring runs ahead (as the pair kernels)
     static constexpr size_t LDS = (size_t)NE * 16;
 };
 
-template <int C, int NT_>
+template <int C, int NT_, int K_>
 __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(const BfoChainParams p) {
-    using G = BfoChainGeo<C, NT_>;
-    constexpr int K = 3, NO = G::NO, NH = G::NH, WN = G::WN, NT = G::NT, WS = G::WS, NXI = G::NXI;
+    using G = BfoChainGeo<C, NT_, K_>;
+    constexpr int K = K_, H = G::H, NO = G::NO, NH = G::NH, WN = G::WN, NT = G::NT, WS = G::WS, NXI = G::NXI;
     extern __shared__ __attribute__((aligned(16))) uint4 Xs[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 5, l31 = lane & 31;
     const int wm = wid / WN, wn = wid % WN;
-    const int HT = p.dil[0] + p.dil[1] + p.dil[2] + 3;      // columns lost on each side over the three pairs
+    const int HT = H * (p.dil[0] + p.dil[1] + p.dil[2] + 3);   // columns lost on each side over the three pairs: (K-1)/2 (d + 1) per pair
     const int TS = G::NCOLS - 2 * HT;
     int b = blockIdx.z;
     int q0 = blockIdx.x * TS;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(co
 #pragma unroll 1
     for (int m = 0; m < G::NP; ++m) {
         const int dil = p.dil[m];
-        // ---- phase A: T column c = position xw + dil + c
+        // ---- phase A: T column c = position xw + H dil + c
         {
             float bv[16];
 #pragma unroll
@@ -100,10 +106,10 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(co
         }
         bfo_mma<K, G::PH, NT>(acc, bfo_rsrc(p.w1[m], wbytes), wv, 2 * C * 16, sB, NH, 2 * WS, dil);
 
-        // residual = the pair's (activated) input at its output positions: output column n reads window column n + dil + 1
+        // residual = the pair's (activated) input at its output positions: output column n reads window column n + H (dil + 1)
         bfo_i2 rv[NT][4];
         {
-            const int rc0 = cw + dil + 1;
+            const int rc0 = cw + H * (dil + 1);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(co
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int col = cw + 32 * j;
-                const int pos = xw + dil + col;
+                const int pos = xw + H * dil + col;
                 const int live = (pos >= 0 && pos < len) ? -1 : 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(co
         }
         __syncthreads();
 
-        // ---- phase B: output column n = position xw + dil + 1 + n; accumulators start from b2 + x
+        // ---- phase B: output column n = position xw + H (dil + 1) + n; accumulators start from b2 + x
         {
             float bv[16];
 #pragma unroll
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(co
                 }
         }
         bfo_mma<K, G::PH, NT>(acc, bfo_rsrc(p.w2[m], wbytes), wv, 2 * C * 16, sB, NH, 2 * WS, 1);
-        xw += dil + 1;
+        xw += H * (dil + 1);
         if (m + 1 == G::NP) break;
 
         // ---- the pair's output, activated for the next pair (in_slope) and rounded as the un-fused launch rounds it for HBM,
@@ -201,48 +207,63 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(co
     }
 }
 
-template <int C, int NT>
+template <int C, int NT, int K>
 static int32_t bfo_launch_chain_nt(const BfoChainParams& p, hipStream_t stream) {
-    using G = BfoChainGeo<C, NT>;
+    using G = BfoChainGeo<C, NT, K>;
     static bool attr_set[16] = {};
     int dev_id = 0;
     TTS_CHECK_HIP(hipGetDevice(&dev_id));
     dev_id &= 15;
     if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_resblock_chain<C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_resblock_chain<C, NT, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
         attr_set[dev_id] = true;
     }
-    const int TS = G::NCOLS - 2 * (p.dil[0] + p.dil[1] + p.dil[2] + 3);
+    const int TS = G::NCOLS - 2 * G::H * (p.dil[0] + p.dil[1] + p.dil[2] + 3);
     dim3 grid((p.L + TS - 1) / TS, 1, p.batch);
     BfoChainParams q = p;
     q.compact = compact_order(p.lens, p.batch) ? 1 : 0;
-    hipLaunchKernelGGL((bfo_resblock_chain<C, NT>), grid, dim3(256), G::LDS, stream, q);
+    hipLaunchKernelGGL((bfo_resblock_chain<C, NT, K>), grid, dim3(256), G::LDS, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-// k = 3 ResBlock (three pairs) in one launch: C = 32 / 64 / 128, dilations within the LDS row's halo.  TTSAMD_BFO_CHAIN=0 keeps the
-// three pair launches (measured: batch 32 11.63 -> 11.32 ms per step, batch 8 4.38 -> 4.21, batch 1 2.09 -> 1.97).
+// A ResBlock (three pairs) in one launch: k = 3 at C = 32 / 64 / 128, k = 7 at C = 32 / 64 (there the pairs keep the matrix pipe 34-54 %
+// busy and sit at 0.4 of the HBM roof: the halo's extra MFMAs -- 72 of 256 / 512 columns -- are affordable, the two saved tensor round trips
+// are not free; at k = 11 and at C = 128 k = 7 the pairs run at the power-managed matrix roof and the halo would only cost).
+// TTSAMD_BFO_CHAIN=0 keeps the three pair launches, TTSAMD_BFO_CHAIN7=0 / 1 forces the k = 7 choice (k = 3 measured: batch 32 11.63 -> 11.32 ms per step,
+// batch 8 4.38 -> 4.21, batch 1 2.09 -> 1.97).
 bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch) {
     const char* ce = getenv("TTSAMD_BFO_CHAIN");               // read per call, like the other schedule switches: tests and A/B runs flip it
     const bool off = ce && ce[0] == '0';
-    (void)batch;
-    if (off || k != 3 || n_pairs != 3 || !(channels == 32 || channels == 64 || channels == 128)) return false;
+    if (off || n_pairs != 3) return false;
+    if (k == 7) {
+        const char* c7 = getenv("TTSAMD_BFO_CHAIN7");           // 0 / 1 force it; default: small batches only
+        const bool on7 = c7 ? c7[0] != '0' : (int64_t)batch * L <= kBfoChain7MaxColumns;
+        if (!on7 || !(channels == 32 || channels == 64)) return false;
+    } else if (k != 3 || !(channels == 32 || channels == 64 || channels == 128)) {
+        return false;
+    }
     for (int m = 0; m < 3; ++m)
         if (dil[m] < 1 || dil[m] > BFO_DMAX) return false;
     if ((int64_t)channels * L * 2 >= ((int64_t)1 << 31)) return false;
     const int ncols = channels == 32 ? 512 : 256;
-    return ncols - 2 * (dil[0] + dil[1] + dil[2] + 3) >= ncols / 2;
+    return ncols - (k - 1) * (dil[0] + dil[1] + dil[2] + 3) >= ncols / 2;
 }
 
 int32_t bfo_launch_chain(int32_t channels, const BfoChainParams& p, hipStream_t stream) {
-    TTS_REQUIRE(bfo_chain_supported(channels, 3, p.dil, 3, p.L, p.batch), "bf16 ResBlock chain: unsupported geometry (C=%d, L=%d)", channels, p.L);
+    TTS_REQUIRE(p.k == 3 || p.k == 7, "bf16 ResBlock chain: kernel size %d (3 or 7)", p.k);
+    TTS_REQUIRE(bfo_chain_supported(channels, p.k, p.dil, 3, p.L, p.batch), "bf16 ResBlock chain: unsupported geometry (C=%d, k=%d, L=%d)", channels,
+                p.k, p.L);
     TTS_REQUIRE(p.x != p.y, "bf16 ResBlock chain: x and y must differ (halo reads)");
     TTS_REQUIRE(p.mode == 0 || p.sum_in != nullptr, "bf16 ResBlock chain: mode %d needs sum_in", p.mode);
-    conv_log("bfo_chain", 3, channels, channels, p.L, p.batch, 1, p.mode, p.len_mul, p.lens != nullptr, 3);
-    if (channels == 128) return bfo_launch_chain_nt<128, 8>(p, stream);
-    if (channels == 64) return bfo_launch_chain_nt<64, 4>(p, stream);
-    return bfo_launch_chain_nt<32, 4>(p, stream);
+    conv_log("bfo_chain", p.k, channels, channels, p.L, p.batch, 1, p.mode, p.len_mul, p.lens != nullptr, 3);
+    if (p.k == 7) {
+        if (channels == 64) return bfo_launch_chain_nt<64, 4, 7>(p, stream);
+        return bfo_launch_chain_nt<32, 4, 7>(p, stream);
+    }
+    if (channels == 128) return bfo_launch_chain_nt<128, 8, 3>(p, stream);
+    if (channels == 64) return bfo_launch_chain_nt<64, 4, 3>(p, stream);
+    return bfo_launch_chain_nt<32, 4, 3>(p, stream);
 }
 
 }  // namespace ttsamd

@@ -466,7 +466,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                 if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_fork, 0));
                 const void* src = upso;
                 {
-                    // a k = 3 ResBlock whose three pairs fit the chained kernel goes out as ONE launch (bfo_chain.hip; bit-identical)
+                    // a ResBlock whose three pairs fit the chained kernel (k = 3; k = 7 at C <= 64) goes out as ONE launch (bfo_chain.hip; bit-identical)
                     const int li0 = (i * cfg.n_kernels + j) * cfg.n_dilations;
                     int32_t dl[3] = {0, 0, 0};
                     for (int m = 0; m < cfg.n_dilations && m < 3; ++m) dl[m] = cfg.resblock_dilations[j][m];
@@ -479,12 +479,12 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                             cc.w1[m] = W16 + w1.wo_off; cc.w2[m] = W16 + w2.wo_off; cc.b1[m] = h->dev + w1.b_off; cc.b2[m] = h->dev + w2.b_off;
                             cc.dil[m] = dl[m];
                         }
-                        cc.lens = lens; cc.len_mul = mul; cc.L = L; cc.batch = B;
+                        cc.lens = lens; cc.len_mul = mul; cc.L = L; cc.batch = B; cc.k = h->c1[li0].k;
                         cc.mode = cfg.n_kernels == 1 ? 0 : (j == 0 ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2));
                         cc.div = (float)cfg.n_kernels; cc.in_slope = 0.1f; cc.mid_slope = 0.1f;
                         cc.out_slope = j + 1 == cfg.n_kernels ? next_slope : 1.f;
                         if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
-                        const double fl = 3 * 2.0 * (2.0 * h->c1[li0].cin * h->c1[li0].cin * 3) * mul;
+                        const double fl = 3 * 2.0 * (2.0 * h->c1[li0].cin * h->c1[li0].cin * h->c1[li0].k) * mul;
                         if (in_section) prof_add(fl); else prof_begin(st, fl);
                         rc = bfo_launch_chain(h->c1[li0].cin, cc, st);
                         if (!in_section) prof_end(st);

@@ -79,8 +79,8 @@ def resblock_pair(x, w1p, b1, w2p, b2, k, dilation, lens=None, len_mul=1, sum_in
 
 
 def resblock_chain(x, w1p, b1, w2p, b2, dilations, lens=None, len_mul=1, sum_in=None, mode=0, div=1.0, in_slope=0.1, mid_slope=0.1,
-                   out_slope=0.1, y=None):
-    """A whole k = 3 ResBlock (three pairs) in one launch; w1p / b1 / w2p / b2: lists of three device tensors."""
+                   out_slope=0.1, y=None, k=3):
+    """A whole ResBlock (three pairs) in one launch, k = 3 or (C <= 64) k = 7; w1p / b1 / w2p / b2: lists of three device tensors."""
     import ctypes
     B, no, Ln, _ = x.shape
     if y is None:
@@ -89,7 +89,7 @@ def resblock_chain(x, w1p, b1, w2p, b2, dilations, lens=None, len_mul=1, sum_in=
     dl = (ctypes.c_int32 * 3)(*[int(d) for d in dilations])
     L.check(L.load().ttsamd_bfo_resblock_chain(_ptr(x), arr(w1p), arr(b1), arr(w2p), arr(b2), dl, _ptr(sum_in), _ptr(lens), len_mul,
                                                B, no * 8, Ln, mode, float(div), float(in_slope), float(mid_slope), float(out_slope),
-                                               _ptr(y), _stream()), 'bfo_resblock_chain')
+                                               _ptr(y), _stream(), int(k)), 'bfo_resblock_chain')
     return y
 
 
