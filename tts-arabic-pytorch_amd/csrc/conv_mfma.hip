@@ -596,9 +596,22 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_f32(const ConvP
         // +0.2 % because three concurrent launches share the L2; TTSAMD_XCD_W=0 disables)
         // g = gcd(n_co_tiles, 8) classes of co-tiles; XCD x serves class x % g = the n_co_tiles / g co-tiles {x % g + g*k}
         const unsigned lin = bx_ + gridDim.x * (by_ + gridDim.y * bz_), xcd = lin & 7u, slot = lin >> 3;
-        const unsigned nct = gridDim.y, g = (unsigned)p.xcd_w, per = nct / g;
-        const unsigned idx2 = slot * (8u / g) + xcd / g, rest = idx2 / per;
-        by_ = xcd % g + g * (idx2 % per); bx_ = rest % gridDim.x; bz_ = rest / gridDim.x;
+        const unsigned nct = gridDim.y, g = (unsigned)p.xcd_w & 0xffu, per = nct / g;
+        unsigned rest;
+        if (p.xcd_w & 0x100) {
+            // input locality on top: an XCD owns WHOLE time tiles of its class -- the per co-tiles of one time tile are consecutive
+            // slots of one XCD, run side by side on its CUs and read the tile's input window through one L2 (with per = 1 co-tile
+            // per class every window crosses the fabric nct times: C = 256 on 64-row tiles 4x, C = 128 k = 11 2x -- measured
+            // 2.6-4.1x and 1.36-1.56x the algorithmic bytes, profiles/r4/traffic.json).  g is the launcher's choice: the fewest
+            // classes whose weight slice still sits in the 4 MB L2 next to the streaming windows.
+            rest = (slot / per) * (8u / g) + xcd / g;
+            by_ = xcd % g + g * (slot % per);
+        } else {
+            const unsigned idx2 = slot * (8u / g) + xcd / g;
+            rest = idx2 / per;
+            by_ = xcd % g + g * (idx2 % per);
+        }
+        bx_ = rest % gridDim.x; bz_ = rest / gridDim.x;
     }
     int b = p.tile_major ? (int)((bx_ + bz_) % (unsigned)p.batch) : (int)bz_;
     int q0 = (p.tile_major ? bz_ : bx_) * NT_BLK;
@@ -676,6 +689,12 @@ bool tile_major_order(const ConvParams& p, unsigned n_tiles) {
     return force != 0 && p.lens_out != nullptr && p.batch > 1 && n_tiles <= 65535;
 }
 
+// Weights one XCD's L2 is asked to keep when co-tiles share an XCD for the input window's sake.  Stand-alone, FETCH_SIZE per launch
+// (profiles/r4/xcd_probe.txt): C = 256 k = 3 / 7 / 11 519 -> 330 / 727 -> 342 / 755 -> 492 MB, C = 128 k = 11 1452 -> 1020 MB -- at the same
+// time per launch to 0.3 % (so the fabric bytes were never what these launches wait for), step 76.5 ms either way (tools/ab_xcd.sh).
+// Kept on: 20 GB less fabric traffic per step for nothing.
+constexpr int kXcdWeightKB = 3000;
+
 template <int K, int MT, int NTL, int WM, int WN>
 static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int CO_BLK = WM * MT * 32, NT_BLK = WN * NTL * 32;
@@ -693,6 +712,16 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         const unsigned nct = grid.y;
         const unsigned g = (nct % 8 == 0) ? 8 : (nct % 4 == 0 ? 4 : (nct % 2 == 0 ? 2 : 1));
         q.xcd_w = (xw && !q.tile_major && p.n_phase == 1 && g > 1 && ((int64_t)grid.x * grid.y * grid.z) % 8 == 0) ? (int)g : 0;
+        // fewer classes (g2 < g) = several co-tiles of a time tile on one XCD: as few as keep a class's weights under
+        // TTSAMD_XCD_WMAX_KB (0 = one co-tile per class as before)
+        const char* we = getenv("TTSAMD_XCD_WMAX_KB");
+        const int64_t wmax = (we ? (int64_t)atoi(we) : (int64_t)kXcdWeightKB) * 1024;
+        if (q.xcd_w && wmax > 0) {
+            const int64_t wbytes = (int64_t)p.CoutP * p.Cin * K * 4;
+            unsigned g2 = g;
+            while (g2 > 1 && wbytes / (g2 / 2) <= wmax) g2 /= 2;
+            if (g2 < g && ((int64_t)grid.x * grid.z * g2) % 8 == 0) q.xcd_w = (int)g2 | 0x100 | ((int)g << 16);   // (bits 16..: the plain choice, for a split-K launch)
+        }
     }
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
     const int n_chunks = p.Cin / G::KC;
@@ -703,7 +732,9 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         int64_t ks = std::min<int64_t>((sk_target + nblk - 1) / nblk, n_chunks / 4);
         ks = std::min<int64_t>(ks, p.splitk_floats / per);
         if (ks >= 2) q.ksplit = (int)ks;
+        if (ks >= 2 && (q.xcd_w & 0x100)) q.xcd_w >>= 16;
     }
+    if (q.xcd_w & 0x100) q.xcd_w &= 0x1ff;
     grid.y *= q.ksplit;
     // epilogue kind (see the kernel): the float4 row epilogue needs 16-byte aligned rows of y (and of the residual)
     const bool vec_ok = q.ksplit == 1 && p.y_ts == 1 && p.n_phase == 1 && (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 &&
