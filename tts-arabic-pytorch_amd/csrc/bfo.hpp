@@ -210,9 +210,17 @@ __device__ __forceinline__ void bfo_mma(bfo_f16 (&acc)[NT], const bfo_i4 wrs, co
                 // scheduler otherwise sinks each read to right in front of its MFMA (lgkmcnt(0) per pair of MFMAs).
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
+#if !defined(BFO_EXP) || (BFO_EXP & 1) == 0      /* timing builds of tools/bfo_pair_bench only (results are wrong): 1 = no MFMAs, */
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfo_h8, A[ph][t]),
                                                                      __builtin_bit_cast(bfo_h8, Bf[j]), acc[j], 0, 0, 0);
+#else
+                    asm volatile("" : "+v"(Bf[j].x), "+v"(Bf[j].y), "+v"(Bf[j].z), "+v"(Bf[j].w));
+#endif
+#if !defined(BFO_EXP) || (BFO_EXP & 6) == 0      /* 2 = every second B refill dropped, 4 = no B refills at all */
                     Bf[j] = nx[j * 32];
+#elif (BFO_EXP & 2)
+                    if (j & 1) Bf[j] = nx[j * 32];
+#endif
                     if (j == NT - 1) A[ph][t] = bfo_ld16(wrs, wv, ((h0 + hn) * K + t) * wstep, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
