@@ -763,3 +763,24 @@ def test_fastpitch_deep_splitk_tiles(dev, fastpitch_engine, monkeypatch):
     assert torch.equal(dl0, dl1) and bool(torch.isfinite(mel1).all())
     assert maxabs(mel0, mel1) < 2e-5
     assert not torch.equal(mel0, mel1)          # the other schedule did run
+
+
+def test_attention_schedules_bit_identical(dev, fastpitch_engine, monkeypatch):
+    """FastPitch's self-attention (transformer.py:131-141) merges one tile-local softmax per 64-key tile in tile order; which block
+    does it is a schedule: 64 or 16 queries per block walking the tiles (TTSAMD_ATT_RA), or one block per (16 queries, key tile)
+    plus a merge launch (the batch-1 default).  Same mel bits on a ragged batch whose decoder sequences span 1 ... 8 key tiles."""
+    from ttsamd import synth
+    ids = synth.synth_ids(3, 64)
+    ids[1, 9:] = 0
+    ids[2, 30:] = 0
+    dur = synth.synth_durations(3, 64) * (ids != 0)
+    ids_d, dur_d = torch.from_numpy(ids).to(dev), torch.from_numpy(dur).to(dev)
+    mels = []
+    for ra, split in (('4', '0'), ('1', '0'), ('2', '0'), ('1', '1')):
+        monkeypatch.setenv('TTSAMD_ATT_RA', ra)
+        monkeypatch.setenv('TTSAMD_ATT_SPLIT', split)
+        mel, lens, *_ = fastpitch_engine.infer(ids_d, dur_tgt=dur_d)
+        mels.append(mel.cpu())
+    assert int(lens.max()) > 128 and int(lens.min()) < 64 and bool(torch.isfinite(mels[0]).all())
+    for m in mels[1:]:
+        assert torch.equal(m, mels[0])

@@ -3,8 +3,8 @@
 # time per launch and FETCH_SIZE per launch (own PMC pass)
 O=gpurun_out/xcd_probe; mkdir -p $O
 export PROD=1 RES_SEP=1 RAGGED=auto CUSTOM="32,256,3,1,3584;32,256,7,3,3584;32,256,11,5,3584;32,128,11,5,28672;32,128,7,3,28672"
-for w in 0 900 2000 3000; do echo "== TTSAMD_XCD_WMAX_KB=$w"; TTSAMD_XCD_WMAX_KB=$w tools/bin/conv_bench; done
-for w in 0 3000; do
+for w in ${TIMEW:-0 900 2000 3000}; do echo "== TTSAMD_XCD_WMAX_KB=$w"; TTSAMD_XCD_WMAX_KB=$w tools/bin/conv_bench; done
+for w in ${PMCW:-0 3000}; do
   export TTSAMD_XCD_WMAX_KB=$w
   ITERS=2 WARM_MS=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_$w -- tools/bin/conv_bench > /dev/null 2>&1
   python3 - $O/fetch_$w $w <<'PY'

@@ -269,14 +269,96 @@ int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos
 }
 
 // ------------------------------------------------------------------------------------
-// Single-head attention, flash-style (online softmax), fp32 VALU: 0.1 % of the path's FLOPs.
+// Single-head attention, fp32 VALU: 0.1 % of the path's FLOPs.
 // Block = QT = 16*RA queries of one utterance; key/value tiles of 64 streamed through LDS, the next
 // tile's 32 values per thread are already in flight (registers) while the current one is consumed.
 // Thread (ti = tid/16, tj = tid%16) owns score rows i0=RA*ti.. and score cols / out dims 4*tj..
-// RA = 4 (64 queries per block) when that gives every CU a block, RA = 1 (16 queries) otherwise:
-// the arithmetic per (query, key) is the same in both, so the result does not depend on RA.
+// Every 64-key tile yields a tile-local softmax (m_t, l_t, o_t) that is merged into the running (m, l, o)
+// in tile order (att_merge): the result depends neither on RA (64 queries per block when that gives every
+// CU a block, 16 otherwise) nor on WHO merges -- at small batches (batch 1: 29 blocks of 16 queries, each
+// walking 8 key tiles in sequence: 34 us for 0.06 GFLOP) every (query block, key tile) is its own block
+// (attention_tile_kernel) and attention_merge_kernel replays the same merges in the same order: the same
+// bits as the one-kernel path (tests/test_gpu_parity.py), 34 -> 11 us per layer at batch 1.
 // ------------------------------------------------------------------------------------
 constexpr int ATT_D = 64;
+constexpr int ATT_PS = 68;          // floats per (query, tile) partial: m, l, 2 pad, o[64]
+
+// running (m, l, o[4]) <- merged with a tile's (mt, lt, ot[4]); explicit roundings: both kernels must agree bit for bit
+__device__ __forceinline__ void att_merge(float& m, float& l, float (&o)[4], const float mt, const float lt, const float (&ot)[4]) {
+    const float m_new = fmaxf(m, mt);
+    const float ea = expf(m - m_new), eb = expf(mt - m_new);
+    l = __fmaf_rn(l, ea, __fmul_rn(lt, eb));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = __fmaf_rn(o[c], ea, __fmul_rn(ot[c], eb));
+    m = m_new;
+}
+
+// one 64-key tile (already in Ks / Vs) against the block's queries: tile-local max, sum and weighted values
+template <int RA, int QT>
+__device__ __forceinline__ void att_tile(const float (&Qs)[ATT_D][QT + 4], const float (&Ks)[ATT_D][64 + 4], const float (&Vs)[ATT_D][64 + 1],
+                                         float (&Ps)[QT][64 + 4], const int i0, const int j0, const int kt, const int len, const float scale,
+                                         float (&mt)[RA], float (&lt)[RA], float (&ot)[RA][4]) {
+    float sc[RA][4];
+#pragma unroll
+    for (int a = 0; a < RA; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sc[a][c] = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < ATT_D; ++d) {
+        float qa[RA];
+        if constexpr (RA == 4) {
+            const float4 qv = *reinterpret_cast<const float4*>(&Qs[d][i0]);
+            qa[0] = qv.x; qa[1] = qv.y; qa[2] = qv.z; qa[3] = qv.w;
+        } else {
+#pragma unroll
+            for (int a = 0; a < RA; ++a) qa[a] = Qs[d][i0 + a];
+        }
+        const float4 kv = *reinterpret_cast<const float4*>(&Ks[d][j0]);
+        const float ka[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sc[a][c] = fmaf(qa[a], ka[c], sc[a][c]);
+    }
+#pragma unroll
+    for (int a = 0; a < RA; ++a) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            sc[a][c] = (kt + j0 + c < len) ? sc[a][c] * scale : -INFINITY;
+            mx = fmaxf(mx, sc[a][c]);
+        }
+        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float rs = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float pv = expf(sc[a][c] - mx);
+            sc[a][c] = pv;
+            rs += pv;
+        }
+        for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off);
+        mt[a] = mx;
+        lt[a] = rs;
+        *reinterpret_cast<float4*>(&Ps[i0 + a][j0]) = make_float4(sc[a][0], sc[a][1], sc[a][2], sc[a][3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ot[a][c] = 0.f;
+    }
+    __syncthreads();
+    // O_t[i0+a][d0+c] = sum_j P[i0+a][j] * V[d0+c][j], d0 = j0
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+        float pa[RA], va[4];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) pa[a] = Ps[i0 + a][j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) va[c] = Vs[j0 + c][j];
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ot[a][c] = fmaf(pa[a], va[c], ot[a][c]);
+    }
+}
+
 template <int RA>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
                                                         const int64_t* __restrict__ lens, int S, float scale,
@@ -331,67 +413,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
         __syncthreads();
         if (kt + 64 < len) fetch(kt + 64);
-        float sc[RA][4];
+        float mt[RA], lt[RA], ot[RA][4];
+        att_tile<RA, QT>(Qs, Ks, Vs, Ps, i0, j0, kt, len, scale, mt, lt, ot);
 #pragma unroll
-        for (int a = 0; a < RA; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) sc[a][c] = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < ATT_D; ++d) {
-            float qa[RA];
-            if constexpr (RA == 4) {
-                const float4 qv = *reinterpret_cast<const float4*>(&Qs[d][i0]);
-                qa[0] = qv.x; qa[1] = qv.y; qa[2] = qv.z; qa[3] = qv.w;
-            } else {
-#pragma unroll
-                for (int a = 0; a < RA; ++a) qa[a] = Qs[d][i0 + a];
-            }
-            const float4 kv = *reinterpret_cast<const float4*>(&Ks[d][j0]);
-            const float ka[4] = {kv.x, kv.y, kv.z, kv.w};
-#pragma unroll
-            for (int a = 0; a < RA; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) sc[a][c] = fmaf(qa[a], ka[c], sc[a][c]);
-        }
-#pragma unroll
-        for (int a = 0; a < RA; ++a) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                sc[a][c] = (kt + j0 + c < len) ? sc[a][c] * scale : -INFINITY;
-                mx = fmaxf(mx, sc[a][c]);
-            }
-            for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-            const float m_new = fmaxf(m_run[a], mx);
-            const float alpha = expf(m_run[a] - m_new);
-            float rs = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float pv = expf(sc[a][c] - m_new);
-                sc[a][c] = pv;
-                rs += pv;
-            }
-            for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off);
-            l_run[a] = l_run[a] * alpha + rs;
-            m_run[a] = m_new;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[a][c] *= alpha;
-            *reinterpret_cast<float4*>(&Ps[i0 + a][j0]) = make_float4(sc[a][0], sc[a][1], sc[a][2], sc[a][3]);
-        }
-        __syncthreads();
-        // O[i0+a][d0+c] += sum_j P[i0+a][j] * V[d0+c][j], d0 = j0
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            float pa[RA], va[4];
-#pragma unroll
-            for (int a = 0; a < RA; ++a) pa[a] = Ps[i0 + a][j];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) va[c] = Vs[j0 + c][j];
-#pragma unroll
-            for (int a = 0; a < RA; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[a][c] = fmaf(pa[a], va[c], o[a][c]);
-        }
+        for (int a = 0; a < RA; ++a) att_merge(m_run[a], l_run[a], o[a], mt[a], lt[a], ot[a]);
     }
     float* ob = out + (int64_t)b * ATT_D * S;
 #pragma unroll
@@ -404,8 +429,77 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// Small batches: block (x, y, z) = 16 queries of utterance y against key tile z; its (m_t, l_t, o_t) go to
+// part[((y * gridDim.x + x) * gridDim.z + z) * 16 + query][ATT_PS]
+__global__ __launch_bounds__(256) void attention_tile_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lens, int S,
+                                                             float scale, float* __restrict__ part) {
+    constexpr int QT = 16;
+    __shared__ float Qs[ATT_D][QT + 4];
+    __shared__ float Ks[ATT_D][64 + 4];
+    __shared__ float Vs[ATT_D][64 + 1];
+    __shared__ float Ps[QT][64 + 4];
+    const int b = blockIdx.y, kt = blockIdx.z * 64;
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int j0 = tj * 4;
+    const int qbase = blockIdx.x * QT;
+    int len = S;
+    if (lens) len = min(S, (int)lens[b]);
+    if (kt >= len) return;
+    const float* qb = qkv + (int64_t)b * 3 * ATT_D * S;
+    const float* kb = qb + (int64_t)ATT_D * S;
+    const float* vb = kb + (int64_t)ATT_D * S;
+    const int lj = tid & 63, ld = tid >> 6;
+    {
+        const bool ok = kt + lj < len;
+        const int64_t off = (int64_t)ld * S + kt + lj;
+        float kreg[16], vreg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            kreg[r] = ok ? kb[off + (int64_t)(4 * r) * S] : 0.f;
+            vreg[r] = ok ? vb[off + (int64_t)(4 * r) * S] : 0.f;
+        }
+        for (int e = tid; e < ATT_D * QT; e += 256) {
+            const int d = e / QT, i = e % QT;
+            Qs[d][i] = (qbase + i < S) ? qb[(int64_t)d * S + qbase + i] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            Ks[4 * r + ld][lj] = kreg[r];
+            Vs[4 * r + ld][lj] = vreg[r];
+        }
+    }
+    __syncthreads();
+    float mt[1], lt[1], ot[1][4];
+    att_tile<1, QT>(Qs, Ks, Vs, Ps, ti, j0, kt, len, scale, mt, lt, ot);
+    float* pp = part + ((((int64_t)b * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * 16 + ti) * ATT_PS;
+    if (tj == 0) { pp[0] = mt[0]; pp[1] = lt[0]; }
+    *reinterpret_cast<float4*>(pp + 4 + j0) = make_float4(ot[0][0], ot[0][1], ot[0][2], ot[0][3]);
+}
+
+// ... and the merges of attention_kernel's tile loop, in its order, for 16 queries per block
+__global__ __launch_bounds__(256) void attention_merge_kernel(const float* __restrict__ part, const int64_t* __restrict__ lens, int S,
+                                                              int n_tiles_max, float* __restrict__ out) {
+    const int b = blockIdx.y, tid = threadIdx.x, ti = tid >> 4, j0 = (tid & 15) * 4;
+    int len = S;
+    if (lens) len = min(S, (int)lens[b]);
+    float m = -INFINITY, l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* pp = part + ((((int64_t)b * gridDim.x + blockIdx.x) * n_tiles_max) * 16 + ti) * ATT_PS;
+    for (int kt = 0; kt < len; kt += 64, pp += 16 * ATT_PS) {
+        const float4 ov = *reinterpret_cast<const float4*>(pp + 4 + j0);
+        const float ot[4] = {ov.x, ov.y, ov.z, ov.w};
+        att_merge(m, l, o, pp[0], pp[1], ot);
+    }
+    const int i = blockIdx.x * 16 + ti;
+    if (i >= S) return;
+    const float inv = 1.0f / l;
+    float* ob = out + (int64_t)b * ATT_D * S;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ob[(int64_t)(j0 + c) * S + i] = o[c] * inv;
+}
+
 int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S, float scale,
-                         float* out, hipStream_t s) {
+                         float* out, hipStream_t s, float* ws, int64_t ws_floats) {
     TTS_REQUIRE(D == ATT_D, "attention: d_head=%d, only %d is built", D, ATT_D);
     if (S <= 0 || B <= 0) return 0;
     if (default_precision() == 1) {                              // config 3: bf16 MFMA attention (TTSAMD_BF16_ATTN=0: the fp32 kernel)
@@ -416,7 +510,17 @@ int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32
     // (batch 1 / 8: 4.60 / 21.94 ms against 4.80 / 22.14); TTSAMD_ATT_RA=1/2/4 forces the tile
     const char* rae = getenv("TTSAMD_ATT_RA");
     const int ra = rae ? atoi(rae) : ((int64_t)((S + 63) / 64) * B >= 256 ? 4 : 1);
-    if (ra == 4) {
+    // fewer than half a block per CU and several key tiles: one block per (16 queries, key tile) + the merge launch (same bits);
+    // TTSAMD_ATT_SPLIT=0/1 forces either
+    const int qb = (S + 15) / 16, nt = (S + 63) / 64;
+    const char* spe = getenv("TTSAMD_ATT_SPLIT");
+    const bool fits = ws != nullptr && (int64_t)B * qb * nt * 16 * ATT_PS <= ws_floats;
+    const bool split = fits && nt >= 2 && (spe ? spe[0] == '1' : (ra == 1 && (int64_t)qb * B < 128));
+    if (split) {
+        hipLaunchKernelGGL(attention_tile_kernel, dim3(qb, B, nt), dim3(256), 0, s, qkv, lens, S, scale, ws);
+        TTS_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(attention_merge_kernel, dim3(qb, B), dim3(256), 0, s, (const float*)ws, lens, S, nt, out);
+    } else if (ra == 4) {
         dim3 grid((S + 63) / 64, B);
         hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, qkv, lens, S, scale, out);
     } else if (ra == 2) {

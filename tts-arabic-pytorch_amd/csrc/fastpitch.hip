@@ -315,7 +315,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
     }
     for (const FftLayer& l : layers) {
         TTS_TRY(run_conv(h, l.qkv, x, w.q, nullptr, B, S, nullptr, 0, s));
-        TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s));
+        TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s, t_splitk_ws, t_splitk_ws ? kSplitKFloatsFp : 0));
         TTS_TRY(run_conv(h, l.o_net, w.a, w.y, x, B, S, nullptr, 0, s));
         TTS_TRY(launch_layernorm_cf(w.y, w.y, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
         TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s));

@@ -31,8 +31,9 @@ int32_t launch_embed(const int64_t* ids, const float* word_emb, const float* pos
 
 // 1-head self attention over channel-first q,k,v = rows [0,D),[D,2D),[2D,3D) of qkv [B][3D][S]
 // (transformer.py:131-141): out[b][d][i] = sum_j softmax_j(q_i.k_j * scale | j < lens[b]) v_j[d]
+// ws / ws_floats: scratch for the small-batch schedule (one block per key tile + a merge launch; same bits), or nullptr
 int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32_t D, int32_t S,
-                         float scale, float* out, hipStream_t s);
+                         float scale, float* out, hipStream_t s, float* ws = nullptr, int64_t ws_floats = 0);
 
 // the same on the bf16 matrix cores (attention_bf16.hip; config 3): launch_attention routes here under ttsamd_set_precision(1)
 // out_octet != nullptr: the result leaves as an octet bf16 tensor [B][D/8][S][8] (bfo.hpp) instead of fp32 channel-first
