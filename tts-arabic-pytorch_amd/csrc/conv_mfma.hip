@@ -711,16 +711,19 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         static const bool xw = [] { const char* e = getenv("TTSAMD_XCD_W"); return !(e && e[0] == '0'); }();
         const unsigned nct = grid.y;
         const unsigned g = (nct % 8 == 0) ? 8 : (nct % 4 == 0 ? 4 : (nct % 2 == 0 ? 2 : 1));
-        q.xcd_w = (xw && !q.tile_major && p.n_phase == 1 && g > 1 && ((int64_t)grid.x * grid.y * grid.z) % 8 == 0) ? (int)g : 0;
-        // fewer classes (g2 < g) = several co-tiles of a time tile on one XCD: as few as keep a class's weights under
-        // TTSAMD_XCD_WMAX_KB (0 = one co-tile per class as before)
+        const bool can = xw && !q.tile_major && p.n_phase == 1 && ((int64_t)grid.x * grid.y * grid.z) % 8 == 0;
+        q.xcd_w = (can && g > 1) ? (int)g : 0;
+        // an XCD owns whole time tiles: the co-tiles of its class are consecutive slots and share the input window through its L2.  As few
+        // classes (g2 <= g) as keep a class's weights under TTSAMD_XCD_WMAX_KB (0 = the plain map above); with more co-tiles than classes
+        // (FastPitch's 384 -> 1536 conv: 12 co-tiles in 4 classes; 1536 -> 384: 3 in 1) the same g already saves the re-reads
         const char* we = getenv("TTSAMD_XCD_WMAX_KB");
         const int64_t wmax = (we ? (int64_t)atoi(we) : (int64_t)kXcdWeightKB) * 1024;
-        if (q.xcd_w && wmax > 0) {
+        if (can && wmax > 0 && nct > 1) {
             const int64_t wbytes = (int64_t)p.CoutP * p.Cin * K * 4;
             unsigned g2 = g;
             while (g2 > 1 && wbytes / (g2 / 2) <= wmax) g2 /= 2;
-            if (g2 < g && ((int64_t)grid.x * grid.z * g2) % 8 == 0) q.xcd_w = (int)g2 | 0x100 | ((int)g << 16);   // (bits 16..: the plain choice, for a split-K launch)
+            if (nct / g2 > 1 && ((int64_t)grid.x * grid.z * g2) % 8 == 0)
+                q.xcd_w = (int)g2 | 0x100 | (q.xcd_w << 16);   // (bits 16..: the plain choice, for a split-K launch)
         }
     }
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
