@@ -27,8 +27,8 @@ def main():
     raw = open('/tmp/taco_dump.bin', 'rb').read()
     x = np.frombuffer(raw[32:], dtype=np.uint32)
     st = x[26624:26624 + 8192].reshape(256, 32)[:, 8:19].astype(np.int64)
-    names = ['stop flags in', 'S1 late (poll pre, gates, store att_h)', 'poll att_h', 'query + energies + store', 'S5 early', 'S4 (poll epart, softmax, ctx)',
-             'S5 late (poll ctx, gates, store dec_h)', 'S6 (poll dec_h, proj, store h0)', 'S1 early (next step)', 'S7 (poll h0, prenet 2)']
+    names = ['stop flags in', 'S1 late (poll pre, gates, store att_h)', 'poll att_h', 'query + energies + store', 'S2 tail (att_h super-steps of both cells)', 'S4 (poll epart, softmax, ctx)',
+             'S5 late (poll ctx, gates, store dec_h, context tails)', 'S6 (poll dec_h, proj, store h0)', 'S6 tail (dec_h super-steps, next step)', 'S7 (poll h0, prenet 2)']
     d = np.diff(st, axis=1) * 0.01
     print('step length (block 0): %.2f us' % ((st[0, 10] - st[0, 0]) * 0.01))
     for i, n in enumerate(names):

@@ -966,19 +966,28 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 #define TACO_DEC_XOFF(i_) ({ const int k_ = 16 * (i_) + 4 * kq, kc_ = k_ - 1024, cg_ = kc_ / G::MC;                             \
         k_ < 1024 ? TR_ATT + (k_ >> 2) * 32 + bl * 4 : k_ < 1024 + M_ ? TR_CTX + (bl * 32 + cg_) * 32 + (kc_ - cg_ * G::MC)    \
                                                       : TR_DEC + ((k_ - 1024 - M_) >> 2) * 32 + bl * 4; })
-    // early half of the attention cell for the step that reads region (rq, pq) as its previous state: the [ctx | att_h] super-steps
-    // (n >= 4: super-steps 0..15 are the prenet columns).  First attempt through L2, any sentinel sends the lane to the coherent path.
-    constexpr int NEA = NSWA - 4;
-#define TACO_ATT_EARLY(rq, pq)                                                                                              \
+    // Round 4: the operand tiles a lane polls for one phase are exactly the ones the NEXT phases' "early halves" of the two cells need (same
+    // offsets: att_h of S2 = the decoder cell's and the next attention cell's att_h super-steps, the context of S5 late = the next attention
+    // cell's and the projection's context super-steps, dec_h of S6 = the next decoder cell's dec_h super-steps).  Those super-steps now run from
+    // the registers right behind the store of the phase that polled them ("tails") instead of re-loading the tiles through L2 two phases later
+    // (S5 early + S1 early: 7.9 us of a 32 us step, most of it the re-load round trips).  Carried across phases: accA (next attention cell:
+    // att_h part from the S2 tail, + context part from the S5-late tail, + prenet part in S1 late), accD (decoder cell: dec_h part from the
+    // previous step's S6 tail, + att_h part from the S2 tail, + context part in S5 late), pj (projection's context part from the S5-late tail).
+    // Before the first step of a launch the same parts are computed from region 0 with loads, in the same order (a later segment reproduces the
+    // one-launch bits).  First attempt through L2, any sentinel sends the lane to the coherent path.
+    constexpr int NEA = NSWA - 4, NCA = M_ / 64;      // early super-steps of the attention cell per wave: n = 0 .. NCA - 1 context, NCA .. NEA - 1 att_h
+    constexpr int NCD = M_ / 64;                      // context super-steps of the decoder cell (n = 16 .. 16 + NCD - 1); n >= 16 + NCD: dec_h
+#define TACO_ATT_LOAD_PART(rq, pq, N0, N1, INIT)                                                                            \
     {                                                                                                                       \
+        constexpr int n0_ = (N0), cnt_ = (N1) - (N0);                                                                       \
         int vp = 0;                                                                                                         \
         asm volatile("" : "+v"(vp));                                                                                        \
         const int wz = wid + vp;                                                                                            \
-        taco_f4 xs[NEA];                                                                                                    \
+        taco_f4 xs[cnt_];                                                                                                   \
         for (int spin = 0;; ++spin) {                                                                                       \
             bool okv = true;                                                                                                \
-            _Pragma("unroll") for (int n = 0; n < NEA; ++n) {                                                               \
-                const int off_ = TACO_ATT_XOFF(wz + 4 * (n + 4));                                                           \
+            _Pragma("unroll") for (int n = 0; n < cnt_; ++n) {                                                              \
+                const int off_ = TACO_ATT_XOFF(wz + 4 * (n0_ + n + 4));                                                     \
                 xs[n] = spin == 0 ? *reinterpret_cast<const taco_f4*>((pq) + off_) : TACO_LD4(rq, off_);                    \
                 okv = okv && TACO_OK4(xs[n]);                                                                               \
             }                                                                                                               \
@@ -986,17 +995,49 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             if (spin > POLL_LIM) { bad = true; break; }                                                                     \
             TACO_BACKOFF                                                                                                    \
         }                                                                                                                   \
-        accA0 = taco_f4{0.f, 0.f, 0.f, 0.f};                                                                                \
-        accA1 = accA0;                                                                                                      \
-        _Pragma("unroll") for (int n = 0; n < NEA; ++n) {                                                                   \
-            const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * (n + 4)) * 64 + lane]);                     \
+        if (INIT) {                                                                                                         \
+            accA0 = taco_f4{0.f, 0.f, 0.f, 0.f};                                                                            \
+            accA1 = accA0;                                                                                                  \
+        }                                                                                                                   \
+        _Pragma("unroll") for (int n = 0; n < cnt_; ++n) {                                                                  \
+            const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * (n0_ + n + 4)) * 64 + lane]);               \
             TACO_MFMA4(accA0, accA1, wa, xs[n])                                                                             \
         }                                                                                                                   \
     }
-
     taco_i4 rs0;
     TACO_RSRC(rs0, p.xch)
-    TACO_ATT_EARLY(rs0, p.xch)                                       // step 0: zero state
+    TACO_ATT_LOAD_PART(rs0, p.xch, NCA, NEA, true)                    // region 0 (zero state, or the previous segment's last region): att_h part ...
+    TACO_ATT_LOAD_PART(rs0, p.xch, 0, NCA, false)                     // ... then the context part, as the tails below do it
+    {                                                                 // ... and the decoder cell's dec_h part
+        int vp = 0;
+        asm volatile("" : "+v"(vp));
+        const int wz = wid + vp;
+        taco_f4 xs[16];
+        for (int spin = 0;; ++spin) {
+            bool okv = true;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int off_ = TR_DEC + (4 * (wz + 4 * n) + kq) * 32 + bl * 4;
+                xs[n] = spin == 0 ? *reinterpret_cast<const taco_f4*>(p.xch + off_) : TACO_LD4(rs0, off_);
+                okv = okv && TACO_OK4(xs[n]);
+            }
+            if (okv) break;
+            if (spin > POLL_LIM) { bad = true; break; }
+            TACO_BACKOFF
+        }
+        accD0 = taco_f4{0.f, 0.f, 0.f, 0.f};
+        accD1 = accD0;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            taco_f4 w;
+            w.x = wm[16 + NCD + n][0];
+            w.y = wm[16 + NCD + n][1];
+            w.z = wm[16 + NCD + n][2];
+            w.w = wm[16 + NCD + n][3];
+            TACO_MFMA4(accD0, accD1, w, xs[n])
+        }
+    }
+    taco_f4 pjc0 = {0.f, 0.f, 0.f, 0.f}, pjc1 = pjc0;                 // projection's context part (S5-late tail -> S6)
     for (int s = p.s0; s < p.s1; ++s) {
         float* curw = p.xch + (int64_t)(s - p.s0 + 1) * p.step_floats;
         taco_i4 rs, rq;                                              // this step's region (stores, fresh reads); the previous step's
@@ -1152,45 +1193,30 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                     if (d == 0) XST(R_EP + (g16 * 16 + tile) * PTp + pair, val);
                 }
             }
-        }
-        TF_STAMP()   /* 4 energies stored */
-        // ---------------- S5 early: the [att_h | dec_h] super-steps of the decoder cell (both already complete in memory)
-        {
-            int vp = 0;
-            asm volatile("" : "+v"(vp));
-            const int wz = wid + vp;
-            constexpr int NC = M_ / 64, NED = NSWD - NC;                  // context super-steps per wave (n = 16 .. 16 + NC - 1); the others
-            taco_f4 xs[NED];
-            const float* prvp = curw - p.step_floats;
-            for (int spin = 0;; ++spin) {
-                bool okv = true;
+            TF_STAMP()   /* 4 energies stored */
+            // ---- tail: the att_h super-steps of the decoder cell (this step) and of the attention cell (next step), operands = xa
+            {
+                const int wz = wid + vp;
 #pragma unroll
-                for (int e = 0; e < NED; ++e) {
-                    const int n = e < 16 ? e : e + NC;
-                    const int off = TACO_DEC_XOFF(wz + 4 * n);
-                    if (spin == 0) xs[e] = *reinterpret_cast<const taco_f4*>((e < 16 ? curw : prvp) + off);
-                    else xs[e] = e < 16 ? TACO_LD4(rs, off) : TACO_LD4(rq, off);
-                    okv = okv && TACO_OK4(xs[e]);
+                for (int n = 0; n < 16; ++n) {
+                    taco_f4 w;                                            // (a plain use: the compiler feeds the MFMA from the AGPR itself -- behind
+                                                                          //  an inline-asm v_accvgpr_read it does not see the VALU -> MFMA hazard)
+                    w.x = wm[n][0];
+                    w.y = wm[n][1];
+                    w.z = wm[n][2];
+                    w.w = wm[n][3];
+                    TACO_MFMA4(accD0, accD1, w, xa[n])
                 }
-                if (okv) break;
-                if (spin > POLL_LIM) { bad = true; break; }
-                TACO_BACKOFF
-            }
-            accD0 = taco_f4{0.f, 0.f, 0.f, 0.f};
-            accD1 = accD0;
+                accA0 = taco_f4{0.f, 0.f, 0.f, 0.f};
+                accA1 = accA0;
 #pragma unroll
-            for (int e = 0; e < NED; ++e) {
-                const int n = e < 16 ? e : e + NC;
-                taco_f4 w;                                        // (a plain use: the compiler feeds the MFMA from the AGPR itself -- behind
-                                                                  //  an inline-asm v_accvgpr_read it does not see the VALU -> MFMA hazard)
-                w.x = wm[n][0];
-                w.y = wm[n][1];
-                w.z = wm[n][2];
-                w.w = wm[n][3];
-                TACO_MFMA4(accD0, accD1, w, xs[e])
+                for (int n = 0; n < 16; ++n) {
+                    const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * (NCA + n + 4)) * 64 + lane]);
+                    TACO_MFMA4(accA0, accA1, wa, xa[n])
+                }
             }
         }
-        TF_STAMP()   /* 5 S5 early done */
+        TF_STAMP()   /* 5 S2 tail done */
         // ---------------- S4: masked softmax over the tokens of utterance b4, context columns cg MC .. +MC
         if (b4 < B) {
             const int t = tid;
@@ -1262,6 +1288,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             taco_f4 xc[NC], xn[NC];
 #pragma unroll
             for (int e = 0; e < NC; ++e) xc[e] = TACO_LD4(rs, TACO_DEC_XOFF(wz + 4 * (16 + e)));
+            // (constants for the tail: the projection's context columns, tile rows alternate (row 81 + bid, row bid) as in S6)
+            const float* wrowc = p.projx_w + (int64_t)((c16 & 1) ? min(bid, p.n_mels) : p.n_mels + 1 + bid) * G::KP + 4 * kq;
+            taco_f4 wc[NC];
+#pragma unroll
+            for (int e = 0; e < NC; ++e) wc[e] = *reinterpret_cast<const taco_f4*>(wrowc + 16 * (64 + wz + 4 * e));
             __builtin_amdgcn_s_sleep(TACO_POLL_GAP);
             for (int spin = 0;; ++spin) {
                 bool okv = true;
@@ -1293,37 +1324,27 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                 c_dec = sigmoidf_(gf) * c_dec + sigmoidf_(gi) * tanhf(gg);
                 if (c16 < B) XST(TR_DEC + bid * 32 + c16 * 4 + kq, sigmoidf_(go) * tanhf(c_dec));
             }
+            // ---- tail: the context super-steps of the next attention cell and of the projection, operands = xc
+#pragma unroll
+            for (int e = 0; e < NC; ++e) {
+                const taco_f4 wa = *reinterpret_cast<const taco_f4*>(&sWa[(wz + 4 * (e + 4)) * 64 + lane]);
+                TACO_MFMA4(accA0, accA1, wa, xc[e])
+            }
+            pjc0 = taco_f4{0.f, 0.f, 0.f, 0.f};
+            pjc1 = pjc0;
+#pragma unroll
+            for (int e = 0; e < NC; ++e) { TACO_MFMA4(pjc0, pjc1, wc[e], xc[e]) }
         }
         __syncthreads();
-        TF_STAMP()   /* 7 S5 late done (ctx polled, dec_h stored) */
+        TF_STAMP()   /* 7 S5 late done (ctx polled, dec_h stored, context tails) */
         // ---------------- S6: mel / gate row bid (< 81) and prenet layer-1 unit bid (folded) from [dec_h | ctx], on the matrix pipe:
-        // tile rows alternate (row 81 + bid, row bid); the context super-steps are folded in before the wait for dec_h
+        // tile rows alternate (row 81 + bid, row bid)
         {
             int vp = 0;
             asm volatile("" : "+v"(vp));
             const int wz = wid + vp;
             const float* wrow = p.projx_w + (int64_t)((c16 & 1) ? min(bid, p.n_mels) : p.n_mels + 1 + bid) * G::KP + 4 * kq;
-            constexpr int NC = M_ / 64;
-            taco_f4 pj0 = {0.f, 0.f, 0.f, 0.f}, pj1 = pj0;
-            {
-                taco_f4 wc[NC], xc[NC];
-#pragma unroll
-                for (int e = 0; e < NC; ++e) wc[e] = *reinterpret_cast<const taco_f4*>(wrow + 16 * (64 + wz + 4 * e));
-                for (int spin = 0;; ++spin) {                             // (complete since this block's S5 late: one pass)
-                    bool okv = true;
-#pragma unroll
-                    for (int e = 0; e < NC; ++e) {
-                        const int kc = 16 * (wz + 4 * e) + 4 * kq, cgx = kc / G::MC;
-                        xc[e] = TACO_LD4(rs, TR_CTX + (bl * 32 + cgx) * 32 + (kc - cgx * G::MC));
-                        okv = okv && TACO_OK4(xc[e]);
-                    }
-                    if (okv) break;
-                    if (spin > POLL_LIM) { bad = true; break; }
-                    TACO_BACKOFF
-                }
-#pragma unroll
-                for (int e = 0; e < NC; ++e) { TACO_MFMA4(pj0, pj1, wc[e], xc[e]) }
-            }
+            taco_f4 pj0 = pjc0, pj1 = pjc1;                              // the context columns: folded in by the S5-late tail
             taco_f4 wp[16], xd[16];
 #pragma unroll
             for (int n = 0; n < 16; ++n) wp[n] = *reinterpret_cast<const taco_f4*>(wrow + 16 * (wz + 4 * n));
@@ -1368,14 +1389,22 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                     XST(R_FIN + bb, __builtin_bit_cast(float, fin));
                 }
             }
+            TF_STAMP()   /* 8 S6 done (dec_h polled, h0 stored) */
+            // ---- tail: the dec_h super-steps of the NEXT step's decoder cell, operands = xd
+            accD0 = taco_f4{0.f, 0.f, 0.f, 0.f};
+            accD1 = accD0;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                taco_f4 w;
+                w.x = wm[16 + NCD + n][0];
+                w.y = wm[16 + NCD + n][1];
+                w.z = wm[16 + NCD + n][2];
+                w.w = wm[16 + NCD + n][3];
+                TACO_MFMA4(accD0, accD1, w, xd[n])
+            }
         }
         __syncthreads();
-        TF_STAMP()   /* 8 S6 done (dec_h polled, h0 stored) */
-        // ---------------- S1 early of the next step (context and att_h of this step are complete in memory); on the 64 prenet
-        // blocks it runs while h0 is on its way, so that they are not 4 us behind the others when the prenet output lands
-        TACO_ATT_EARLY(rs, curw)
-        __syncthreads();
-        TF_STAMP()   /* 9 S1 early done */
+        TF_STAMP()   /* 9 S6 tail done */
         // ---------------- S7: prenet layer 2, units 4 bid .. 4 bid + 3 on blocks 0..63
         if (bid < 64) {
             int vp = 0;
@@ -1422,7 +1451,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             return;
         }
     }
-#undef TACO_ATT_EARLY
+#undef TACO_ATT_LOAD_PART
 #undef TACO_MFMA4
 #undef TACO_ATT_XOFF
 #undef TACO_DEC_XOFF
