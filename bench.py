@@ -900,14 +900,15 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
                     'unit': 'audio samples/s', 'rtf': el / (fr * hop / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': 'f32',
                     'ms_tacotron2': el_t * 1e3, 'us_per_decoder_step': el_t / frames_t * 1e6,
                     'parity': 'unpinned (torchaudio Tacotron2 is not in the reference tree; SURVEY §8c)',
-                    # two parts with two different bounds: the decoder is a 448-step recurrence whose step is a chain of cross-XCD
-                    # hand-offs (latency: MI355X_MICROARCH.md hand-off price list), the vocoder is the MFMA conv engine
+                    # two parts with two different bounds: the decoder is a 448-step recurrence whose step is ONE dependent chain (six
+                    # cross-XCD hand-offs, the cells' serial MFMAs, operand round trips through L2), the vocoder is the MFMA conv engine
                     'roofline': dict(wall_roofline('f32', hgf * fr, 0.0, max(el - el_t, 1e-9)),
                                      what='HiFi-GAN part only: conv FLOPs / (whole call - Tacotron2 alone)'),
-                    'decoder': {'bound': 'latency (dependent cross-XCD hand-offs inside one persistent launch)',
+                    'decoder': {'bound': 'latency (one dependent chain per step inside one persistent launch)',
                                 'us_per_step': el_t / frames_t * 1e6, 'handoffs_per_step': TACO_HANDOFFS_PER_STEP,
-                                'handoff_us': 3.5, 'floor_us_per_step': TACO_HANDOFFS_PER_STEP * 3.5,
-                                'frac_of_floor': TACO_HANDOFFS_PER_STEP * 3.5 / (el_t / frames_t * 1e6),
+                                'handoff_us': TACO_HANDOFF_US, 'mfma_us_per_step': TACO_MFMA_US_PER_STEP,
+                                'floor_us_per_step': TACO_HANDOFFS_PER_STEP * TACO_HANDOFF_US + TACO_MFMA_US_PER_STEP,
+                                'frac_of_floor': (TACO_HANDOFFS_PER_STEP * TACO_HANDOFF_US + TACO_MFMA_US_PER_STEP) / (el_t / frames_t * 1e6),
                                 'lstm_tflops': lstm * fr / el_t / 1e12,
                                 'note': 'ms_tacotron2 also holds the encoder, the postnet and the host stop test (once per call)'}})
         del taco
@@ -995,6 +996,8 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
 
 
 TACO_HANDOFFS_PER_STEP = 6           # csrc/tacotron2.hip: dependent cross-CU hand-offs of one decoder step in the dataflow schedule
+TACO_HANDOFF_US = 0.5                # one word across XCDs, sc1 store -> sc1 poll (tools/handoff_bench.hip, profiles/r4/handoff_bench.txt)
+TACO_MFMA_US_PER_STEP = 5.8          # 108 super-steps x 4 v_mfma_f32_16x16x4_f32 (32 cycles each) per wave and step at 2.4 GHz: the serial matrix work
 
 
 def c1_configs(dev):
