@@ -1038,6 +1038,16 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         }
     }
     taco_f4 pjc0 = {0.f, 0.f, 0.f, 0.f}, pjc1 = pjc0;                 // projection's context part (S5-late tail -> S6)
+    // this thread's word of the alignment window of the block's energy tile (p1 - p0 + 2 half <= 158 words: one per thread)
+    const int aw_n = (p1 - p0) + 2 * half;
+    const int aw_fp = p0 - half + tid;
+    const bool aw_ok = aw_fp >= 0 && aw_fp < BL;
+    const int aw_fb = aw_ok ? aw_fp / L : 0, aw_fo = aw_fb * Lp + (aw_ok ? aw_fp - aw_fb * L : 0);
+    float aw_pre = 0.f, cum_pre = 0.f;
+    if (tid < aw_n) {
+        aw_pre = TACO_LD1(rs0, TR_AW + aw_fo);
+        cum_pre = TACO_LD1(rs0, R_CUM + aw_fo);
+    }
     for (int s = p.s0; s < p.s1; ++s) {
         float* curw = p.xch + (int64_t)(s - p.s0 + 1) * p.step_floats;
         taco_i4 rs, rq;                                              // this step's region (stores, fresh reads); the previous step's
@@ -1108,22 +1118,19 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             int vp = 0;
             asm volatile("" : "+v"(vp));
             const int tid = (int)threadIdx.x + vp;
-            // the previous step's alignment weights first: they have been in memory since its softmax phase
-            const int nw = (p1 - p0) + 2 * half;
-            for (int i = tid; i < nw; i += 256) {
-                const int fp = p0 - half + i;
-                const bool ok = fp >= 0 && fp < BL;
-                const int fb = ok ? fp / L : 0, fo = fb * Lp + (ok ? fp - fb * L : 0);
-                float a = 0.f, c = 0.f;
-                for (int spin = 0;; ++spin) {
-                    a = TACO_LD1(rq, TR_AW + fo);
-                    c = TACO_LD1(rq, R_CUM + fo);
-                    if (__builtin_bit_cast(unsigned, a) != SENT && __builtin_bit_cast(unsigned, c) != SENT) break;
+            // the previous step's alignment weights first: in memory since its softmax phase, and in this thread's registers since the
+            // fetch behind its S5 late (aw_pre / cum_pre: the 1.5-2 us round trip used to sit here, in front of the att_h poll); a sentinel
+            // (the fetch overtook the store) sends the thread to the polling path
+            if (tid < aw_n) {
+                float a = aw_pre, c = cum_pre;
+                for (int spin = 0; __builtin_bit_cast(unsigned, a) == SENT || __builtin_bit_cast(unsigned, c) == SENT; ++spin) {
                     if (spin > POLL_LIM) { bad = true; break; }
                     TACO_BACKOFF
+                    a = TACO_LD1(rq, TR_AW + aw_fo);
+                    c = TACO_LD1(rq, R_CUM + aw_fo);
                 }
-                sAw[i] = ok ? a : 0.f;
-                sCum[i] = ok ? c : 0.f;
+                sAw[tid] = aw_ok ? a : 0.f;
+                sCum[tid] = aw_ok ? c : 0.f;
             }
             __syncthreads();
             // the location term of this tile's energies depends on the previous alignment only: computed now, while att_h is on its way
@@ -1136,11 +1143,23 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
                     const int pair = it >> 3, d = it & 7, pp = p0 + pair, b = pp / L, t = pp - b * L;
                     const float* gd = sG + d * 2 * KS;
                     float loc = 0.f;
-                    for (int k = 0; k < KS; ++k) {
-                        const int tt = t + k - half;
-                        const bool ok = tt >= 0 && tt < L;
-                        loc = fmaf(gd[k], ok ? sAw[pair + k] : 0.f, loc);
-                        loc = fmaf(gd[KS + k], ok ? sCum[pair + k] : 0.f, loc);
+                    if (KS == 31) {                                       // the published filter length, unrolled: its 124 LDS reads go out together
+                                                                          // (rolled, every tap waited for its own four reads: 2.4 us at the head of S2)
+#pragma unroll
+                        for (int k = 0; k < 31; ++k) {
+                            const int tt = t + k - 15;
+                            const bool ok = tt >= 0 && tt < L;
+                            const float av = sAw[pair + k], cv = sCum[pair + k];
+                            loc = fmaf(gd[k], ok ? av : 0.f, loc);
+                            loc = fmaf(gd[31 + k], ok ? cv : 0.f, loc);
+                        }
+                    } else {
+                        for (int k = 0; k < KS; ++k) {
+                            const int tt = t + k - half;
+                            const bool ok = tt >= 0 && tt < L;
+                            loc = fmaf(gd[k], ok ? sAw[pair + k] : 0.f, loc);
+                            loc = fmaf(gd[KS + k], ok ? sCum[pair + k] : 0.f, loc);
+                        }
                     }
                     locv[u] = loc;
                 }
@@ -1334,6 +1353,12 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             pjc1 = pjc0;
 #pragma unroll
             for (int e = 0; e < NC; ++e) { TACO_MFMA4(pjc0, pjc1, wc[e], xc[e]) }
+            // ---- and the fetch of this step's alignment window for the NEXT step's location term (stored in S4, before the context this
+            // block has just seen complete)
+            if ((int)threadIdx.x < aw_n) {
+                aw_pre = TACO_LD1(rs, TR_AW + aw_fo);
+                cum_pre = TACO_LD1(rs, R_CUM + aw_fo);
+            }
         }
         __syncthreads();
         TF_STAMP()   /* 7 S5 late done (ctx polled, dec_h stored, context tails) */
@@ -1971,6 +1996,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         const char* pe = getenv("TTSAMD_TACO_PERSISTENT");
         const bool explicit_req = pe && (pe[0] == '1' || pe[0] == '2');          // an explicit request must run the persistent kernel or fail
         bool fits = want && B <= 8 && L <= 256 && (M == 512 || M == 640) && A == 1024 && D == 1024 && P == 256 && KS % 2 == 1 &&
+                    (B * L + 15) / 16 + KS - 1 <= 256 &&      /* the alignment window of an energy tile: one word per thread */
                     lds <= (size_t)std::max(lds_max, 64 * 1024) && n_cu >= 256 && coop && w.tail_o > 0;
         if (explicit_req && !fits) {
             set_error("tacotron2_infer: TTSAMD_TACO_PERSISTENT=%c but the persistent decoder does not fit (B=%d <= 8, L=%d <= 256, memory dim %d in "
