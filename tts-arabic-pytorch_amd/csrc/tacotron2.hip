@@ -1038,6 +1038,11 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
         }
     }
     taco_f4 pjc0 = {0.f, 0.f, 0.f, 0.f}, pjc1 = pjc0;                 // projection's context part (S5-late tail -> S6)
+    float pre1w[4] = {0.f, 0.f, 0.f, 0.f};                            // prenet layer 2: this thread's column of the block's four rows (blocks 0..63)
+    if (bid < 64) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre1w[r] = p.pre1[(int64_t)(4 * bid + r) * 256 + tid];
+    }
     // this thread's word of the alignment window of the block's energy tile (p1 - p0 + 2 half <= 158 words: one per thread)
     const int aw_n = (p1 - p0) + 2 * half;
     const int aw_fp = p0 - half + tid;
@@ -1452,7 +1457,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
             float v[32];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float wr = p.pre1[(int64_t)(4 * bid + r) * 256 + tid];
+                const float wr = pre1w[r];                               // (resident since the set-up: a load here sat between the h0 poll and the store of pre)
 #pragma unroll
                 for (int bb = 0; bb < 8; ++bb) v[r * 8 + bb] = wr * xs8[min(bb, B - 1)];
             }
