@@ -27,11 +27,14 @@ def main():
     raw = open('/tmp/taco_dump.bin', 'rb').read()
     x = np.frombuffer(raw[32:], dtype=np.uint32)
     st = x[26624:26624 + 8192].reshape(256, 32)[:, 8:19].astype(np.int64)
-    names = ['stop flags in', 'S1 late (poll pre, gates, store att_h)', 'poll att_h', 'query + energies + store', 'S2 tail (att_h super-steps of both cells)', 'S4 (poll epart, softmax, ctx)',
-             'S5 late (poll ctx, gates, store dec_h, context tails)', 'S6 (poll dec_h, proj, store h0)', 'S6 tail (dec_h super-steps, next step)', 'S7 (poll h0, prenet 2)']
+    names = ['stop flags in', 'S1 late (poll pre, gates, store att_h)', 'poll att_h', 'query + energies + store', 'S2 tail (att_h super-steps of both cells)',
+             'S4 (poll epart, softmax, ctx)', 'S5 late (poll ctx, gates, store dec_h, context tails)', 'S6 (poll dec_h, proj, store h0)',
+             'S6 tail (dec_h super-steps, next step)', 'S7 (poll h0, prenet 2)']
     d = np.diff(st, axis=1) * 0.01
     print('step length (block 0): %.2f us' % ((st[0, 10] - st[0, 0]) * 0.01))
+    ends = (st[:, 1:] - st[:, :1].min()) * 0.01     # absolute end time of every phase on every block, from the earliest block's step top
     for i, n in enumerate(names):
+        print(f'   [end of the phase below over the blocks: earliest {ends[:, i].min():6.2f}  mean {ends[:, i].mean():6.2f}  latest {ends[:, i].max():6.2f} us, latest block {int(ends[:, i].argmax())}, earliest block {int(ends[:, i].argmin())}]')
         print(f'{n:42s} mean {d[:, i].mean():6.2f}  min {d[:, i].min():6.2f}  max {d[:, i].max():6.2f} us   blocks 0-63 {d[:64, i].mean():6.2f}  block 80 {d[80, i]:6.2f}')
 
 

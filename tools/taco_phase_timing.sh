@@ -12,6 +12,6 @@ done
 if [ -n "$2" ]; then   # second argument: also the per-phase stamps of one step
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTP_TIMING -c tacotron2.hip -o /tmp/taco_skip.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../ttsamd/lib/libttsamd.so $(ls build/*.o | grep -v tacotron2.o) /tmp/taco_skip.o -ldl
-  (cd ../.. && timeout 300 python3 tools/taco_phase_stamps.py 2>&1 | tail -14; timeout 300 python3 tools/taco_flow_stamps.py 2>&1 | tail -12)
+  (cd ../.. && timeout 300 python3 tools/taco_phase_stamps.py 2>&1 | tail -14; timeout 300 python3 tools/taco_flow_stamps.py 2>&1 | tail -40)
 fi
 cp /tmp/libttsamd.keep ../ttsamd/lib/libttsamd.so
