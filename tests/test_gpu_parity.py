@@ -784,3 +784,31 @@ def test_attention_schedules_bit_identical(dev, fastpitch_engine, monkeypatch):
     assert int(lens.max()) > 128 and int(lens.min()) < 64 and bool(torch.isfinite(mels[0]).all())
     for m in mels[1:]:
         assert torch.equal(m, mels[0])
+
+
+@pytest.mark.parametrize('cin,cout,k,dil,lin,B', [(256, 256, 7, 3, 3584, 16), (128, 128, 11, 5, 7168, 16), (384, 1536, 3, 1, 448, 32), (1536, 384, 3, 1, 512, 16)])
+def test_conv1d_block_order_maps_bit_identical(dev, monkeypatch, cin, cout, k, dil, lin, B):
+    """Which XCD runs which (time tile, co-tile) is a schedule: the tile-owning map (an XCD keeps the co-tiles of its time tiles: default), one
+    co-tile class per XCD (TTSAMD_XCD_WMAX_KB=0) and the plain grid order (TTSAMD_XCD_W is read once per process, so that one is covered by
+    tools/ab_env.sh) give the same bits on a ragged batch with an empty utterance, and the float64 result within the conv tolerance."""
+    from ttsamd.engine import conv1d
+    g = torch.Generator().manual_seed(cin + cout + k + lin)
+    x = torch.randn(B, cin, lin, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    rng = np.random.default_rng(lin)
+    lens = torch.from_numpy(rng.integers(lin // 2, lin + 1, size=B)).long()
+    lens[0], lens[1], lens[B - 1] = lin, 0, lin - 3
+    xd, wd, bd, ld = x.to(dev), w.to(dev), b.to(dev), lens.to(dev)
+    ys = []
+    for wmax in ('3000', '0', '100000'):
+        monkeypatch.setenv('TTSAMD_XCD_WMAX_KB', wmax)
+        ys.append(conv1d(xd, wd, bd, ld, dilation=dil, in_slope=0.1).cpu())
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    for i in (0, 1, 2, B - 1):
+        n = int(lens[i])
+        if n:
+            ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x[i:i + 1, :, :n].double(), 0.1), w.double(), b.double(),
+                                             dilation=dil, padding=(k * dil - dil) // 2)[0]
+            assert maxabs(ys[0][i, :, :n], ref) < 3e-5, (i, n)
+        assert n == lin or float(ys[0][i, :, n:].abs().max()) == 0.0
