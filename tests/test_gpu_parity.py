@@ -789,8 +789,8 @@ def test_attention_schedules_bit_identical(dev, fastpitch_engine, monkeypatch):
 @pytest.mark.parametrize('cin,cout,k,dil,lin,B', [(256, 256, 7, 3, 3584, 16), (128, 128, 11, 5, 7168, 16), (384, 1536, 3, 1, 448, 32), (1536, 384, 3, 1, 512, 16)])
 def test_conv1d_block_order_maps_bit_identical(dev, monkeypatch, cin, cout, k, dil, lin, B):
     """Which XCD runs which (time tile, co-tile) is a schedule: the tile-owning map (an XCD keeps the co-tiles of its time tiles: default), one
-    co-tile class per XCD (TTSAMD_XCD_WMAX_KB=0) and the plain grid order (TTSAMD_XCD_W is read once per process, so that one is covered by
-    tools/ab_env.sh) give the same bits on a ragged batch with an empty utterance, and the float64 result within the conv tolerance."""
+    co-tile class per XCD (TTSAMD_XCD_WMAX_KB=0), every co-tile on one XCD and the plain grid order (TTSAMD_XCD_W=0) give the same bits on a
+    ragged batch with an empty utterance, and the float64 result within the conv tolerance."""
     from ttsamd.engine import conv1d
     g = torch.Generator().manual_seed(cin + cout + k + lin)
     x = torch.randn(B, cin, lin, generator=g)
@@ -801,10 +801,11 @@ def test_conv1d_block_order_maps_bit_identical(dev, monkeypatch, cin, cout, k, d
     lens[0], lens[1], lens[B - 1] = lin, 0, lin - 3
     xd, wd, bd, ld = x.to(dev), w.to(dev), b.to(dev), lens.to(dev)
     ys = []
-    for wmax in ('3000', '0', '100000'):
+    for wmax, xw in (('3000', '1'), ('0', '1'), ('100000', '1'), ('3000', '0')):
         monkeypatch.setenv('TTSAMD_XCD_WMAX_KB', wmax)
+        monkeypatch.setenv('TTSAMD_XCD_W', xw)
         ys.append(conv1d(xd, wd, bd, ld, dilation=dil, in_slope=0.1).cpu())
-    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
     for i in (0, 1, 2, B - 1):
         n = int(lens[i])
         if n:

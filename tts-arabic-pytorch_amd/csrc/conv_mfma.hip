@@ -708,7 +708,8 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     if (q.tile_major) std::swap(grid.x, grid.z);
     q.compact = (!q.tile_major && compact_order(p.lens_out, p.batch)) ? 1 : 0;
     {
-        static const bool xw = [] { const char* e = getenv("TTSAMD_XCD_W"); return !(e && e[0] == '0'); }();
+        const char* xe = getenv("TTSAMD_XCD_W");                    // read per call, like the other schedule switches
+        const bool xw = !(xe && xe[0] == '0');
         const unsigned nct = grid.y;
         const unsigned g = (nct % 8 == 0) ? 8 : (nct % 4 == 0 ? 4 : (nct % 2 == 0 ? 2 : 1));
         const bool can = xw && !q.tile_major && p.n_phase == 1 && ((int64_t)grid.x * grid.y * grid.z) % 8 == 0;
