@@ -107,13 +107,12 @@ def test_resblock_pair(dev, monkeypatch, C, k, dil, L, mode, out_slope, small_ti
 
 @pytest.mark.parametrize('C,L,mode,out_slope,B,k', [(128, 700, 0, 1.0, 3, 3), (64, 900, 1, 1.0, 3, 3), (32, 1500, 2, 0.1, 3, 3), (128, 300, 2, 0.01, 70, 3),
                                                     (64, 900, 0, 1.0, 3, 7), (32, 1500, 1, 1.0, 3, 7), (64, 700, 2, 0.01, 70, 7), (32, 1300, 2, 0.1, 5, 7)])
-def test_resblock_chain_equals_three_pairs_bit_for_bit(dev, monkeypatch, C, L, mode, out_slope, B, k):
+def test_resblock_chain_equals_three_pairs_bit_for_bit(dev, C, L, mode, out_slope, B, k):
     """The whole ResBlock in one launch (bfo_chain.hip; k = 3, and k = 7 at C <= 64) against three fused-pair launches of the same
     weights: identical bits (the chained kernel rounds the tensor between two pairs exactly where the pair launch rounds it for HBM).
     Ragged batch: an utterance ending inside the halo of a tile (24 of 256 / 512 columns at k = 3, 72 at k = 7), one shorter than a
     tile, (one case each) more than 64 utterances."""
     from ttsamd import bfo
-    monkeypatch.setenv('TTSAMD_BFO_CHAIN7', '1')
     g = torch.Generator().manual_seed(C + L + mode + k)
     dils = (1, 3, 5)
     x = torch.randn(B, C, L, generator=g) * 1.5
@@ -368,3 +367,24 @@ def test_split_k_small_batch(dev, synth_weights, monkeypatch):
     w_ab, w_a = float((wave_a - wave_b).abs().max()), float((wave_a - wave32).abs().max())
     print(f'split K vs un-split: mel {e_ab:.2e}, wave {w_ab:.2e}; vs fp32: mel {e_a:.2e}, wave {w_a:.2e}')
     assert e_a < BF16_MEL_TOL and w_a < BF16_WAVE_TOL and e_ab < 2e-2 and w_ab < 2e-2
+
+
+def test_resblock_chain_entry_rejects_what_it_cannot_run(dev):
+    """C-ABI error behaviour of the kernel-level chain entry: k = 7 exists for C <= 64 only, k = 11 not at all, x == y never; what it can run it runs
+    whatever the generator's routing switches say (TTSAMD_BFO_CHAIN / _CHAIN7 steer hifigan.hip, not the entry)."""
+    from ttsamd import bfo
+    from ttsamd.lib import TtsAmdError
+    x = bfo.pack(torch.randn(1, 128, 300, device=dev), 0.1)
+    def ws(C, k):
+        return ([bfo.pack_weight(torch.randn(C, C, k) / np.sqrt(C * k), device=dev) for _ in range(3)], [torch.zeros(C, device=dev) for _ in range(3)])
+    w7, b7 = ws(128, 7)
+    with pytest.raises(TtsAmdError, match='unsupported geometry'):
+        bfo.resblock_chain(x, w7, b7, w7, b7, (1, 3, 5), k=7)                    # C = 128 at k = 7
+    w11, b11 = ws(128, 11)
+    with pytest.raises(TtsAmdError, match='kernel size'):
+        bfo.resblock_chain(x, w11, b11, w11, b11, (1, 3, 5), k=11)
+    w3, b3 = ws(128, 3)
+    with pytest.raises(TtsAmdError, match='differ'):
+        bfo.resblock_chain(x, w3, b3, w3, b3, (1, 3, 5), y=x, k=3)
+    with pytest.raises(TtsAmdError, match='unsupported geometry'):
+        bfo.resblock_chain(x, w3, b3, w3, b3, (1, 3, 9), k=3)                    # dilation beyond the built window

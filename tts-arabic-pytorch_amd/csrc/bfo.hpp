@@ -106,6 +106,7 @@ bool bfo_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L);
 int32_t bfo_launch_pair(int32_t channels, int32_t k, const BfoPairParams& p, hipStream_t s);
 // a whole k = 3 (or, C <= 64, k = 7) ResBlock in one launch (bfo_chain.hip); TTSAMD_BFO_CHAIN=0: three pair launches
 bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch);
+bool bfo_chain_wanted(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch);      // + the routing switches
 int32_t bfo_launch_chain(int32_t channels, const BfoChainParams& p, hipStream_t s);
 int32_t bfo_launch_conv(const BfoConvParams& p, hipStream_t s);
 int32_t bfo_launch_convt(const BfoConvParams& p, hipStream_t s);

@@ -232,14 +232,12 @@ static int32_t bfo_launch_chain_nt(const BfoChainParams& p, hipStream_t stream) 
 // are not free; at k = 11 and at C = 128 k = 7 the pairs run at the power-managed matrix roof and the halo would only cost).
 // TTSAMD_BFO_CHAIN=0 keeps the three pair launches, TTSAMD_BFO_CHAIN7=0 / 1 forces the k = 7 choice (k = 3 measured: batch 32 11.63 -> 11.32 ms per step,
 // batch 8 4.38 -> 4.21, batch 1 2.09 -> 1.97).
+// what the kernel can run (the C-ABI entry ttsamd_bfo_resblock_chain accepts exactly this) ...
 bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch) {
-    const char* ce = getenv("TTSAMD_BFO_CHAIN");               // read per call, like the other schedule switches: tests and A/B runs flip it
-    const bool off = ce && ce[0] == '0';
-    if (off || n_pairs != 3) return false;
+    (void)batch;
+    if (n_pairs != 3) return false;
     if (k == 7) {
-        const char* c7 = getenv("TTSAMD_BFO_CHAIN7");           // 0 / 1 force it; default: small batches only
-        const bool on7 = c7 ? c7[0] != '0' : (int64_t)batch * L <= kBfoChain7MaxColumns;
-        if (!on7 || !(channels == 32 || channels == 64)) return false;
+        if (!(channels == 32 || channels == 64)) return false;
     } else if (k != 3 || !(channels == 32 || channels == 64 || channels == 128)) {
         return false;
     }
@@ -248,6 +246,18 @@ bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_
     if ((int64_t)channels * L * 2 >= ((int64_t)1 << 31)) return false;
     const int ncols = channels == 32 ? 512 : 256;
     return ncols - (k - 1) * (dil[0] + dil[1] + dil[2] + 3) >= ncols / 2;
+}
+
+// ... and what the generator routes to it (the switches are read per call, like the other schedule switches: tests and A/B runs flip them)
+bool bfo_chain_wanted(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch) {
+    const char* ce = getenv("TTSAMD_BFO_CHAIN");
+    if (ce && ce[0] == '0') return false;
+    if (k == 7) {
+        const char* c7 = getenv("TTSAMD_BFO_CHAIN7");           // 0 / 1 force it; default: small batches only
+        const bool on7 = c7 ? c7[0] != '0' : (int64_t)batch * L <= kBfoChain7MaxColumns;
+        if (!on7) return false;
+    }
+    return bfo_chain_supported(channels, k, dil, n_pairs, L, batch);
 }
 
 int32_t bfo_launch_chain(int32_t channels, const BfoChainParams& p, hipStream_t stream) {

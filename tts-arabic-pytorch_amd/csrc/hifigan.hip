@@ -470,7 +470,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     const int li0 = (i * cfg.n_kernels + j) * cfg.n_dilations;
                     int32_t dl[3] = {0, 0, 0};
                     for (int m = 0; m < cfg.n_dilations && m < 3; ++m) dl[m] = cfg.resblock_dilations[j][m];
-                    if (bfo_chain_supported(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B)) {
+                    if (bfo_chain_wanted(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B)) {
                         BfoChainParams cc;
                         std::memset(&cc, 0, sizeof(cc));
                         cc.x = src; cc.y = curo; cc.sum_in = curo;
