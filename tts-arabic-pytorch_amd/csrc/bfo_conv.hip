@@ -369,8 +369,11 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream
     const bool ln = p.ln_g != nullptr;
     if (ln) TTS_REQUIRE(OUT_F32 && p.y_f32 && p.ln_b && p.ln_octet && p.Cout % 64 == 0 && p.Cout <= 8 * LNO_MAXV_R,
                         "bfo conv: the LayerNorm epilogue needs the fp32 output and Cout %% 64 == 0, <= %d (Cout=%d)", 8 * LNO_MAXV_R, p.Cout);
-    const char* fle = getenv("TTSAMD_BFO_FUSED_LN");           // 0: reduction and LayerNorm as two launches (A/B, parity tests)
-    const bool fuse_ln = !(fle && fle[0] == '0') && (p.Cout == 256 || p.Cout == 384 || p.Cout == 512) &&
+    // TTSAMD_BFO_FUSED_LN=1: the reduction finishes with the LayerNorm (one launch less, same bits).  Default OFF since round 4: its 15-block grid at
+    // batch 1 (32 positions per block, ksplit x 48 loads per thread) is slower than the wide reduction + the LayerNorm launch it replaces
+    // (bf16 batch 1 2.40 -> 2.35 ms, batch 8 4.67 -> 4.65; the fp32 twin of this kernel measured 4.88 -> 5.25 ms and was not kept)
+    const char* fle = getenv("TTSAMD_BFO_FUSED_LN");
+    const bool fuse_ln = (fle && fle[0] == '1') && (p.Cout == 256 || p.Cout == 384 || p.Cout == 512) &&
                          (int64_t)p.batch * p.Cout * p.Lin * 4 * 4 < ((int64_t)1 << 31);      // 32-bit buffer offsets over <= 4 slices
     if (p.ksplit > 1) {
         if (ln && fuse_ln) {
