@@ -107,9 +107,9 @@ typedef struct ttsamd_tagger_cfg {
 const char* ttsamd_last_error(void);
 /* ABI revision of this header.  Bumped whenever a struct gains a field or an argument changes meaning (2: ttsamd_tacotron2_cfg
  * gained decoder_early_stopping, ttsamd_profile_read's third value became the number of timed sections; 3: ttsamd_dp_* may be
- * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument).  ttsamd_version() returns the value the library was BUILT with: a caller
+ * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument; 5: the ttsamd_bfo3_* entries).  ttsamd_version() returns the value the library was BUILT with: a caller
  * compiled against another revision must refuse to run (ttsamd/lib.py does). */
-#define TTSAMD_ABI_VERSION 4
+#define TTSAMD_ABI_VERSION 5
 int32_t ttsamd_version(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
 int32_t ttsamd_device_ok(void);
@@ -302,6 +302,28 @@ int32_t ttsamd_bfo_resblock_chain(const void* x, const void* const* w1, const fl
 /* wave[b][t] = tanh(bias + conv7(x)); x = 32-channel octet tensor already activated with slope 0.01 (models.py:123-125) */
 int32_t ttsamd_bfo_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul,
                              int32_t batch, int32_t channels, int32_t len, float* wave, int64_t wave_stride, void* stream);
+
+/* ---- split-bf16 ("x3") mode of the octet engine: the same layers with fp32-class results (north_star's 1e-3 / 1e-4), every
+ *      value = hi + lo (two bf16), three v_mfma_f32_32x32x16_bf16 per product (Wh xh + Wh xl + Wl xh, fp32 accumulate).
+ *      Activations ("x3 tensor"): [B][C/8][L][2][hi 4 bf16 | lo 4 bf16] = 32 bytes per (octet, position) -- the 16-byte half kk
+ *      holds channels 8o + 4kk + {0..3}, one lane's slice of the MFMA C layout -- stored PRE-ACTIVATED like the bf16 tensors.
+ *      Weights: [phases][Cin/16][K][2][CoutP][hi 8 | lo 8] bf16.  Same argument meanings as the ttsamd_bfo_* twins above;
+ *      ttsamd_hifigan_forward / ttsamd_fastpitch_* route through these kernels under ttsamd_set_precision(2).
+ *      Ops: vocoder/hifigan/models.py:46-53, 96-99, 111-127. ------------------------------------------------------------------- */
+int32_t ttsamd_bfo3_pack(const float* x, int32_t batch, int32_t channels, int32_t len, float slope, void* out, void* stream);
+int32_t ttsamd_bfo3_unpack(const void* in, int32_t batch, int32_t channels, int32_t len, float slope, float* out, void* stream);
+int64_t ttsamd_bfo3_weight_elems(int32_t cout, int32_t cin, int32_t k, int32_t up);
+int32_t ttsamd_bfo3_pack_weight(const float* w, int32_t cout, int32_t cin, int32_t k, int32_t up, uint16_t* out);
+int32_t ttsamd_bfo3_conv1d(const void* x, const void* w_packed, const float* bias, const void* res, const void* sum_in,
+                           const int64_t* lens, int32_t len_mul, int32_t batch, int32_t cin, int32_t cout, int32_t k,
+                           int32_t dilation, int32_t up, int32_t len_in, int32_t mode, float div, float res_slope,
+                           float out_slope, void* y, float* y_f32, const float* res_f32, void* stream);
+int32_t ttsamd_bfo3_resblock_pair(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                                  const void* sum_in, const int64_t* lens, int32_t len_mul, int32_t batch, int32_t channels,
+                                  int32_t k, int32_t dilation, int32_t len, int32_t mode, float div, float in_slope,
+                                  float mid_slope, float out_slope, void* y, void* stream);
+int32_t ttsamd_bfo3_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul,
+                              int32_t batch, int32_t channels, int32_t len, float* wave, int64_t wave_stride, void* stream);
 
 /* MFMA operand precision of every conv/linear GEMM launched by the model forwards (process-wide):
  *   0 (default) exact fp32 (v_mfma_f32_32x32x2_f32) — BASELINE config 2;

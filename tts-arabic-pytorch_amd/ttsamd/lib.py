@@ -96,6 +96,13 @@ SYMBOLS = {
     'ttsamd_bfo_resblock_pair': (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P, _P]),
     'ttsamd_bfo_resblock_chain': (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P, _P, _I32]),
     'ttsamd_bfo_conv_post': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P]),
+    'ttsamd_bfo3_pack': (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),
+    'ttsamd_bfo3_unpack': (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),
+    'ttsamd_bfo3_weight_elems': (_I64, [_I32, _I32, _I32, _I32]),
+    'ttsamd_bfo3_pack_weight': (_I32, [_P, _I32, _I32, _I32, _I32, _P]),
+    'ttsamd_bfo3_conv1d': (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _P, _P, _P, _P]),
+    'ttsamd_bfo3_resblock_pair': (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P, _P]),
+    'ttsamd_bfo3_conv_post': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P]),
     'ttsamd_set_precision': (_I32, [_I32]),
     'ttsamd_get_precision': (_I32, []),
     'ttsamd_dp_unique_id': (_I32, [_P]),
@@ -113,7 +120,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 4            # == TTSAMD_ABI_VERSION of include/ttsamd.h (struct layouts and argument meanings of this binding)
+ABI_VERSION = 5            # == TTSAMD_ABI_VERSION of include/ttsamd.h (struct layouts and argument meanings of this binding)
 
 
 def load():
