@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "kernels.hpp"
-#include "bfo.hpp"
+#include "bfo3.hpp"
 
 namespace ttsamd {
 
@@ -24,6 +24,7 @@ struct ConvW {
     int64_t w_off = 0, b_off = 0;  // float offsets into the device weight blob
     int64_t w16_off = 0, w_n = 0;  // bf16 planes (hi, lo) in the uint16 blob; packed element count
     int64_t wo_off = -1;           // bf16 octet engine (bfo.hpp): [Cin/16][K][2][CoutP][8] in the same uint16 blob (-1: not packed)
+    int64_t wo3_off = -1;          // its split-bf16 mode (bfo3.hpp): [Cin/16][K][2][CoutP][hi 8 | lo 8]
     int cin = 0, cout = 0, k = 0;
 };
 
@@ -59,7 +60,7 @@ static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
     // bf16 octet engine: the launches are power-bound at batch 32 and latency-bound below; the fork / join events cost more than the
     // overlap returns under ~8 k frames (batch 1: 2.09 -> 1.92 ms, batch 8: 4.35 -> 4.26 on one stream; batch 32: 10.02 -> 9.88 ms with
     // three under the two-stream pipeline)
-    if (default_precision() == 1 && h->bfo_ok) {
+    if ((default_precision() == 1 || default_precision() == 2) && h->bfo_ok) {
         const char* bfo_env = std::getenv("TTSAMD_BFO");
         if (!(bfo_env && bfo_env[0] == '0')) return (int64_t)B * T >= 8192;
     }
@@ -182,6 +183,10 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
         cw.wo_off = (int64_t)blob16.size();
         blob16.resize(blob16.size() + (size_t)bfo_packed_conv_elems(cout, cin, k));
         bfo_pack_conv_weight(w.data(), cout, cin, k, blob16.data() + cw.wo_off);
+        blob16.resize(align_up((int64_t)blob16.size(), 64));
+        cw.wo3_off = (int64_t)blob16.size();
+        blob16.resize(blob16.size() + (size_t)bfo3_packed_conv_elems(cout, cin, k));
+        bfo3_pack_conv_weight(w.data(), cout, cin, k, blob16.data() + cw.wo3_off);
     }
     blob.resize(align_up((int64_t)blob.size(), 64));
     return get_bias(tm, base, cout, blob, cw.b_off);
@@ -234,6 +239,10 @@ int32_t hifigan_create(const ttsamd_tensor* weights, int32_t n, const ttsamd_hif
             cw.wo_off = (int64_t)blob16.size();
             blob16.resize(blob16.size() + (size_t)bfo_packed_convt_elems(cin, cout, u));
             bfo_pack_convt_weight(w.data(), cin, cout, u, blob16.data() + cw.wo_off);
+            blob16.resize(align_up((int64_t)blob16.size(), 64));
+            cw.wo3_off = (int64_t)blob16.size();
+            blob16.resize(blob16.size() + (size_t)bfo3_packed_convt_elems(cin, cout, u));
+            bfo3_pack_convt_weight(w.data(), cin, cout, u, blob16.data() + cw.wo3_off);
         }
         blob.resize(align_up((int64_t)blob.size(), 64));
         rc = get_bias(tm, "ups." + std::to_string(i), cout, blob, cw.b_off);
@@ -342,7 +351,7 @@ int64_t hifigan_workspace_bytes(const HifiGan* h, int32_t B, int32_t T) {
     const int nb = use_branch_streams(h, B, T) ? 3 : 1;
     for (int i = 0; i < 2 + 2 * nb; ++i) a.take<float>((int64_t)B * h->max_cl * T);
     for (int i = 0; i < nb; ++i) a.take<float>(kSplitKFloats);
-    a.take<uint16_t>((int64_t)B * align_up(h->cfg.num_mels, 8) * T);   // bf16 octet engine: the mel in its layout
+    a.take<uint16_t>((int64_t)B * align_up(h->cfg.num_mels, 8) * T * 2);   // octet engine: the mel in its layout (x3: 4 bytes per element)
     return a.off;
 }
 
@@ -361,7 +370,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     }
     for (int i = 0; i < nb; ++i) splitks[i] = a.take<float>(kSplitKFloats);
     for (int i = nb; i < 3; ++i) { Tbs[i] = Tbs[0]; Rs[i] = Rs[0]; splitks[i] = splitks[0]; }
-    uint16_t* mel_o = a.take<uint16_t>((int64_t)B * align_up(h->cfg.num_mels, 8) * T);
+    uint16_t* mel_o = a.take<uint16_t>((int64_t)B * align_up(h->cfg.num_mels, 8) * T * 2);
     if (!ws || !a.ok) {
         set_error("hifigan_forward: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
         return TTSAMD_ENOMEM;
@@ -422,22 +431,30 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
 
 #define HG_TRY(expr) do { int32_t rc_ = (expr); if (rc_ != 0) return fail(rc_); } while (0)
 #define HG_CHECK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return fail(TTSAMD_EHIP); } } while (0)
-    // ---- config 3: plain bf16 runs on the octet engine (bfo.hpp): v_mfma_f32_32x32x16_bf16, bf16 activations in HBM stored
-    // pre-activated for their consumer, fused c1 -> c2 pairs for C <= 128.  TTSAMD_BFO=0 keeps the round-2 bf16 engine.
+    // ---- config 3: plain bf16 (precision 1) and split bf16 (precision 2) run on the octet engine (bfo.hpp / bfo3.hpp):
+    // v_mfma_f32_32x32x16_bf16, activations in HBM as octet entries (bf16, or hi + lo) stored pre-activated for their consumer,
+    // fused c1 -> c2 pairs for C <= 128.  TTSAMD_BFO=0 keeps the round-2 bf16 engine (fp32 activations in HBM).
     const char* bfo_env = std::getenv("TTSAMD_BFO");
-    if (default_precision() == 1 && h->bfo_ok && !(bfo_env && bfo_env[0] == '0')) {
+    const int prec = default_precision();
+    if ((prec == 1 || prec == 2) && h->bfo_ok && !(bfo_env && bfo_env[0] == '0')) {
+        const bool x3 = prec == 2;
         const uint16_t* W16 = h->dev16;
-        void *curo = cur, *upso = ups_out;                 // the fp32-sized buffers hold bf16 tensors of the same element count
-        HG_TRY(bfo_launch_pack(mel, B, cfg.num_mels, T, 1.f, mel_o, s));
+        const auto woff = [x3](const ConvW& cw) { return x3 ? cw.wo3_off : cw.wo_off; };
+        const auto l_conv = x3 ? bfo3_launch_conv : bfo_launch_conv;
+        const auto l_convt = x3 ? bfo3_launch_convt : bfo_launch_convt;
+        const auto l_pair = x3 ? bfo3_launch_pair : bfo_launch_pair;
+        const auto pair_ok = x3 ? bfo3_pair_supported : bfo_pair_supported;
+        void *curo = cur, *upso = ups_out;                 // the fp32-sized buffers hold bf16 / x3 tensors of the same element count
+        HG_TRY((x3 ? bfo3_launch_pack : bfo_launch_pack)(mel, B, cfg.num_mels, T, 1.f, mel_o, s));
         BfoConvParams cp;
         std::memset(&cp, 0, sizeof(cp));
         cp.batch = B; cp.lens = lens; cp.div = 1.f; cp.res_slope = 1.f;
         // conv_pre (models.py:112); its consumer, the first upsampler, applies leaky_relu(0.1) (models.py:114)
-        cp.x = mel_o; cp.y = curo; cp.w = W16 + h->conv_pre.wo_off; cp.bias = h->dev + h->conv_pre.b_off;
+        cp.x = mel_o; cp.y = curo; cp.w = W16 + woff(h->conv_pre); cp.bias = h->dev + h->conv_pre.b_off;
         cp.len_mul = 1; cp.Lin = T; cp.Cin = h->conv_pre.cin; cp.Cout = h->conv_pre.cout; cp.K = 7; cp.dil = 1; cp.up = 1;
         cp.mode = 0; cp.out_slope = 0.1f;
         prof_begin(s, 2.0 * cp.Cout * cp.Cin * 7);
-        int32_t rc = bfo_launch_conv(cp, s);
+        int32_t rc = l_conv(cp, s);
         prof_end(s);
         HG_TRY(rc);
         int L = T, mul = 1;
@@ -445,11 +462,11 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
             const int u = cfg.upsample_rates[i];
             const ConvW& uw = h->ups[i];
             // ConvTranspose1d on the activated stage input; the ResBlocks read its output through leaky_relu(0.1)
-            cp.x = curo; cp.y = upso; cp.w = W16 + uw.wo_off; cp.bias = h->dev + uw.b_off; cp.res = nullptr; cp.sum_in = nullptr;
+            cp.x = curo; cp.y = upso; cp.w = W16 + woff(uw); cp.bias = h->dev + uw.b_off; cp.res = nullptr; cp.sum_in = nullptr;
             cp.len_mul = mul; cp.Lin = L; cp.Cin = uw.cin; cp.Cout = uw.cout; cp.K = 2; cp.dil = 1; cp.up = u;
             cp.mode = 0; cp.out_slope = 0.1f;
             prof_begin(s, 2.0 * uw.cout * uw.cin * 2 * u * mul);
-            rc = bfo_launch_convt(cp, s);
+            rc = l_convt(cp, s);
             prof_end(s);
             HG_TRY(rc);
             L *= u; mul *= u;
@@ -470,13 +487,13 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     const int li0 = (i * cfg.n_kernels + j) * cfg.n_dilations;
                     int32_t dl[3] = {0, 0, 0};
                     for (int m = 0; m < cfg.n_dilations && m < 3; ++m) dl[m] = cfg.resblock_dilations[j][m];
-                    if (bfo_chain_wanted(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B)) {
+                    if (!x3 && bfo_chain_wanted(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B)) {
                         BfoChainParams cc;
                         std::memset(&cc, 0, sizeof(cc));
                         cc.x = src; cc.y = curo; cc.sum_in = curo;
                         for (int m = 0; m < 3; ++m) {
                             const ConvW &w1 = h->c1[li0 + m], &w2 = h->c2[li0 + m];
-                            cc.w1[m] = W16 + w1.wo_off; cc.w2[m] = W16 + w2.wo_off; cc.b1[m] = h->dev + w1.b_off; cc.b2[m] = h->dev + w2.b_off;
+                            cc.w1[m] = W16 + woff(w1); cc.w2[m] = W16 + woff(w2); cc.b1[m] = h->dev + w1.b_off; cc.b2[m] = h->dev + w2.b_off;
                             cc.dil[m] = dl[m];
                         }
                         cc.lens = lens; cc.len_mul = mul; cc.L = L; cc.batch = B; cc.k = h->c1[li0].k;
@@ -504,15 +521,15 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     const float out_slope = !last ? 0.1f : (j + 1 == cfg.n_kernels ? next_slope : 1.f);
                     if (multi && last && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
                     const double fl = 2.0 * (2.0 * w1.cin * w1.cin * w1.k) * mul;
-                    if (bfo_pair_supported(w1.cin, w1.k, d, L)) {
+                    if (pair_ok(w1.cin, w1.k, d, L)) {
                         BfoPairParams pp;
                         std::memset(&pp, 0, sizeof(pp));
                         pp.x = src; pp.y = dst; pp.sum_in = curo;
-                        pp.w1 = W16 + w1.wo_off; pp.w2 = W16 + w2.wo_off; pp.b1 = h->dev + w1.b_off; pp.b2 = h->dev + w2.b_off;
+                        pp.w1 = W16 + woff(w1); pp.w2 = W16 + woff(w2); pp.b1 = h->dev + w1.b_off; pp.b2 = h->dev + w2.b_off;
                         pp.lens = lens; pp.len_mul = mul; pp.L = L; pp.dil = d; pp.batch = B;
                         pp.mode = mode; pp.div = (float)cfg.n_kernels; pp.in_slope = 0.1f; pp.mid_slope = 0.1f; pp.out_slope = out_slope;
                         if (in_section) prof_add(fl); else prof_begin(st, fl);
-                        rc = bfo_launch_pair(w1.cin, w1.k, pp, st);
+                        rc = l_pair(w1.cin, w1.k, pp, st);
                         if (!in_section) prof_end(st);
                         HG_TRY(rc);
                     } else {
@@ -520,16 +537,16 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                         // residual only at its own output positions, so it may run in place (dst == src == R)
                         void* t1 = Tb;
                         if (!last) dst = R;
-                        cp.x = src; cp.y = t1; cp.w = W16 + w1.wo_off; cp.bias = h->dev + w1.b_off; cp.res = nullptr; cp.sum_in = nullptr;
+                        cp.x = src; cp.y = t1; cp.w = W16 + woff(w1); cp.bias = h->dev + w1.b_off; cp.res = nullptr; cp.sum_in = nullptr;
                         cp.len_mul = mul; cp.Lin = L; cp.Cin = w1.cin; cp.Cout = w1.cout; cp.K = w1.k; cp.dil = d; cp.up = 1;
                         cp.mode = 0; cp.out_slope = 0.1f; cp.res_slope = 1.f;
                         cp.splitk_ws = splitks[j % 3]; cp.splitk_floats = kSplitKFloats;     // batch 1: 30 blocks per stage-1 conv
                         if (in_section) prof_add(fl); else prof_begin(st, fl);
-                        rc = bfo_launch_conv(cp, st);
+                        rc = l_conv(cp, st);
                         if (rc == 0) {
-                            cp.x = t1; cp.y = dst; cp.w = W16 + w2.wo_off; cp.bias = h->dev + w2.b_off; cp.res = src; cp.sum_in = curo;
+                            cp.x = t1; cp.y = dst; cp.w = W16 + woff(w2); cp.bias = h->dev + w2.b_off; cp.res = src; cp.sum_in = curo;
                             cp.dil = 1; cp.mode = mode; cp.div = (float)cfg.n_kernels; cp.out_slope = out_slope; cp.res_slope = 0.1f;
-                            rc = bfo_launch_conv(cp, st);
+                            rc = l_conv(cp, st);
                         }
                         if (!in_section) prof_end(st);
                         HG_TRY(rc);
@@ -544,7 +561,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                 prof_section_end(s);
             }
         }
-        HG_TRY(bfo_launch_conv_post(curo, h->dev + h->conv_post.w_off, h->dev + h->conv_post.b_off, lens, mul, B, h->conv_post.cin,
+        HG_TRY((x3 ? bfo3_launch_conv_post : bfo_launch_conv_post)(curo, h->dev + h->conv_post.w_off, h->dev + h->conv_post.b_off, lens, mul, B, h->conv_post.cin,
                                     L, wave, (int64_t)L, s));
         return 0;
     }
