@@ -28,6 +28,9 @@ int32_t bfo3_launch_convt(const BfoConvParams& p, hipStream_t s);
 // fp32 channel-first [B][C][L] <-> x3 tensor (leaky-relu with `slope` on the way in, its inverse on the way out)
 int32_t bfo3_launch_pack(const float* x, int32_t B, int32_t C, int32_t L, float slope, void* out, hipStream_t s);
 int32_t bfo3_launch_unpack(const void* in, int32_t B, int32_t C, int32_t L, float slope, float* out, hipStream_t s);
+// LayerNorm over the channels of a channel-first fp32 tensor (in place or not) + its x3 copy for the conv that follows (C = 256 / 384 / 512)
+int32_t launch_layernorm_cf_x3(const float* x, float* y, void* y_x3, const float* gamma, const float* beta, const int64_t* lens,
+                               int32_t apply_mask, int32_t B, int32_t C, int32_t S, hipStream_t s, float eps = 1e-5f);
 // HiFi-GAN tail on an x3 tensor activated with slope 0.01: wave = tanh(conv7(a) + b)   (models.py:123-125)
 int32_t bfo3_launch_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul, int32_t B,
                               int32_t C, int32_t L, float* wave, int64_t wave_bs, hipStream_t s);

@@ -184,16 +184,18 @@ static int32_t bfo3_launch_conv_k(const BfoConvParams& p, hipStream_t stream) {
     // tiles for short sequences (FastPitch encoder: 64 tokens per utterance) and for grids under one block per CU
     const int64_t blocks4 = (int64_t)((p.Lin + 127) / 128) * ((p.Cout + 127) / 128) * p.batch;
     const bool narrow = p.Cout >= 128 && (p.Lin <= 96 || blocks4 < 256);
+    // slab depth: 4 16-channel groups (45 KB of LDS at k = 11), 8 at k <= 3 (70 KB): half the barriers of the deep-K conv-FF convs
+    constexpr int SH = K <= 3 ? 8 : 4;
     if (p.y_f32) {
         if (p.Cout < 128) {
             set_error("bfo3 conv: fp32 output is built for Cout >= 128 (got %d)", p.Cout);
             return TTSAMD_EINVAL;
         }
-        if (narrow) return bfo3_launch_conv_cfg<K, 4, 1, 2, 4, true>(p, stream);
-        return bfo3_launch_conv_cfg<K, 4, 1, 4, 4, true>(p, stream);
+        if (narrow) return bfo3_launch_conv_cfg<K, 4, 1, 2, SH, true>(p, stream);
+        return bfo3_launch_conv_cfg<K, 4, 1, 4, SH, true>(p, stream);
     }
-    if (narrow) return bfo3_launch_conv_cfg<K, 4, 1, 2, 4, false>(p, stream);
-    if (p.Cout >= 128) return bfo3_launch_conv_cfg<K, 4, 1, 4, 4, false>(p, stream);
+    if (narrow) return bfo3_launch_conv_cfg<K, 4, 1, 2, SH, false>(p, stream);
+    if (p.Cout >= 128) return bfo3_launch_conv_cfg<K, 4, 1, 4, SH, false>(p, stream);
     if (p.Cout >= 64) return bfo3_launch_conv_cfg<K, 2, 2, 4, 4, false>(p, stream);
     return bfo3_launch_conv_cfg<K, 1, 4, 4, 2, false>(p, stream);
 }
@@ -373,6 +375,76 @@ __global__ __launch_bounds__(256) void bfo3_unpack_kernel(const uint4* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e)
         if (8 * o + e < C) yr[(int64_t)e * L] = (inv_slope >= 1.f ? bfo_unrelu(v[e], inv_slope) : bfo_lrelu(v[e], inv_slope));
+}
+
+// LayerNorm over the channel axis of a channel-first fp32 tensor (transformer.py:88,158,174,176; model.py:56) that ALSO writes its
+// result as an x3 tensor: the input copy of the conv that follows (FastPitch in this mode).  The arithmetic is that of
+// layernorm_cf_octet_kernel (bfo_conv.hip): block = 32 positions x 8 channel groups, group g owns the contiguous channels
+// [g C/8, (g+1) C/8) = C/64 whole octets, so its 32-byte entries are complete in one thread.
+template <int CPG>
+__global__ __launch_bounds__(256) void layernorm_cf_x3_kernel(const float* __restrict__ x, float* __restrict__ y, uint4* __restrict__ yo,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const int64_t* __restrict__ lens, int apply_mask, int C, int S, float eps) {
+    __shared__ float red[8][32];
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tl;
+    const bool ok = t < S;
+    const int c0 = g * CPG;
+    const float* xb = x + ((int64_t)b * C + c0) * S + (ok ? t : 0);
+    float v[CPG];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPG; ++i) {
+        v[i] = xb[(int64_t)i * S];
+        sum += v[i];
+    }
+    red[g][tl] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][tl];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPG; ++i) {
+        const float d = v[i] - mean;
+        sq = fmaf(d, d, sq);
+    }
+    red[g][tl] = sq;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][tl];
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+    if (!ok) return;
+    float m = 1.f;
+    if (apply_mask && lens && t >= (int)lens[b]) m = 0.f;
+    float* yb = y + ((int64_t)b * C + c0) * S + t;
+#pragma unroll
+    for (int i = 0; i < CPG; ++i) {
+        v[i] = ((v[i] - mean) * rstd * gamma[c0 + i] + beta[c0 + i]) * m;
+        yb[(int64_t)i * S] = v[i];
+    }
+#pragma unroll
+    for (int o = 0; o < CPG / 8; ++o) {
+        uint4* dst = yo + (((int64_t)b * (C / 8) + c0 / 8 + o) * S + t) * 2;
+        dst[0] = __builtin_bit_cast(uint4, bfo3_split4(v[8 * o], v[8 * o + 1], v[8 * o + 2], v[8 * o + 3], -1));
+        dst[1] = __builtin_bit_cast(uint4, bfo3_split4(v[8 * o + 4], v[8 * o + 5], v[8 * o + 6], v[8 * o + 7], -1));
+    }
+}
+
+int32_t launch_layernorm_cf_x3(const float* x, float* y, void* y_x3, const float* gamma, const float* beta, const int64_t* lens,
+                               int32_t apply_mask, int32_t B, int32_t C, int32_t S, hipStream_t s, float eps) {
+    TTS_REQUIRE((C == 384 || C == 256 || C == 512) && y_x3, "layernorm (x3): built for 256 / 384 / 512 channels (C=%d)", C);
+    if (S <= 0 || B <= 0) return 0;
+    dim3 grid((S + 31) / 32, B);
+    if (C == 384) hipLaunchKernelGGL(layernorm_cf_x3_kernel<48>, grid, dim3(256), 0, s, x, y, (uint4*)y_x3, gamma, beta, lens, apply_mask, C, S, eps);
+    else if (C == 256) hipLaunchKernelGGL(layernorm_cf_x3_kernel<32>, grid, dim3(256), 0, s, x, y, (uint4*)y_x3, gamma, beta, lens, apply_mask, C, S, eps);
+    else hipLaunchKernelGGL(layernorm_cf_x3_kernel<64>, grid, dim3(256), 0, s, x, y, (uint4*)y_x3, gamma, beta, lens, apply_mask, C, S, eps);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int32_t bfo3_launch_pack(const float* x, int32_t B, int32_t C, int32_t L, float slope, void* out, hipStream_t s) {

@@ -12,13 +12,14 @@
 #include <vector>
 
 #include "kernels.hpp"
-#include "bfo.hpp"
+#include "bfo3.hpp"
 
 namespace ttsamd {
 
 struct PConv {
     int64_t w_off = 0, b_off = -1, w16_off = 0;
     int64_t wo_off = -1;   // bf16 octet engine weights [Cin/16][K][2][CoutP][8] in the uint16 blob (the conv-FF convs; -1: not packed)
+    int64_t wo3_off = -1;  // ... and their split-bf16 twin [Cin/16][K][2][CoutP][hi 8 | lo 8] (bfo3.hpp)
     int cin = 0, cout = 0, k = 0;
 };
 struct FftLayer {
@@ -105,6 +106,10 @@ struct Builder {
             c.wo_off = (int64_t)blob16.size();
             blob16.resize(blob16.size() + (size_t)bfo_packed_conv_elems(cout, cin, k));
             bfo_pack_conv_weight(w->data, cout, cin, k, blob16.data() + c.wo_off);
+            blob16.resize(align_up((int64_t)blob16.size(), 64));
+            c.wo3_off = (int64_t)blob16.size();
+            blob16.resize(blob16.size() + (size_t)bfo3_packed_conv_elems(cout, cin, k));
+            bfo3_pack_conv_weight(w->data, cout, cin, k, blob16.data() + c.wo3_off);
         }
         blob.resize(align_up((int64_t)blob.size(), 64));
         if (bias) c.b_off = raw(base + ".bias", cout);
@@ -234,6 +239,7 @@ void fastpitch_destroy(FastPitch* h) {
 
 struct FftWs {
     float *q, *a, *y, *hid, *splitk;
+    float* o3;          // split-bf16 mode: the x3 copies of x, y and the attention output ((2 d + d_head) x 4 bytes per position)
 };
 
 // split-K scratch of the call in flight on this thread (carved from the caller's workspace by encode / decode)
@@ -313,6 +319,46 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
         }
         return 0;
     }
+    bool x3 = default_precision() == 2 && !(ffe && ffe[0] == '0') && (d == 384 || d == 256 || d == 512) && d_head % 8 == 0 && w.o3;
+    for (const FftLayer& l : layers)
+        x3 = x3 && l.ff0.wo3_off >= 0 && l.ff2.wo3_off >= 0 && l.qkv.wo3_off >= 0 && l.o_net.wo3_off >= 0 && l.qkv.cout == 3 * d_head;
+    if (x3) {
+        // ---- split bf16: the block above with every GEMM operand = hi + lo (bfo3.hpp).  The residual stream stays fp32 channel-first;
+        // each GEMM reads an x3 copy of its input written by its producer (LayerNorm, the ReLU conv, or a pack of the attention output):
+        //   xo -> qkv conv -> fp32 q|k|v -> exact fp32 attention -> a -> pack -> ao -> o_net conv + x -> y -> LayerNorm 1 -> y, yo
+        //   -> Conv1d + ReLU -> hid (x3, 1536 channels = the whole fp32-sized buffer) -> Conv1d + y -> x -> LayerNorm 2 -> x, xo
+        const int di = layers[0].ff0.cout;
+        (void)di;
+        char* base = (char*)w.o3;
+        void* xo = base;
+        void* yo = base + (int64_t)B * d * S * 4;
+        void* ao = (char*)yo + (int64_t)B * d * S * 4;
+        void* hid_o = w.hid;
+        TTS_TRY(bfo3_launch_pack(x, B, d, S, 1.f, xo, s));
+        BfoConvParams cp;
+        auto conv = [&](const PConv& c, const void* in, void* out_o, float* out_f, const float* res_f, float out_slope) -> int32_t {
+            std::memset(&cp, 0, sizeof(cp));
+            cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
+            cp.x = in; cp.y = out_o; cp.y_f32 = out_f; cp.res_f32 = res_f;
+            cp.w = h->dev16 + c.wo3_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
+            cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = out_slope;
+            prof_begin(s, 2.0 * c.cout * c.cin * c.k);
+            const int32_t rc = bfo3_launch_conv(cp, s);
+            prof_end(s);
+            return rc;
+        };
+        for (const FftLayer& l : layers) {
+            TTS_TRY(conv(l.qkv, xo, nullptr, w.q, nullptr, 1.f));
+            TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s, t_splitk_ws, t_splitk_ws ? kSplitKFloatsFp : 0));
+            TTS_TRY(bfo3_launch_pack(w.a, B, d_head, S, 1.f, ao, s));
+            TTS_TRY(conv(l.o_net, ao, nullptr, w.y, x, 1.f));
+            TTS_TRY(launch_layernorm_cf_x3(w.y, w.y, yo, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
+            TTS_TRY(conv(l.ff0, yo, hid_o, nullptr, nullptr, 0.f));               // ReLU = leaky-relu with slope 0, applied by the producer
+            TTS_TRY(conv(l.ff2, hid_o, nullptr, x, w.y, 1.f));
+            TTS_TRY(launch_layernorm_cf_x3(x, x, xo, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
+        }
+        return 0;
+    }
     for (const FftLayer& l : layers) {
         TTS_TRY(run_conv(h, l.qkv, x, w.q, nullptr, B, S, nullptr, 0, s));
         TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s, t_splitk_ws, t_splitk_ws ? kSplitKFloatsFp : 0));
@@ -328,7 +374,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
 // model.py:129-133; input masked on load (lens_in), hidden NOT masked
 static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const float* x, const int64_t* lens, int B,
                              int S, float* t0, float* t1, float* out, float* out2, float max_dur, float mul,
-                             float add, hipStream_t s) {
+                             float add, hipStream_t s, void* px3 = nullptr) {
     const float* src = x;
     float* bufs[2] = {t0, t1};
     {
@@ -365,6 +411,34 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
             return launch_pred_fc(t0, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul, add, s);
         }
     }
+    {
+        // split bf16: the same chain on the x3 kernels.  The x3 tensors are as large as the fp32 ones: the packed input ([B][cin][S] x 4
+        // bytes, cin <= 2 filter would not fit) and the copy of the first LayerNorm's output both go to `px3`
+        const char* ffe = std::getenv("TTSAMD_BFO_FF");
+        bool x3 = default_precision() == 2 && !(ffe && ffe[0] == '0') && pr.convs.size() == 2 && (pr.filter == 256 || pr.filter == 384 || pr.filter == 512) &&
+                  pr.convs[0].cin % 8 == 0 && pr.convs[0].cin <= pr.filter * 2 && px3 != nullptr;
+        for (const PConv& c : pr.convs) x3 = x3 && c.wo3_off >= 0;
+        if (x3) {
+            BfoConvParams cp;
+            auto conv = [&](const PConv& c, const void* in, float* out_f, const int64_t* lens_in) -> int32_t {
+                std::memset(&cp, 0, sizeof(cp));
+                cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
+                cp.x = in; cp.y_f32 = out_f; cp.lens = lens_in; cp.out_all = 1;
+                cp.w = h->dev16 + c.wo3_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
+                cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = 0.f;                      // ReLU
+                prof_begin(s, 2.0 * c.cout * c.cin * c.k);
+                const int32_t rc = bfo3_launch_conv(cp, s);
+                prof_end(s);
+                return rc;
+            };
+            TTS_TRY(bfo3_launch_pack(x, B, pr.convs[0].cin, S, 1.f, px3, s));
+            TTS_TRY(conv(pr.convs[0], px3, t0, lens));
+            TTS_TRY(launch_layernorm_cf_x3(t0, t0, px3, h->dev + pr.ln_g[0], h->dev + pr.ln_b[0], nullptr, 0, B, pr.filter, S, s));
+            TTS_TRY(conv(pr.convs[1], px3, t1, nullptr));
+            TTS_TRY(launch_layernorm_cf(t1, t1, h->dev + pr.ln_g[1], h->dev + pr.ln_b[1], nullptr, 0, B, pr.filter, S, s));
+            return launch_pred_fc(t1, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul, add, s);
+        }
+    }
     for (size_t i = 0; i < pr.convs.size(); ++i) {
         float* dst = bufs[i & 1];
         TTS_TRY(run_conv(h, pr.convs[i], src, dst, nullptr, B, S, i == 0 ? lens : nullptr, 1, s));
@@ -389,6 +463,7 @@ static void carve_enc(const FastPitch* h, Arena& a, int B, int L, EncWs& w) {
     w.f.a = a.take<float>((int64_t)B * c.in_fft_n_heads * c.in_fft_d_head * L);
     w.f.y = a.take<float>((int64_t)B * d * L);
     w.f.hid = a.take<float>((int64_t)B * c.in_fft_filter * L);
+    w.f.o3 = a.take<float>((int64_t)B * (2 * d + c.in_fft_n_heads * c.in_fft_d_head) * L);
     w.p0 = a.take<float>((int64_t)B * filt * L);
     w.p1 = a.take<float>((int64_t)B * filt * L);
     w.log_dur = a.take<float>((int64_t)B * L);
@@ -430,15 +505,15 @@ int32_t fastpitch_encode(const FastPitch* h, const int64_t* ids, int32_t B, int3
                          w.lens, s));
     TTS_TRY(run_fft(h, h->enc, c.in_fft_d_head, x, w.lens, B, L, w.f, s));
     // durations (model.py:367-368)
-    TTS_TRY(run_predictor(h, h->dur, x, w.lens, B, L, w.p0, w.p1, w.log_dur, dur_pred, max_duration, 1.f, 0.f, s));
+    TTS_TRY(run_predictor(h, h->dur, x, w.lens, B, L, w.p0, w.p1, w.log_dur, dur_pred, max_duration, 1.f, 0.f, s, w.f.o3));
     // pitch (model.py:371-386); pitch_trf = mul*p + add (networks.py:38-42)
-    TTS_TRY(run_predictor(h, h->pitch, x, w.lens, B, L, w.p0, w.p1, pitch_pred, nullptr, 0.f, pitch_mul, pitch_add, s));
+    TTS_TRY(run_predictor(h, h->pitch, x, w.lens, B, L, w.p0, w.p1, pitch_pred, nullptr, 0.f, pitch_mul, pitch_add, s, w.f.o3));
     TTS_TRY(launch_scalar_emb_add(x, pitch_tgt ? pitch_tgt : pitch_pred, h->dev + h->pitch_emb_w,
                                   h->dev + h->pitch_emb_b, B, d, L, c.pitch_emb_kernel, s));
     // energy (model.py:389-399)
     if (c.energy_conditioning) {
         if (energy_pred)
-            TTS_TRY(run_predictor(h, h->energy, x, w.lens, B, L, w.p0, w.p1, energy_pred, nullptr, 0.f, 1.f, 0.f, s));
+            TTS_TRY(run_predictor(h, h->energy, x, w.lens, B, L, w.p0, w.p1, energy_pred, nullptr, 0.f, 1.f, 0.f, s, w.f.o3));
         TTS_TRY(launch_scalar_emb_add(x, energy_tgt ? energy_tgt : energy_pred, h->dev + h->energy_emb_w,
                                       h->dev + h->energy_emb_b, B, d, L, c.energy_emb_kernel, s));
     }
@@ -453,6 +528,7 @@ static void carve_dec(const FastPitch* h, Arena& a, int B, int T, FftWs& w) {
     w.y = a.take<float>((int64_t)B * c.d_model * T);
     w.hid = a.take<float>((int64_t)B * c.out_fft_filter * T);
     w.splitk = a.take<float>(kSplitKFloatsFp);
+    w.o3 = a.take<float>((int64_t)B * (2 * c.d_model + c.out_fft_n_heads * c.out_fft_d_head) * T);
 }
 
 int64_t fastpitch_decode_workspace_bytes(const FastPitch* h, int32_t B, int32_t T) {
