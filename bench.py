@@ -726,7 +726,7 @@ def main():
         # (profiles/rN/traffic.json; gpurun forbids mixing PMC with the timed run), newest round first
         traffic, traffic_src, traffic_alg = None, None, None
         if B == 32 and Lt == 64 and world == 1:
-            for rnd in ('r4', 'r3', 'r2', 'r1'):
+            for rnd in ('r5', 'r4', 'r3', 'r2', 'r1'):
                 try:
                     with open(os.path.join(REPO, 'profiles', rnd, 'traffic.json' if args.precision == 'f32' else f'traffic_{args.precision}.json')) as f:
                         tj = json.load(f)
@@ -751,7 +751,7 @@ def main():
                 'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
-                    'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'conv1d_mfma_bf16') + ' (all instantiations)',
+                    'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
                      'traffic_algorithmic': traffic_alg, 'traffic_ratio': (traffic / traffic_alg) if (traffic and traffic_alg) else None,
@@ -861,6 +861,23 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
         del ids256, dur256
     except Exception as e:                                       # noqa: BLE001
         res.append({'config': 'C3 at batch 256 on one GPU', 'error': str(e)[:300]})
+    # C3 INSIDE north_star's tolerance (mel 1e-3 / wave 1e-4): the same engine in its split-bf16 mode -- every operand hi + lo, three
+    # v_mfma_f32_32x32x16_bf16 per product, x3 tensors (4 bytes per element) in HBM; tests: test_full_batch_every_utterance[bf16x3],
+    # test_config3_full_size_256_utterances_bf16x3.  `peak` of its roofline entry = 2.5 PFLOP/s / 3 algorithmic.
+    try:
+        c3x = small_config(B, prec='bf16x3', pipelined=True,
+                           name=f'C3 per-GPU share inside the 1e-3 / 1e-4 tolerance: FastPitch+HiFi-GAN, synthetic 64-phoneme x batch{B}, '
+                                'split-bf16 MFMA on the octet engine (bfo3_*)')
+        c3x['ms_per_step_one_stream'] = small_config(B, prec='bf16x3')['ms_per_step']
+        res.append(c3x)
+        b_full = 256
+        ids256 = torch.from_numpy(synth.synth_ids(b_full, ids.shape[1])).to(dev)
+        dur256 = torch.from_numpy(synth.synth_durations(b_full, ids.shape[1])).to(dev)
+        res.append(small_config(b_full, prec='bf16x3', pipelined=True, inputs=(ids256, dur256),
+                                name='C3 at its full size on ONE GPU inside the 1e-3 / 1e-4 tolerance: synthetic 64-phoneme x batch256, split-bf16 MFMA'))
+        del ids256, dur256
+    except Exception as e:                                       # noqa: BLE001
+        res.append({'config': 'C3 split-bf16', 'error': str(e)[:300]})
     torch.cuda.empty_cache()
     n = max(args.steps, 10)
     hgf = hifigan_flops_per_frame(HIFIGAN_CONFIG)

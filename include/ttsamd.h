@@ -322,6 +322,11 @@ int32_t ttsamd_bfo3_resblock_pair(const void* x, const void* w1, const float* b1
                                   const void* sum_in, const int64_t* lens, int32_t len_mul, int32_t batch, int32_t channels,
                                   int32_t k, int32_t dilation, int32_t len, int32_t mode, float div, float in_slope,
                                   float mid_slope, float out_slope, void* y, void* stream);
+/* a whole k = 3 ResBlock1 (three pairs, dilations[0..2]) in one launch; equals three ttsamd_bfo3_resblock_pair calls bit for bit */
+int32_t ttsamd_bfo3_resblock_chain(const void* x, const void* const* w1, const float* const* b1, const void* const* w2,
+                                   const float* const* b2, const int32_t* dilations, const void* sum_in, const int64_t* lens,
+                                   int32_t len_mul, int32_t batch, int32_t channels, int32_t len, int32_t mode, float div,
+                                   float in_slope, float mid_slope, float out_slope, void* y, void* stream);
 int32_t ttsamd_bfo3_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul,
                               int32_t batch, int32_t channels, int32_t len, float* wave, int64_t wave_stride, void* stream);
 

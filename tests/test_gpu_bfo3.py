@@ -76,8 +76,8 @@ def _pair_ref(a, w1, b1, w2, b2, k, dil, sum_raw, mode, div, in_slope, out_slope
 ])
 def test_resblock_pair3(dev, C, k, dil, L, mode, out_slope):
     """Fused c1 -> c2 pair vs the reference ops in float64; ragged batch incl. an utterance ending inside a tile halo, one ending
-    before the first tile boundary, and the untouched tail past each length; every window geometry of the launcher (two blocks per
-    CU; C = 128 k = 11 at dilation <= 3; the 8-wave block of C = 128 k = 11 d = 5)."""
+    before the first tile boundary, and the untouched tail past each length; every window geometry of the launcher (two 4-wave blocks
+    per CU at C <= 64, the 8-wave block of C = 128)."""
     from ttsamd import bfo
     g = torch.Generator().manual_seed(C * 100 + k * 10 + dil)
     B = 3
@@ -86,7 +86,7 @@ def test_resblock_pair3(dev, C, k, dil, L, mode, out_slope):
     w2 = torch.randn(C, C, k, generator=g) / np.sqrt(C * k)
     b1, b2 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
     s_raw = torch.randn(B, C, L, generator=g)
-    ncols = {128: 128, 64: 256, 32: 512}[C] * (2 if (C, k, dil) == (128, 11, 5) else 1)
+    ncols = {128: 256, 64: 256, 32: 512}[C]                                            # C = 128: one 8-wave block, 2 x 128 columns
     ts = ncols - (k - 1)                                                               # outputs per block (Bfo3PairGeo::TS)
     lens = torch.tensor([L, min(L, ts + 2), max(1, min(L, ts) - 5)], dtype=torch.int64)     # ends 2 columns into tile 1 / inside tile 0
     xo = bfo.pack3(x.to(dev), 0.1)
@@ -224,3 +224,57 @@ def test_conv_post3(dev):
         ref = torch.tanh(F.conv1d(a_all[i:i + 1, :, :n], w.double(), b.double(), padding=3))[0, 0]
         assert float((wave[i, :n].double() - ref).abs().max()) < 1e-5
         assert float(wave[i, n:].abs().max()) == 0.0 if n < L else True
+
+
+@pytest.mark.parametrize('C,L,mode,out_slope,B', [(128, 700, 0, 1.0, 3), (64, 900, 1, 1.0, 3), (32, 1500, 2, 0.1, 3), (128, 300, 2, 0.01, 70),
+                                                  (64, 520, 0, 0.1, 5), (32, 1100, 1, 1.0, 4)])
+def test_resblock_chain3_equals_three_pairs_bit_for_bit(dev, C, L, mode, out_slope, B):
+    """The whole k = 3 ResBlock in one launch (bfo3_chain.hip) against three fused-pair launches of the same weights: identical bits
+    (the chained kernel splits the tensor between two pairs exactly where the pair launch splits it for HBM) -- and the pairs are
+    checked against float64 above.  Ragged batch: an utterance ending inside the halo of a tile (24 of 256 / 512 columns), one shorter
+    than a tile, (one case) more than 64 utterances."""
+    from ttsamd import bfo
+    g = torch.Generator().manual_seed(C + L + mode)
+    k, dils = 3, (1, 3, 5)
+    x = torch.randn(B, C, L, generator=g) * 1.5
+    ws = [[torch.randn(C, C, k, generator=g) / np.sqrt(C * k) for _ in range(3)] for _ in range(2)]
+    bs = [[torch.randn(C, generator=g) * 0.3 for _ in range(3)] for _ in range(2)]
+    s_raw = torch.randn(B, C, L, generator=g)
+    ts = {128: 256, 64: 256, 32: 512}[C] - 24
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2] = L, min(L, ts + 5), max(1, min(L, ts) - 9)
+    lens_d = lens.to(dev)
+    xo, so = bfo.pack3(x.to(dev), 0.1), bfo.pack3(s_raw.to(dev), 1.0)
+    w1p, w2p = [bfo.pack_weight3(w, device=dev) for w in ws[0]], [bfo.pack_weight3(w, device=dev) for w in ws[1]]
+    b1d, b2d = [b.to(dev) for b in bs[0]], [b.to(dev) for b in bs[1]]
+    t = xo
+    for m in range(3):                      # three pair launches, as csrc/hifigan.hip issues them under TTSAMD_BFO_CHAIN=0
+        last = m == 2
+        y = (so.clone() if mode != 0 else torch.full_like(xo, 0x4242)) if last else torch.zeros_like(xo)
+        bfo.resblock_pair3(t, w1p[m], b1d[m], w2p[m], b2d[m], k, dils[m], lens=lens_d, sum_in=y if (last and mode != 0) else None,
+                           mode=mode if last else 0, div=3.0, out_slope=out_slope if last else 0.1, y=y)
+        t = y
+    ref = t
+    y = so.clone() if mode != 0 else torch.full_like(xo, 0x4242)
+    bfo.resblock_chain3(xo, w1p, b1d, w2p, b2d, dils, lens=lens_d, sum_in=y if mode != 0 else None, mode=mode, div=3.0,
+                        out_slope=out_slope, y=y)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+
+
+def test_hifigan_x3_chained_resblocks_change_no_bit(dev, synth_weights, monkeypatch):
+    """The generator's launch schedule in this mode is a routing choice, not a numeric one: k = 3 ResBlocks as one launch (default)
+    or as three pair launches (TTSAMD_BFO_CHAIN=0) give the same wave bit for bit on a ragged batch."""
+    from ttsamd.engine import HifiGanEngine, set_precision
+    g = torch.Generator().manual_seed(9)
+    mel = torch.randn(3, 80, 57, generator=g).to(dev)
+    lens = torch.tensor([57, 31, 4], dtype=torch.int64, device=dev)
+    set_precision('bf16x3')
+    try:
+        hg = HifiGanEngine(synth_weights['hifigan'], device=dev)
+        wave = hg.forward(mel, lens).clone()
+        monkeypatch.setenv('TTSAMD_BFO_CHAIN', '0')
+        wave_p = hg.forward(mel, lens).clone()
+    finally:
+        set_precision('f32')
+    assert torch.equal(wave, wave_p)

@@ -23,6 +23,9 @@ namespace ttsamd {
 // sum_in pointing at x3 tensors and w at x3 weights
 bool bfo3_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L);
 int32_t bfo3_launch_pair(int32_t channels, int32_t k, const BfoPairParams& p, hipStream_t s);
+// a whole k = 3 ResBlock (three pairs) in one launch (bfo3_chain.hip); bit-identical to three bfo3_launch_pair calls
+bool bfo3_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L);
+int32_t bfo3_launch_chain(int32_t channels, const BfoChainParams& p, hipStream_t s);
 int32_t bfo3_launch_conv(const BfoConvParams& p, hipStream_t s);
 int32_t bfo3_launch_convt(const BfoConvParams& p, hipStream_t s);
 // fp32 channel-first [B][C][L] <-> x3 tensor (leaky-relu with `slope` on the way in, its inverse on the way out)

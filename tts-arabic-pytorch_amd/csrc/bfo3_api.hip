@@ -72,6 +72,28 @@ int32_t ttsamd_bfo3_resblock_pair(const void* x, const void* w1, const float* b1
     return rc;
 }
 
+int32_t ttsamd_bfo3_resblock_chain(const void* x, const void* const* w1, const float* const* b1, const void* const* w2,
+                                   const float* const* b2, const int32_t* dilations, const void* sum_in, const int64_t* lens,
+                                   int32_t len_mul, int32_t batch, int32_t channels, int32_t len, int32_t mode, float div,
+                                   float in_slope, float mid_slope, float out_slope, void* y, void* stream) {
+    TTS_REQUIRE(x && w1 && b1 && w2 && b2 && dilations && y && batch >= 1, "bfo3_resblock_chain: null argument");
+    TTS_REQUIRE(mode >= 0 && mode <= 2 && in_slope > 0.f && mid_slope > 0.f && out_slope > 0.f, "bfo3_resblock_chain: bad mode / slope");
+    BfoChainParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x; p.y = y; p.sum_in = sum_in; p.lens = lens;
+    for (int m = 0; m < 3; ++m) {
+        TTS_REQUIRE(w1[m] && b1[m] && w2[m] && b2[m], "bfo3_resblock_chain: null weight");
+        p.w1[m] = w1[m]; p.w2[m] = w2[m]; p.b1[m] = b1[m]; p.b2[m] = b2[m]; p.dil[m] = dilations[m];
+    }
+    p.len_mul = len_mul; p.L = len; p.batch = batch; p.mode = mode; p.div = div; p.k = 3;
+    p.in_slope = in_slope; p.mid_slope = mid_slope; p.out_slope = out_slope;
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(s, 3 * 2.0 * (2.0 * channels * channels * 3));
+    const int32_t rc = bfo3_launch_chain(channels, p, s);
+    prof_end(s);
+    return rc;
+}
+
 int32_t ttsamd_bfo3_conv_post(const void* x, const float* w, const float* bias, const int64_t* lens, int32_t len_mul,
                               int32_t batch, int32_t channels, int32_t len, float* wave, int64_t wave_stride, void* stream) {
     TTS_REQUIRE(x && w && wave && batch >= 1, "bfo3_conv_post: null argument");

@@ -6,10 +6,9 @@
 //   * the window is TWO planes (hi, lo) of octet entries, so LDS holds 2 x C x (NCOLS + (K - 1) d) x 2 bytes; the three
 //     products re-read the hi plane instead of staging it twice (two ds_read_b128 per three MFMAs);
 //   * HBM accesses are 16 bytes per lane (the 32-byte x3 entry = the C-layout halves of lanes kk = 0 / 1 side by side).
-// Block = NW waves (4, or 8 for the C = 128 k = 11 d = 5 window that only fits a CU once), each owning a 32-row x (NT x 32)-
-// column slab; WM = C / 32 row slabs x WN = NW / WM column slabs.  LDS is sized by DM = the largest dilation an instantiation
-// serves, so every pair but that one keeps two blocks per CU (<= 80 KB): one block's staging / exchange / stores run
-// under the other's MFMAs.
+// Block = NW waves, each owning a 32-row x (NT x 32)-column slab; WM = C / 32 row slabs x WN = NW / WM column slabs.
+// C <= 64: NW = 4, two blocks per CU (<= 80 KB of LDS each): one block's staging / exchange / stores run under the other's
+// MFMAs.  C = 128: NW = 8 (4 x 2 waves, 256 columns), one block per CU (136-154 KB; DM = the largest dilation served).
 //   stage    2 NE 16-byte pieces (piece u = half kk = u & 1 of entry u >> 1), fully coalesced; halves -> the two planes;
 //   phase A  T = conv(window, w1) on NCOLS = TS + K - 1 positions, accumulators start from b1 (bfo3_mma);
 //   T -> LDS lrelu(T), zero outside the utterance, split into hi / lo, over the dead window;
@@ -227,16 +226,16 @@ int32_t bfo3_launch_pair(int32_t channels, int32_t k, const BfoPairParams& p, hi
     TTS_REQUIRE(p.x != p.y, "split-bf16 ResBlock pair: x and y must differ (halo reads)");
     TTS_REQUIRE(p.mode == 0 || p.sum_in != nullptr, "split-bf16 ResBlock pair: mode %d needs sum_in", p.mode);
     conv_log("bfo3_pair", k, channels, channels, p.L, p.batch, 1, p.mode, p.len_mul, p.lens != nullptr, 1);
-    // every window with two blocks per CU: 4 waves x (32 rows x 128 columns); C = 128 k = 11 fits twice up to dilation 3
+    // C <= 64: two blocks of 4 waves x (32 rows x 128 columns) per CU.  C = 128: ONE block of 8 waves per CU (WM = 4 row slabs x
+    // WN = 2 column slabs, 256 columns: half the halo of a 128-column block, 136-154 KB of LDS)
 #define BFO3_CASE(KK, CC) if (k == KK && channels == CC) return bfo3_launch_pair_cfg<KK, CC, 4, 4, BFO_DMAX>(p, stream);
     BFO3_CASE(3, 32) BFO3_CASE(7, 32) BFO3_CASE(11, 32)
     BFO3_CASE(3, 64) BFO3_CASE(7, 64) BFO3_CASE(11, 64)
-    BFO3_CASE(3, 128) BFO3_CASE(7, 128)
 #undef BFO3_CASE
-    if (k == 11 && channels == 128) {
-        if (p.dil <= 3) return bfo3_launch_pair_cfg<11, 128, 4, 4, 3>(p, stream);
-        return bfo3_launch_pair_cfg<11, 128, 4, 8, BFO_DMAX>(p, stream);     // 8 waves x 128 columns, one block per CU
-    }
+    // (measured on the bench step, tools/ab_x3_w8.sh: 26.05-26.08 ms against 26.18 with two 4-wave blocks per CU where they fit)
+#define BFO3_CASE8(KK) if (k == KK && channels == 128) return bfo3_launch_pair_cfg<KK, 128, 4, 8, BFO_DMAX>(p, stream);
+    BFO3_CASE8(3) BFO3_CASE8(7) BFO3_CASE8(11)
+#undef BFO3_CASE8
     return TTSAMD_EINVAL;
 }
 

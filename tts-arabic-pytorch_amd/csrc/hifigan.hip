@@ -487,7 +487,9 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     const int li0 = (i * cfg.n_kernels + j) * cfg.n_dilations;
                     int32_t dl[3] = {0, 0, 0};
                     for (int m = 0; m < cfg.n_dilations && m < 3; ++m) dl[m] = cfg.resblock_dilations[j][m];
-                    if (!x3 && bfo_chain_wanted(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B)) {
+                    const char* c3e = std::getenv("TTSAMD_BFO_CHAIN");      // 0: three pair launches (bit-identical; A/B and parity runs)
+                    const bool chain3 = x3 && !(c3e && c3e[0] == '0') && bfo3_chain_supported(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L);
+                    if (chain3 || (!x3 && bfo_chain_wanted(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B))) {
                         BfoChainParams cc;
                         std::memset(&cc, 0, sizeof(cc));
                         cc.x = src; cc.y = curo; cc.sum_in = curo;
@@ -503,7 +505,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                         if (multi && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));
                         const double fl = 3 * 2.0 * (2.0 * h->c1[li0].cin * h->c1[li0].cin * h->c1[li0].k) * mul;
                         if (in_section) prof_add(fl); else prof_begin(st, fl);
-                        rc = bfo_launch_chain(h->c1[li0].cin, cc, st);
+                        rc = x3 ? bfo3_launch_chain(h->c1[li0].cin, cc, st) : bfo_launch_chain(h->c1[li0].cin, cc, st);
                         if (!in_section) prof_end(st);
                         HG_TRY(rc);
                         if (multi) HG_CHECK_HIP(hipEventRecord(h->ev_done[j], st));

@@ -163,6 +163,21 @@ def resblock_pair3(x, w1p, b1, w2p, b2, k, dilation, lens=None, len_mul=1, sum_i
     return y
 
 
+def resblock_chain3(x, w1p, b1, w2p, b2, dilations, lens=None, len_mul=1, sum_in=None, mode=0, div=1.0, in_slope=0.1, mid_slope=0.1,
+                    out_slope=0.1, y=None):
+    """A whole k = 3 ResBlock (three pairs) in one launch of the split-bf16 engine; w1p / b1 / w2p / b2: lists of three device tensors."""
+    import ctypes
+    B, no, Ln, _ = x.shape
+    if y is None:
+        y = torch.zeros_like(x)
+    arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    dl = (ctypes.c_int32 * 3)(*[int(d) for d in dilations])
+    L.check(L.load().ttsamd_bfo3_resblock_chain(_ptr(x), arr(w1p), arr(b1), arr(w2p), arr(b2), dl, _ptr(sum_in), _ptr(lens), len_mul,
+                                                B, no * 8, Ln, mode, float(div), float(in_slope), float(mid_slope), float(out_slope),
+                                                _ptr(y), _stream()), 'bfo3_resblock_chain')
+    return y
+
+
 def conv_post3(x, w, bias, lens=None, len_mul=1):
     B, no, Ln, _ = x.shape
     wave = torch.zeros(B, Ln, dtype=torch.float32, device=x.device)

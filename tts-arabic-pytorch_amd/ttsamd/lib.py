@@ -102,6 +102,7 @@ SYMBOLS = {
     'ttsamd_bfo3_pack_weight': (_I32, [_P, _I32, _I32, _I32, _I32, _P]),
     'ttsamd_bfo3_conv1d': (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _P, _P, _P, _P]),
     'ttsamd_bfo3_resblock_pair': (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P, _P]),
+    'ttsamd_bfo3_resblock_chain': (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P, _P]),
     'ttsamd_bfo3_conv_post': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P]),
     'ttsamd_set_precision': (_I32, [_I32]),
     'ttsamd_get_precision': (_I32, []),
