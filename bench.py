@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py — audio samples/s of the FastPitch -> HiFi-GAN hot path on MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--tokens 64]

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """GPU idle time between kernels from a rocprofv3 --kernel-trace CSV.
 usage: python profiles/gaps.py <kernel_trace.csv> [min_gap_us]
 Prints busy/idle totals and the gaps above min_gap_us with the kernels on either side."""

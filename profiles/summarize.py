@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV by (kernel, grid): calls, total/avg duration.
 usage: python profiles/summarize.py <kernel_trace.csv> > profiles/<name>_by_grid.txt"""
 import csv

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """FETCH_SIZE / WRITE_SIZE calibration factors from two rocprofv3 --pmc passes of tools/bin/traffic_calib (every kernel
 moves exactly 1 GiB per launch): bytes actually moved per counted KB, per access pattern.
 usage: python profiles/traffic_calib.py <fetch_dir> <write_dir> > profiles/rN/traffic_calib.json"""

@@ -346,23 +346,6 @@ def test_split_k_small_batch(dev, synth_weights, monkeypatch):
     finally:
         set_precision('f32')
     assert torch.equal(mel_a, mel_a2) and torch.equal(wave_a, wave_a2)
-    # the split launches that feed a LayerNorm run it inside their reduction kernel (bfo_splitk_reduce_ln): same bits as the
-    # reduction followed by the LayerNorm launch, at batch 1 and on a ragged batch of 3
-    set_precision('bf16')
-    try:
-        ids3 = synth.synth_ids(3, 40)
-        ids3[1, 25:] = 0
-        dur3 = synth.synth_durations(3, 40) * (ids3 != 0)
-        got = {}
-        for flag in ('1', '0'):
-            monkeypatch.setenv('TTSAMD_BFO_SPLITK', '1')
-            monkeypatch.setenv('TTSAMD_BFO_FUSED_LN', flag)
-            got[flag] = (fp.infer(ids, dur_tgt=dur)[0], fp.infer(ids3, dur_tgt=dur3)[0])
-    finally:
-        set_precision('f32')
-        monkeypatch.delenv('TTSAMD_BFO_FUSED_LN', raising=False)
-    assert torch.equal(got['1'][0], got['0'][0]) and torch.equal(got['1'][1], got['0'][1])
-    assert torch.equal(got['1'][0], mel_a)
     e_ab, e_a = float((mel_a - mel_b).abs().max()), float((mel_a - mel32).abs().max())
     w_ab, w_a = float((wave_a - wave_b).abs().max()), float((wave_a - wave32).abs().max())
     print(f'split K vs un-split: mel {e_ab:.2e}, wave {w_ab:.2e}; vs fp32: mel {e_a:.2e}, wave {w_a:.2e}')

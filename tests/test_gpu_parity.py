@@ -169,7 +169,6 @@ def test_hifigan_ragged_fused_kernels_vs_oracle(dev, synth_weights, monkeypatch,
     from ttsamd.config import HIFIGAN_CONFIG
     from ttsamd.engine import HifiGanEngine, set_precision
     monkeypatch.setenv('TTSAMD_FUSED_PAIR', '1')
-    monkeypatch.setenv('TTSAMD_FUSED_PAIR_C64', '1')
     monkeypatch.setenv('TTSAMD_CONVT', '1')
     monkeypatch.setenv('TTSAMD_BFO', '1')
     w = O.fold_weight_norm(synth_weights['hifigan'])
@@ -225,7 +224,7 @@ def test_fastpitch_multispeaker_golden(dev, golden, synth_weights):
     assert maxabs(mel, g['mel']) < MEL_TOL
 
 
-def test_end_to_end_golden(dev, golden, fastpitch_engine, hifigan_engine):
+def test_end_to_end_golden_denoise_leg_torch_stft_standin(dev, golden, fastpitch_engine, hifigan_engine):
     """FastPitch2Wave.tts(list, batch_size=3, denoise=0) on three infer_text.txt lines."""
     e = golden('e2e_tts')
     t = golden('infer_text_ids')
@@ -381,7 +380,7 @@ def test_fastpitch_multispeaker_plus_vocos(dev, golden, synth_weights):
         assert maxabs(wave[b, :256 * n], ref) < WAVE_TOL
 
 
-def test_denoiser_strong_setting(dev, golden, hifigan_engine):
+def test_denoiser_strong_setting_torch_stft_standin_golden(dev, golden, hifigan_engine):
     """A large strength makes consecutive frames inconsistent, so every overlap-add term matters
     (a weak denoise is nearly the identity and hides frame-range bugs)."""
     import tts_oracle as O

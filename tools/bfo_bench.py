@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-layer timing of the bf16 octet engine at the bench workload's sizes (B = 32 utterances x 448 frames):
 algorithmic TFLOP/s against the 2.5 PFLOP/s bf16 MFMA peak and algorithmic GB/s against 8 TB/s HBM.
   python tools/bfo_bench.py [--iters 20] [--json out.json]"""

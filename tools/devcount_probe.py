@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Does counting the GPUs initialise the HIP runtime in this process?  (bench.py's launcher / supervisor parents must never hold a GPU
 context: they kill and restart their children.)  Prints the /dev/kfd and /dev/dri descriptors the process holds before and after
 torch.cuda.device_count(), torch.cuda.is_initialized(), and what bench._count_gpus() (sysfs, no runtime) says."""

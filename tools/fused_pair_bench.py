@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Stand-alone timing of the fused ResBlock1 pair kernels of the fp32 engine on the bench workload's shapes
 (B = 32 utterances x 64 tokens, forced durations: 14 341 frames; stage lengths = frames x 64 / 128 / 256 for C = 128 / 64 / 32).
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Table of hipcc -Rpass-analysis=kernel-resource-usage output (stderr file): kernel, VGPRs, AGPRs, SGPRs, spills, LDS, occupancy."""
 import re
 import sys

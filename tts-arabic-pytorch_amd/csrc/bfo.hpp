@@ -93,8 +93,7 @@ struct BfoConvParams {
     int32_t ksplit;        // set by the launcher
     int32_t compact;       // set by the launcher: ragged batch, blocks take the lin-th LIVE tile (common.hpp: live_tile)
     // y_f32 output only: LayerNorm over the channels of the result, in place, plus its bf16 octet copy for the next conv
-    // (transformer.py:88,158: conv + residual -> LayerNorm).  A split-K launch does it inside its reduction kernel
-    // (bfo_splitk_reduce_ln: one launch and one pass over the tensor fewer), otherwise layernorm_cf_octet_kernel follows.
+    // (transformer.py:88,158: conv + residual -> LayerNorm): layernorm_cf_octet_kernel follows the conv (and its split-K reduction).
     const float* ln_g;     // gamma (nullptr = no LayerNorm)
     const float* ln_b;
     void* ln_octet;        // [B][Cout/8][L][8] bf16

@@ -210,7 +210,8 @@ void bfo3_resblock_chain(const BfoChainParams p) {
 template <int C, int NT, int NW>
 static int32_t bfo3_launch_chain_cfg(const BfoChainParams& p, hipStream_t stream) {
     using G = Bfo3ChainGeo<C, NT, NW>;
-    TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo3_resblock_chain<C, NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+    static std::atomic<uint64_t> lds_done{0};
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo3_resblock_chain<C, NT, NW>, (int)G::LDS, lds_done));
     const int TS = G::NCOLS - 2 * G::H * (p.dil[0] + p.dil[1] + p.dil[2] + 3);
     dim3 grid((p.L + TS - 1) / TS, 1, p.batch);
     BfoChainParams q = p;

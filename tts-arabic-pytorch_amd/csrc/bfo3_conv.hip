@@ -167,8 +167,8 @@ template <int K, int WM, int WN, int NT, int SH, bool OUT_F32>
 static int32_t bfo3_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream) {
     BfoConvParams p = p_in;
     using G = Bfo3ConvGeo<K, WM, WN, NT, SH>;
-    TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo3_conv1d<K, WM, WN, NT, SH, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)G::LDS));
+    static std::atomic<uint64_t> lds_done{0};
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo3_conv1d<K, WM, WN, NT, SH, OUT_F32>, (int)G::LDS, lds_done));
     const int CoutP = (p.Cout + 31) & ~31;
     dim3 grid((p.Lin + G::NCOLS - 1) / G::NCOLS, (CoutP + 32 * WM - 1) / (32 * WM), p.batch);
     p.ksplit = 1;
@@ -325,7 +325,8 @@ static int32_t bfo3_launch_convt_cfg(const BfoConvParams& p, hipStream_t stream)
     constexpr int NQ = 32 * NQT;
     const size_t lds = (size_t)(p.Cin / 8) * (NQ + 2) * 32;
     TTS_REQUIRE(lds <= 80 * 1024, "bfo3 convt: window of %zu bytes does not fit (Cin=%d, u=%d)", lds, p.Cin, U);
-    TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo3_convt<U, RT, NQT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    static std::atomic<uint64_t> lds_done{0};
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo3_convt<U, RT, NQT, NT>, 80 * 1024, lds_done));
     dim3 grid((p.Lin + NQ - 1) / NQ, (p.Cout + 32 * RT - 1) / (32 * RT), p.batch);
     BfoConvParams q = p;
     q.compact = compact_order(p.lens, p.batch) ? 1 : 0;

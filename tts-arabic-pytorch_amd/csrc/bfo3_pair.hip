@@ -204,9 +204,8 @@ void bfo3_resblock_pair(const BfoPairParams p) {
 template <int K, int C, int NT, int NW, int DM>
 static int32_t bfo3_launch_pair_cfg(const BfoPairParams& p, hipStream_t stream) {
     using G = Bfo3PairGeo<K, C, NT, NW, DM>;
-    // idempotent and cheap: no per-device cache to race on (the opt-in is needed above 64 KB of dynamic LDS)
-    TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo3_resblock_pair<K, C, NT, NW, DM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)G::LDS));
+    static std::atomic<uint64_t> lds_done{0};
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo3_resblock_pair<K, C, NT, NW, DM>, (int)G::LDS, lds_done));
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
     BfoPairParams q = p;
     q.compact = compact_order(p.lens, p.batch) ? 1 : 0;

@@ -210,14 +210,8 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_chain(co
 template <int C, int NT, int K>
 static int32_t bfo_launch_chain_nt(const BfoChainParams& p, hipStream_t stream) {
     using G = BfoChainGeo<C, NT, K>;
-    static bool attr_set[16] = {};
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_resblock_chain<C, NT, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
-        attr_set[dev_id] = true;
-    }
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo_resblock_chain<C, NT, K>, (int)G::LDS, lds_done));
     const int TS = G::NCOLS - 2 * G::H * (p.dil[0] + p.dil[1] + p.dil[2] + 3);
     dim3 grid((p.L + TS - 1) / TS, 1, p.batch);
     BfoChainParams q = p;

@@ -231,118 +231,14 @@ __global__ __launch_bounds__(256) void bfo_splitk_reduce(const BfoConvParams p) 
     reinterpret_cast<uint4*>(p.y)[ent] = w;
 }
 
-// Split-K reduction + epilogue + LayerNorm in one launch (fp32 channel-first output): block = 32 positions x 8 channel groups as
-// layernorm_cf_octet_kernel, whose arithmetic it repeats on values summed exactly as bfo_splitk_reduce sums them -- the result
-// equals the two launches bit for bit.
-// CPG = channels per thread group = Cout / 8, a compile-time constant (a run-time bound on the unrolled loops puts every load
-// behind its own branch and its own vmcnt(0): 48 serial memory round trips)
 constexpr int LNO_MAXV_R = 64;
-template <int CPG>
-__global__ __launch_bounds__(256) void bfo_splitk_reduce_ln(const BfoConvParams p, float eps) {
-    __shared__ float red[8][32];
-    const int b = blockIdx.y;
-    const int tl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int S = p.Lin, C = p.Cout;
-    const int t = blockIdx.x * 32 + tl;
-    const bool ok = t < S;
-    const int tc = ok ? t : 0;
-    int len = S;
-    if (p.lens && !p.out_all) len = min(len, (int)p.lens[b] * p.len_mul);
-    constexpr int cpg = CPG; const int c0 = g * cpg;
-    const int64_t per = (int64_t)p.batch * C * S;
-    const float* __restrict__ rp = (p.res_f32 ? p.res_f32 : p.splitk_ws) + ((int64_t)b * C + c0) * S + tc;   // no residual: any readable address
-    const bool has_res = p.res_f32 != nullptr, has_bias = p.bias != nullptr;
-    const float* __restrict__ bp = (has_bias ? p.bias : p.ln_g) + c0;
-    float* __restrict__ yb = p.y_f32 + ((int64_t)b * C + c0) * S + tc;
-    const float* __restrict__ lg = p.ln_g + c0;
-    const float* __restrict__ lb = p.ln_b + c0;
-    float v[CPG];
-#pragma unroll
-    for (int i = 0; i < CPG; ++i) v[i] = 0.f;
-    const bool live = tc < len;                      // past the conv's outputs: what the separate LayerNorm launch would have read
-    // slice by slice, all of the thread's channels per slice in flight at once; per element the sum runs in slice order from 0
-    // exactly as in bfo_splitk_reduce
-    // buffer loads: one per-lane offset + a scalar offset per (slice, channel) -- flat loads need a 64-bit address per load in
-    // flight and the compiler then keeps only two in flight (48 x ksplit memory round trips in pairs)
-    {
-        const bfo_i4 prs = bfo_rsrc(p.splitk_ws, (unsigned)(per * p.ksplit * 4));
-        const int vb = (int)((((int64_t)b * C + c0) * S + tc) * 4);
-        for (int ks = 0; ks < p.ksplit; ++ks) {
-            const int sb = (int)(ks * per * 4);
-            float tq[CPG];
-#pragma unroll
-            for (int i = 0; i < CPG; ++i) tq[i] = bfo_ld4f(prs, vb, sb + i * S * 4, 0);   // unconditional; discarded below when !live
-            __builtin_amdgcn_sched_barrier(0);            // all of the slice's loads in flight (left alone: two at a time)
-#pragma unroll
-            for (int i = 0; i < CPG; ++i) v[i] += tq[i];
-        }
-    }
-    const int bmask = has_bias ? -1 : 0, rmask = has_res ? -1 : 0, lmask = live ? -1 : 0;
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPG; ++i) {
-        float x = 0.f;
-        if (i < cpg) {
-            // unconditional loads, selected with bit masks (a ?: lets the compiler sink each load into its own exec-masked branch)
-            const float bv = bp[i], rv = rp[(int64_t)i * S], old = yb[(int64_t)i * S];
-            const float a = v[i] + __builtin_bit_cast(float, __builtin_bit_cast(int, bv) & bmask);
-            const float yv = bfo_lrelu(a + __builtin_bit_cast(float, __builtin_bit_cast(int, rv) & rmask), p.out_slope);
-            x = __builtin_bit_cast(float, (__builtin_bit_cast(int, yv) & lmask) | (__builtin_bit_cast(int, old) & ~lmask));
-        }
-        v[i] = x;
-        sum += x;
-    }
-    red[g][tl] = sum;
-    __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tot += red[k][tl];
-    const float mean = tot / (float)C;
-    __syncthreads();
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPG; ++i) {
-        const float d = (i < cpg) ? v[i] - mean : 0.f;
-        sq = fmaf(d, d, sq);
-    }
-    red[g][tl] = sq;
-    __syncthreads();
-    tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tot += red[k][tl];
-    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
-    if (!ok) return;
-    float m = 1.f;
-    if (p.ln_lens && t >= (int)p.ln_lens[b]) m = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPG; ++i)
-        if (i < cpg) {
-            v[i] = ((v[i] - mean) * rstd * lg[i] + lb[i]) * m;
-            yb[(int64_t)i * S] = v[i];
-        }
-    uint4* yo = reinterpret_cast<uint4*>(p.ln_octet);
-#pragma unroll
-    for (int o = 0; o < CPG / 8; ++o)
-        if (8 * o < cpg) {
-            uint4 w;
-            w.x = (unsigned)bfo_pk(v[8 * o], v[8 * o + 1]); w.y = (unsigned)bfo_pk(v[8 * o + 2], v[8 * o + 3]);
-            w.z = (unsigned)bfo_pk(v[8 * o + 4], v[8 * o + 5]); w.w = (unsigned)bfo_pk(v[8 * o + 6], v[8 * o + 7]);
-            yo[((int64_t)b * (C / 8) + c0 / 8 + o) * S + t] = w;
-        }
-}
 
 template <int K, int WM, int WN, int NT, bool OUT_F32>
 static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream) {
     BfoConvParams p = p_in;
     using G = BfoConvGeo<K, WM, WN, NT>;
-    static bool attr_set[16] = {};
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_conv1d<K, WM, WN, NT, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
-        attr_set[dev_id] = true;
-    }
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo_conv1d<K, WM, WN, NT, OUT_F32>, (int)G::LDS, lds_done));
     const int CoutP = (p.Cout + 31) & ~31;
     dim3 grid((p.Lin + G::NCOLS - 1) / G::NCOLS, (CoutP + 32 * WM - 1) / (32 * WM), p.batch);
     // split K when the tile grid leaves most CUs without a block and the reduction depth allows it (batch 1 / 8)
@@ -352,12 +248,12 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream
     const int n_slabs = ((p.Cin + 15) / 16 + G::SH - 1) / G::SH;
     const int64_t per = (int64_t)p.batch * p.Cout * p.Lin;
     const char* ske = getenv("TTSAMD_BFO_SPLITK");              // 0 disables (A/B and parity runs)
-    const char* mse = getenv("TTSAMD_BFO_SPLITK_MIN_SLABS");
+    const char* mse = exp_env("TTSAMD_BFO_SPLITK_MIN_SLABS");
     const int min_slabs = mse ? atoi(mse) : 4;
-    const char* mbe = getenv("TTSAMD_BFO_SPLITK_BLOCKS");
+    const char* mbe = exp_env("TTSAMD_BFO_SPLITK_BLOCKS");
     const int max_blocks = mbe ? atoi(mbe) : 256;   // under one block per CU
     if (p.splitk_ws && blocks < max_blocks && n_slabs >= min_slabs && !(ske && ske[0] == '0')) {
-        const char* mk = getenv("TTSAMD_BFO_SPLITK_MAX");
+        const char* mk = exp_env("TTSAMD_BFO_SPLITK_MAX");
         int64_t ks = std::min<int64_t>((256 + blocks - 1) / blocks, n_slabs);
         ks = std::min<int64_t>(ks, mk ? atoi(mk) : 4);
         ks = std::min<int64_t>(ks, p.splitk_floats / std::max<int64_t>(per, 1));
@@ -369,26 +265,14 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream
     const bool ln = p.ln_g != nullptr;
     if (ln) TTS_REQUIRE(OUT_F32 && p.y_f32 && p.ln_b && p.ln_octet && p.Cout % 64 == 0 && p.Cout <= 8 * LNO_MAXV_R,
                         "bfo conv: the LayerNorm epilogue needs the fp32 output and Cout %% 64 == 0, <= %d (Cout=%d)", 8 * LNO_MAXV_R, p.Cout);
-    // TTSAMD_BFO_FUSED_LN=1: the reduction finishes with the LayerNorm (one launch less, same bits).  Default OFF since round 4: its 15-block grid at
-    // batch 1 (32 positions per block, ksplit x 48 loads per thread) is slower than the wide reduction + the LayerNorm launch it replaces
-    // (bf16 batch 1 2.40 -> 2.35 ms, batch 8 4.67 -> 4.65; the fp32 twin of this kernel measured 4.88 -> 5.25 ms and was not kept)
-    const char* fle = getenv("TTSAMD_BFO_FUSED_LN");
-    const bool fuse_ln = (fle && fle[0] == '1') && (p.Cout == 256 || p.Cout == 384 || p.Cout == 512) &&
-                         (int64_t)p.batch * p.Cout * p.Lin * 4 * 4 < ((int64_t)1 << 31);      // 32-bit buffer offsets over <= 4 slices
+    // (a reduction that finishes with the LayerNorm in the same launch -- one launch and one pass fewer, same bits -- was built and
+    // measured slower at the batch sizes that split K: bf16 batch 1 2.35 vs 2.40 ms, round 4; removed in round 5)
     if (p.ksplit > 1) {
-        if (ln && fuse_ln) {
-            dim3 rg((p.Lin + 31) / 32, p.batch);
-            if (p.Cout == 384) hipLaunchKernelGGL(bfo_splitk_reduce_ln<48>, rg, dim3(256), 0, stream, p, 1e-5f);
-            else if (p.Cout == 256) hipLaunchKernelGGL(bfo_splitk_reduce_ln<32>, rg, dim3(256), 0, stream, p, 1e-5f);
-            else if (p.Cout == 512) hipLaunchKernelGGL(bfo_splitk_reduce_ln<64>, rg, dim3(256), 0, stream, p, 1e-5f);
-            else { set_error("bfo conv: LayerNorm epilogue is built for 256 / 384 / 512 channels (Cout=%d)", p.Cout); return TTSAMD_EINVAL; }
-        } else {
-            dim3 rg((p.Lin + 255) / 256, p.Cout / 8, p.batch);
-            hipLaunchKernelGGL(bfo_splitk_reduce, rg, dim3(256), 0, stream, p);
-        }
+        dim3 rg((p.Lin + 255) / 256, p.Cout / 8, p.batch);
+        hipLaunchKernelGGL(bfo_splitk_reduce, rg, dim3(256), 0, stream, p);
         TTS_CHECK_HIP(hipGetLastError());
     }
-    if (ln && !(p.ksplit > 1 && fuse_ln)) {
+    if (ln) {
         return launch_layernorm_cf_octet(p.y_f32, p.y_f32, p.ln_octet, p.ln_g, p.ln_b, p.ln_lens, p.ln_lens != nullptr, p.batch, p.Cout,
                                          p.Lin, stream);
     }
@@ -402,7 +286,7 @@ static int32_t bfo_launch_conv_k(const BfoConvParams& p, hipStream_t stream) {
     const int64_t blocks8 = (int64_t)((p.Lin + 255) / 256) * ((p.Cout + 127) / 128) * p.batch;
     // (a grid of 256-column tiles under one block per CU -- FastPitch's 1536 -> 384 conv at batch 32 is 192 blocks -- takes the 64-column
     // tiles too: bf16 one-stream step 11.89 -> 11.57 ms, two-stream unchanged; round 3 had the threshold at 48 blocks)
-    static const int64_t narrow_blocks = [] { const char* e = getenv("TTSAMD_BFO_NARROW_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
+    static const int64_t narrow_blocks = [] { const char* e = exp_env("TTSAMD_BFO_NARROW_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
     const bool narrow = p.Cout >= 128 && (p.Lin <= 96 || blocks8 < narrow_blocks);
     if (p.y_f32) {
         if (narrow) return bfo_launch_conv_cfg<K, 4, 1, 2, true>(p, stream);
@@ -554,14 +438,8 @@ static int32_t bfo_launch_convt_cfg(const BfoConvParams& p, hipStream_t stream) 
     constexpr int NQ = 32 * NQT;
     const size_t lds = std::max((size_t)(p.Cin / 8) * (NQ + 2) * 16, (size_t)4 * RT * NQ * (U + 1) * 16);
     TTS_REQUIRE(lds <= 80 * 1024, "bfo convt: window of %zu bytes does not fit (Cin=%d, u=%d)", lds, p.Cin, U);
-    static size_t attr_lds[16] = {};
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (attr_lds[dev_id] < lds) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_convt<U, RT, NQT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_lds[dev_id] = 80 * 1024;
-    }
+    static std::atomic<uint64_t> lds_done{0};
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo_convt<U, RT, NQT, NT>, 80 * 1024, lds_done));
     dim3 grid((p.Lin + NQ - 1) / NQ, (p.Cout + 32 * RT - 1) / (32 * RT), p.batch);
     BfoConvParams q = p;
     q.compact = compact_order(p.lens, p.batch) ? 1 : 0;

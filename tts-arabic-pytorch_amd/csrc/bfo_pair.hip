@@ -222,14 +222,8 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
 template <int K, int C, int NT>
 static int32_t bfo_launch_pair_nt(const BfoPairParams& p, hipStream_t stream) {
     using G = BfoPairGeo<K, C, NT>;
-    static bool attr_set[16] = {};
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)bfo_resblock_pair<K, C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
-        attr_set[dev_id] = true;
-    }
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
+    TTS_CHECK_HIP(lds_opt_in((const void*)bfo_resblock_pair<K, C, NT>, (int)G::LDS, lds_done));
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
     BfoPairParams q = p;
     q.compact = compact_order(p.lens, p.batch) ? 1 : 0;

@@ -2,8 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/ttsamd.h"
@@ -37,6 +39,31 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Switches of CLOSED experiments (tile orders, split-K thresholds, block-count sweeps: profiles/r2..r4) are read only by a library
+// built with `make EXTRA=-DTTS_EXPERIMENT` (tools/ A/B scripts); the product library ignores them and runs the measured defaults.
+// What stays a run-time switch routes between kernels that BOTH ship and is listed in INTEGRATION.md.
+inline const char* exp_env(const char* name) {
+#ifdef TTS_EXPERIMENT
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device).  `done` is the instantiation's bitmask of
+// devices already opted in; two host threads racing on a first launch both set the attribute (idempotent), devices >= 64 set it on
+// every launch.  (Rounds 2-4 kept an unsynchronised bool[16] indexed by device & 15: a data race, and device 16 aliased device 0.)
+inline hipError_t lds_opt_in(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+}
 
 // Bump allocator over the caller-provided workspace (no hidden hipMalloc on hot calls).
 struct Arena {

@@ -655,15 +655,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 
 template <int K, int MT, int NTL, int WM, int WN, int EPI>
 static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
     const auto kern = conv1d_mfma_f32<K, MT, NTL, WM, WN, EPI>;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev_id] = true;
-    }
+    TTS_CHECK_HIP(lds_opt_in((const void*)kern, (int)lds, lds_done));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
@@ -680,12 +674,12 @@ static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_
 // (time tile, co tile, utterance) grid.
 bool compact_order(const void* lens, int batch) {
     if (lens == nullptr || batch <= 1) return false;
-    const char* e = getenv("TTSAMD_COMPACT");                  // read per call (a dozen ns next to a launch): tests and A/B runs flip it
+    const char* e = exp_env("TTSAMD_COMPACT");                  // read per call (a dozen ns next to a launch): tests and A/B runs flip it
     return !(e && e[0] == '0');
 }
 
 bool tile_major_order(const ConvParams& p, unsigned n_tiles) {
-    static const int force = [] { const char* e = getenv("TTSAMD_TILE_MAJOR"); return e ? atoi(e) : 0; }();
+    static const int force = [] { const char* e = exp_env("TTSAMD_TILE_MAJOR"); return e ? atoi(e) : 0; }();
     return force != 0 && p.lens_out != nullptr && p.batch > 1 && n_tiles <= 65535;
 }
 
@@ -729,9 +723,9 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     }
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z, per = (int64_t)p.batch * p.Cout * p.Nout;
     const int n_chunks = p.Cin / G::KC;
-    static const int sk_blocks = [] { const char* e = getenv("TTSAMD_SPLITK_BLOCKS"); return e ? atoi(e) : 320; }();
-    static const int sk_target = [] { const char* e = getenv("TTSAMD_SPLITK_TARGET"); return e ? atoi(e) : 640; }();
-    static const int sk_chunks = [] { const char* e = getenv("TTSAMD_SPLITK_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
+    static const int sk_blocks = [] { const char* e = exp_env("TTSAMD_SPLITK_BLOCKS"); return e ? atoi(e) : 320; }();
+    static const int sk_target = [] { const char* e = exp_env("TTSAMD_SPLITK_TARGET"); return e ? atoi(e) : 640; }();
+    static const int sk_chunks = [] { const char* e = exp_env("TTSAMD_SPLITK_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
     if (p.splitk_ws && p.n_phase == 1 && p.y_ts == 1 && nblk < sk_blocks && n_chunks >= sk_chunks) {
         int64_t ks = std::min<int64_t>((sk_target + nblk - 1) / nblk, n_chunks / 4);
         ks = std::min<int64_t>(ks, p.splitk_floats / per);
@@ -780,7 +774,7 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
     auto blocks = [&](int co_blk, int nt_blk) -> int64_t {
         return (int64_t)((p.Nout + nt_blk - 1) / nt_blk) * (p.CoutP / co_blk) * p.n_phase * p.batch;
     };
-    static const int64_t want_env = [] { const char* e = getenv("TTSAMD_WANT_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)-1; }();
+    static const int64_t want_env = [] { const char* e = exp_env("TTSAMD_WANT_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)-1; }();
     // blocks a launch should have: 3 per CU -- unless the whole problem is about one round of the smallest tiles (batch 1: 914 tiles
     // of 64 x 64 for a stage-2 conv): then one block per CU of a LARGE tile (64 x 256: 230 blocks at 0.85 of the matrix peak) beats
     // four of the small one (0.62): batch 1 5.04 -> 4.86 ms per call, measured with TTSAMD_WANT_BLOCKS=200 / 768
@@ -848,7 +842,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(!p.x_packed && !p.y_packed, "conv: packed bf16 activations exist only in the bf16 mode");
 #ifdef TTS_WITH_DIRECT   /* tools/conv_bench.hip only: A/B against tools/conv_direct_f32.hip (round 3, no gain: DESIGN.md §4) */
     {
-        const char* de = getenv("TTSAMD_DIRECT");
+        const char* de = exp_env("TTSAMD_DIRECT");
         if (de && de[0] == '1' && direct_supported(p)) return launch_direct(p, stream);   // opt in: the tool's default is the product kernel
     }
 #endif

@@ -529,15 +529,8 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_mfma_bf16(const Conv
 
 template <int K, int MT, int NTL, int WM, int WN, int NPL, int EPI, bool ACT>
 static int32_t launch_act_bf16(const ConvParams& p, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_set[16] = {};          // per device: a process may hold handles on several GPUs
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, EPI, ACT>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev_id] = true;
-    }
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
+    TTS_CHECK_HIP(lds_opt_in((const void*)conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, EPI, ACT>, (int)lds, lds_done));
     hipLaunchKernelGGL((conv1d_mfma_bf16<K, MT, NTL, WM, WN, NPL, EPI, ACT>), grid, dim3(256), lds, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;

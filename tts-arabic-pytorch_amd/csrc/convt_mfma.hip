@@ -197,16 +197,9 @@ __global__ __launch_bounds__(256, 2) void convt_mfma_f32(const ConvParams p) {
 template <int U, int MT, int NTL, int WM>
 static int32_t launch_convt_cfg(const ConvParams& p, hipStream_t stream) {
     using G = ConvtGeo<U, MT, NTL, WM>;
-    static bool attr_set[16] = {};
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
     const size_t lds = (size_t)2 * G::STG4 * sizeof(float4);
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)convt_mfma_f32<U, MT, NTL, WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds));
-        attr_set[dev_id] = true;
-    }
+    TTS_CHECK_HIP(lds_opt_in((const void*)convt_mfma_f32<U, MT, NTL, WM>, (int)lds, lds_done));
     dim3 grid((p.Nout + G::NT_BLK - 1) / G::NT_BLK, p.CoutP / G::CO_BLK, p.batch);
     ConvParams q = p;
     q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
@@ -221,7 +214,7 @@ bool convt_supported(const ConvParams& p) {
     const bool u_ok = (p.n_phase == 8 || p.n_phase == 2) && p.phase_p * 2 == p.n_phase;
     // a grid that leaves most CUs without a block (batch 1: 32 blocks for the first upsampler) does
     // better on the polyphase launch of the generic engine, which has one block per (phase, co tile) and splits K
-    static const int min_blocks = [] { const char* e = std::getenv("TTSAMD_CONVT_MIN_BLOCKS"); return e ? atoi(e) : 100; }();
+    static const int min_blocks = [] { const char* e = exp_env("TTSAMD_CONVT_MIN_BLOCKS"); return e ? atoi(e) : 100; }();
     if (u_ok && p.n_phase == 8 && (int64_t)((p.Nout + 63) / 64) * (p.CoutP / 64) * p.batch < min_blocks) return false;
     return p.precision == 0 && u_ok && p.K == 2 && p.dil == -1 && p.y_ts == p.n_phase && p.res == nullptr && p.mode == 0 &&
            p.scale == nullptr && p.relu_out == 0 && p.Cin % 8 == 0 && !p.x_packed && !p.y_packed &&

@@ -71,24 +71,49 @@ static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
 // which block width: 0 = not this pair, 2 = 256-column blocks, 1 = 128-column blocks.  Bit 3 * ci + ki of the masks, ci = 0 / 1 / 2
 // for C = 32 / 64 / 128, ki = 0 / 1 / 2 for k = 3 / 7 / 11.  TTSAMD_FUSED2=0 turns the kernel off, TTSAMD_FUSED2_MASK / _MASK_N1 (hex)
 // replace the defaults (A/B runs and the forced-kernel parity tests); all read per call.
-static int fused2_choice(int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y, int64_t columns) {
+// The routing switches are read ONCE per forward call (snapshot below) and handed down: a forward used to make several hundred
+// getenv calls, each a window for a concurrent setenv from another host thread (os.environ writes in Python do exactly that).
+struct Fused2Switches {
+    bool on = true, mask_forced = false, small_on = false;
+    unsigned mask = kFused2Mask, mask_n1 = kFused2MaskN1;
+};
+static bool parse_hex_mask(const char* txt, unsigned& out) {
+    if (!txt || !*txt) return false;
+    char* end = nullptr;
+    const unsigned long v = std::strtoul(txt, &end, 16);
+    if (end == txt || *end != '\0' || v > 0x1ff) return false;
+    out = (unsigned)v;
+    return true;
+}
+static int32_t read_fused2_switches(Fused2Switches& sw) {
     const char* e = std::getenv("TTSAMD_FUSED2");
-    if (e && e[0] == '0') return 0;
+    sw.on = !(e && e[0] == '0');
+    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK")) {
+        TTS_REQUIRE(parse_hex_mask(m, sw.mask), "TTSAMD_FUSED2_MASK='%s' is not a hex mask of 9 bits (bit 3 * ci + ki; 1ff = every pair)", m);
+        sw.mask_forced = true;
+    }
+    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK_N1"))
+        TTS_REQUIRE(parse_hex_mask(m, sw.mask_n1), "TTSAMD_FUSED2_MASK_N1='%s' is not a hex mask of 9 bits", m);
+    const char* se = exp_env("TTSAMD_FUSED2_SMALL");
+    sw.small_on = se && se[0] == '1';
+    return 0;
+}
+
+static int fused2_choice(const Fused2Switches& sw, int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y,
+                         int64_t columns) {
+    if (!sw.on) return 0;
     const int ci = channels == 32 ? 0 : (channels == 64 ? 1 : (channels == 128 ? 2 : -1));
     const int ki = k == 3 ? 0 : (k == 7 ? 1 : (k == 11 ? 2 : -1));
     if (ci < 0 || ki < 0) return 0;
-    unsigned mask = kFused2Mask, mask_n1 = kFused2MaskN1;
-    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK")) mask = (unsigned)std::strtoul(m, nullptr, 16);
-    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK_N1")) mask_n1 = (unsigned)std::strtoul(m, nullptr, 16);
+    unsigned mask = sw.mask, mask_n1 = sw.mask_n1;
     const unsigned bit = 1u << (3 * ci + ki);
     // small problems (batch 1 ... 4: under two rounds of 256-column blocks).  Measured (tools/f2_small.sh): every pair as ONE launch of
     // 128-column blocks -- half the launches of the un-fused engine -- is SLOWER there (batch 1: 5.27 vs 5.04 ms per step, batch 4: 13.35
     // vs 12.88; batch 8 equal): the un-fused engine's 64 x 64 tiles with split K put 3-4x more blocks on the chip.  So small problems
-    // keep the un-fused engine; TTSAMD_FUSED2_SMALL=1 routes them through the fused kernel for A/B runs.
-    const char* se = std::getenv("TTSAMD_FUSED2_SMALL");
-    const bool small = columns < (int64_t)kFused2SmallColumns && !std::getenv("TTSAMD_FUSED2_MASK");
+    // keep the un-fused engine (a forced TTSAMD_FUSED2_MASK overrides the rule: parity tests of the fused kernels on small inputs).
+    const bool small = columns < (int64_t)kFused2SmallColumns && !sw.mask_forced;
     if (small) {
-        if (!(se && se[0] == '1')) return 0;
+        if (!sw.small_on) return 0;
         mask = 0x1ff; mask_n1 = 0x1ff;
     }
     if (!(mask & bit)) return 0;
@@ -402,6 +427,8 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     // (ConvParams::y_packed / x_packed; same rounding point as the fp32 buffer + round-on-load, bit-identical)
     const char* pk_env = std::getenv("TTSAMD_BF16_PACKED_T");
     const bool pack_t = default_precision() == 1 && !(pk_env && pk_env[0] == '0');
+    Fused2Switches f2sw;
+    TTS_TRY(read_fused2_switches(f2sw));
     const char* fz_env = std::getenv("TTSAMD_FUSED_PAIR");
     const bool fused_ok = default_precision() == 0 && !(fz_env && fz_env[0] == '0');
     const char* ct_env = std::getenv("TTSAMD_CONVT");
@@ -444,6 +471,8 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         const auto l_convt = x3 ? bfo3_launch_convt : bfo_launch_convt;
         const auto l_pair = x3 ? bfo3_launch_pair : bfo_launch_pair;
         const auto pair_ok = x3 ? bfo3_pair_supported : bfo_pair_supported;
+        const char* c3e = std::getenv("TTSAMD_BFO_CHAIN");      // 0: three pair launches per k = 3 ResBlock (bit-identical; A/B and parity runs)
+        const bool chain3_on = !(c3e && c3e[0] == '0');
         void *curo = cur, *upso = ups_out;                 // the fp32-sized buffers hold bf16 / x3 tensors of the same element count
         HG_TRY((x3 ? bfo3_launch_pack : bfo_launch_pack)(mel, B, cfg.num_mels, T, 1.f, mel_o, s));
         BfoConvParams cp;
@@ -487,8 +516,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     const int li0 = (i * cfg.n_kernels + j) * cfg.n_dilations;
                     int32_t dl[3] = {0, 0, 0};
                     for (int m = 0; m < cfg.n_dilations && m < 3; ++m) dl[m] = cfg.resblock_dilations[j][m];
-                    const char* c3e = std::getenv("TTSAMD_BFO_CHAIN");      // 0: three pair launches (bit-identical; A/B and parity runs)
-                    const bool chain3 = x3 && !(c3e && c3e[0] == '0') && bfo3_chain_supported(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L);
+                    const bool chain3 = x3 && chain3_on && bfo3_chain_supported(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L);
                     if (chain3 || (!x3 && bfo_chain_wanted(h->c1[li0].cin, h->c1[li0].k, dl, cfg.n_dilations, L, B))) {
                         BfoChainParams cc;
                         std::memset(&cc, 0, sizeof(cc));
@@ -612,7 +640,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                     float* dst = last ? cur : (src == R ? Tb : R);
                     const ConvW &w1 = h->c1[li], &w2 = h->c2[li];
                     const bool square = w1.cin == w1.cout && w2.cin == w1.cin && w2.cout == w1.cin && w1.k == w2.k;
-                    const int ntw2 = (fused_ok && square) ? fused2_choice(w1.cin, w1.k, d, L, src, dst, (int64_t)B * L) : 0;
+                    const int ntw2 = (fused_ok && square) ? fused2_choice(f2sw, w1.cin, w1.k, d, L, src, dst, (int64_t)B * L) : 0;
                     if (ntw2 != 0 || (fused_ok && square && fused_pair_supported(w1.cin, w1.k, d, L, src, dst))) {
                         const int mode = !last ? 0 : (cfg.n_kernels == 1 ? 0 : (j == 0 ? 0 : (j + 1 < cfg.n_kernels ? 1 : 2)));
                         if (multi && last && j > 0) HG_CHECK_HIP(hipStreamWaitEvent(st, h->ev_done[j - 1], 0));

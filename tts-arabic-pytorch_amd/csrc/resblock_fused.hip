@@ -326,15 +326,9 @@ __global__ __launch_bounds__(256, 2) void resblock_pair(const FusedPairParams p)
 template <int K, int C>
 static int32_t launch_fused_k(const FusedPairParams& p, hipStream_t stream) {
     using G = FusedGeo<K, C>;
-    static bool attr_set[16] = {};
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
     const size_t lds = (size_t)G::LDS4 * sizeof(float4);
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_pair<K, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev_id] = true;
-    }
+    TTS_CHECK_HIP(lds_opt_in((const void*)resblock_pair<K, C>, (int)lds, lds_done));
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
     hipLaunchKernelGGL((resblock_pair<K, C>), grid, dim3(256), lds, stream, p);
     TTS_CHECK_HIP(hipGetLastError());
@@ -343,7 +337,7 @@ static int32_t launch_fused_k(const FusedPairParams& p, hipStream_t stream) {
 
 // true if the fused kernel covers this pair (C = 32: k = 3 / 7 / 11; C = 64: k = 3, the one that wins there; fp32, aligned rows)
 bool fused_pair_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y) {
-    const char* e64 = getenv("TTSAMD_FUSED_PAIR_C64");         // read per call: the tests and A/B runs flip it
+    const char* e64 = exp_env("TTSAMD_FUSED_PAIR_C64");         // read per call: the tests and A/B runs flip it
     const bool c64 = !(e64 && e64[0] == '0');
     const bool geo = (channels == 32 && (k == 3 || k == 7 || k == 11)) || (channels == 64 && k == 3 && c64);
     return geo && dil >= 1 && dil <= DMAX && (L & 3) == 0 &&

@@ -340,15 +340,8 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 template <int K, int C, int NTW>
 static int32_t launch_fused2_k(const FusedPair2Params& p, hipStream_t stream) {
     using G = Fused2Geo<K, C, NTW>;
-    static bool attr_set[16] = {};
-    int dev_id = 0;
-    TTS_CHECK_HIP(hipGetDevice(&dev_id));
-    dev_id &= 15;
-    if (!attr_set[dev_id]) {
-        TTS_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_pair2<K, C, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)G::lds_bytes(DMAX)));
-        attr_set[dev_id] = true;
-    }
+    static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
+    TTS_CHECK_HIP(lds_opt_in((const void*)resblock_pair2<K, C, NTW>, (int)G::lds_bytes(DMAX), lds_done));
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
     hipLaunchKernelGGL((resblock_pair2<K, C, NTW>), grid, dim3(256), G::lds_bytes(p.dil), stream, p);
     TTS_CHECK_HIP(hipGetLastError());
@@ -380,7 +373,7 @@ int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const flo
     p.mode = mode; p.div = div; p.slope = slope;
     p.compact = compact_order(lens, batch) ? 1 : 0;
 #ifdef TTS_F2_EXP
-    if (const char* e = getenv("TTSAMD_F2_EXP")) p.exp = atoi(e);
+    if (const char* e = exp_env("TTSAMD_F2_EXP")) p.exp = atoi(e);
 #endif
 #define TTS_F2(KK, CC, NN) if (k == KK && channels == CC && ntw == NN) return launch_fused2_k<KK, CC, NN>(p, stream);
     TTS_F2(3, 32, 2) TTS_F2(7, 32, 2) TTS_F2(11, 32, 2)

@@ -1848,7 +1848,9 @@ struct TWs {
     float* pstate;              // persistent decoder: per-thread state carried from one segment's launch to the next
 };
 
-// steps per launch of the persistent decoder = regions of its exchange arena (TTSAMD_TACO_SEG: tests drive several segments on short runs)
+// steps per launch of the persistent decoder = regions of its exchange arena (TTSAMD_TACO_SEG: tests drive several segments on short runs).
+// Read by workspace_bytes and by infer alike; a value that grows between the two calls is caught by infer's own carve of the arena it was
+// given ("workspace of N bytes needed"), never written past.
 static int taco_segment_steps() {
     const char* e = getenv("TTSAMD_TACO_SEG");
     const int v = e ? atoi(e) : 512;
@@ -1982,7 +1984,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
     TTS_CHECK_HIP(hipMemsetAsync(w.dec_in, 0, (size_t)B * c.n_mels * sizeof(float), s));
     TTS_CHECK_HIP(hipMemsetAsync(mel_lens, 0, (size_t)B * sizeof(int32_t), s));
     TTS_CHECK_HIP(hipMemsetAsync(w.step, 0, sizeof(int32_t), s));
-    static const bool dbg = getenv("TTSAMD_TACO_DEBUG") != nullptr;
+    static const bool dbg = exp_env("TTSAMD_TACO_DEBUG") != nullptr;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     int steps = 0;
     bool done = false;
@@ -2071,7 +2073,9 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
                 TTS_CHECK_HIP(hipMemcpyAsync(&tail[0], w.xch + w.tail_o + 256, sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 TTS_CHECK_HIP(hipMemcpyAsync(&tail[1], w.xch + w.tail_o + 320, sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 TTS_CHECK_HIP(hipStreamSynchronize(s));
-                if (tail[0] != 0 || tail[1] < q.s1) break;              // a time-out, or every utterance's gate fired inside this segment
+                // a time-out, or every utterance's gate fired inside this segment -- also on its LAST step (the kernel then reports exactly s1;
+                // an unfinished segment reports max_step): no extra segment (a region copy, an 82 MB memset and a cooperative launch for nothing)
+                if (tail[0] != 0 || (int64_t)tail[1] <= (int64_t)q.s1) break;
             }
             if (dbg) fprintf(stderr, "[taco] persistent decoder: %.0f us for %d steps (%zu B of LDS per block)\n", now_us() - t0, (int)tail[1], lds);
             if (tail[0] != 0) {
@@ -2093,7 +2097,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
                 done = true;
                 h->persist_backoff = 0;
             }
-            if (const char* dump = done ? getenv("TTSAMD_TACO_DUMP") : nullptr) {   // debugging aid: the region the last step produced
+            if (const char* dump = done ? exp_env("TTSAMD_TACO_DUMP") : nullptr) {   // debugging aid: the region the last step produced
                 std::vector<float> hx((size_t)w.step_floats);
                 TTS_CHECK_HIP(hipMemcpy(hx.data(), w.xch + (int64_t)(steps - (steps > 0 ? (steps - 1) / w.seg * w.seg : 0)) * w.step_floats, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
                 if (FILE* f = fopen(dump, "wb")) {

@@ -55,7 +55,13 @@ class _Grow:
 
 
 class Dp:
-    """One per process.  `device`: this rank's GPU (or cpu in the gloo tests)."""
+    """One per process.  `device`: this rank's GPU (or cpu in the gloo tests).
+
+    Ordering contract of the two channels (lengths / audio): every rank must issue the operations of ONE channel in the same HOST
+    order -- the length all-gather of batch i + 1 and the audio fan-in of batch i may interleave freely across the two channels (they
+    may run from two streams, and both RCCL kernels can be resident at once), but two calls on the same channel from different host
+    threads of a rank, or in different orders on different ranks, deadlock the blocking collectives.  One thread per rank drives a Dp
+    (ttsamd.pipeline.submit does); `close()` releases both communicators / the second process group."""
 
     def __init__(self, device, transport=None):
         assert dist.is_initialized(), 'init torch.distributed first (it carries the rendezvous)'
@@ -111,6 +117,11 @@ class Dp:
             if comm is not None:
                 self._lib.ttsamd_dp_destroy(comm)
                 setattr(self, name, None)
+        group = getattr(self, 'group_audio', None)
+        if group is not None:                                 # torch transport: the second channel is a process group of its own
+            self.group_audio = None
+            if dist.is_initialized():
+                dist.destroy_process_group(group)
 
     def __del__(self):
         try:

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libttsamd.so')
+# TTSAMD_LIB: another build of the SAME sources (tools/f2_exp.sh: a timing build in /tmp); the product path never sets it
+LIB_PATH = os.environ.get('TTSAMD_LIB') or os.path.join(_HERE, 'lib', 'libttsamd.so')
 
 
 class TtsAmdError(RuntimeError):

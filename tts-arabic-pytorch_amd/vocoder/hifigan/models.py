@@ -24,12 +24,9 @@ class _HipModule(nn.Module):
     def device(self):
         return self._anchor.device
 
-    def _apply(self, fn, *a, **k):
-        # Device handles survive `.cpu()` / `.to(other)`: the reference's server moves each model to the GPU
-        # and back on every request (utils/app_utils.py:65,81) to share a small card; with 288 GB of HBM the
-        # packed weights (< 1 GB for every model of this repo together) simply stay resident, so the next
-        # `.to('cuda')` costs nothing.  `release_device_memory()` frees them explicitly.
-        return super()._apply(fn, *a, **k)
+    # Device handles survive `.cpu()` / `.to(other)`: the reference's server moves each model to the GPU and back on every request
+    # (utils/app_utils.py:65,81) to share a small card; with 288 GB of HBM the packed weights (< 1 GB for every model of this repo
+    # together) simply stay resident, so the next `.to('cuda')` costs nothing.  `release_device_memory()` frees them explicitly.
 
     def release_device_memory(self):
         """Destroy the C-ABI handles (device copies of the packed weights) of every device."""
