@@ -107,7 +107,7 @@ typedef struct ttsamd_tagger_cfg {
 const char* ttsamd_last_error(void);
 /* ABI revision of this header.  Bumped whenever a struct gains a field or an argument changes meaning (2: ttsamd_tacotron2_cfg
  * gained decoder_early_stopping, ttsamd_profile_read's third value became the number of timed sections; 3: ttsamd_dp_* may be
- * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument; 5: the ttsamd_bfo3_* entries).  ttsamd_version() returns the value the library was BUILT with: a caller
+ * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument; 5: the ttsamd_bfo3_* entries, ttsamd_conv1d_ex).  ttsamd_version() returns the value the library was BUILT with: a caller
  * compiled against another revision must refuse to run (ttsamd/lib.py does). */
 #define TTSAMD_ABI_VERSION 5
 int32_t ttsamd_version(void);
@@ -252,6 +252,12 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
                       int32_t batch, int32_t cin, int32_t cout, int32_t k, int32_t dilation,
                       int32_t lin, float in_slope, int32_t relu_out, float* y, float* packed,
                       void* stream);
+/* the same with the rest of the conv engine's epilogue: y = act(conv + bias + res) | y + ... | (y + ...) / div  (mode 0 | 1 | 2); res
+ * [B][Cout][lin] or NULL.  Drives the residual-preload epilogues of the direct and the Winograd F(2,3) kernel (csrc/conv_wino.hip:
+ * k = 3, dilation 1 launches of at least one 128 x 128 tile per CU; TTSAMD_WINO=0 keeps the direct kernel) in the parity tests. */
+int32_t ttsamd_conv1d_ex(const float* x, const float* w, const float* bias, const float* res, const int64_t* lens, int32_t batch,
+                         int32_t cin, int32_t cout, int32_t k, int32_t dilation, int32_t lin, float in_slope,
+                         int32_t relu_out, int32_t mode, float div, float* y, float* packed, void* stream);
 
 /* One c1 -> c2 pair of a ResBlock1 (vocoder/hifigan/models.py:46-53) in exact fp32, intermediate in LDS:
  *   v = x + conv1d(lrelu(conv1d(lrelu(x, slope), w1, dilation dil) + b1, slope), w2) + b2;  y = v | y + v | (y + v) / div  (mode 0 | 1 | 2)

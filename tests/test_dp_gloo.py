@@ -126,6 +126,75 @@ def test_dp_world2_gloo(tmp_path):
     assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')
 
 
+def _worker_many(rank, world, port, tmpdir, n_utts):
+    """world 4 / 8: uneven shards, ranks with ZERO utterances, the two-channel schedule (the next batch's length exchange issued
+    between a batch's length exchange and its audio fan-in), sharded tts == 1-rank result bit for bit."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), 'tts-arabic-pytorch_amd'))
+    from ttsamd import dp
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dpx = dp.Dp(torch.device('cpu'))
+        spans = [dp.shard_bounds(n_utts, world, r) for r in range(world)]
+        lo, hi = spans[rank]
+        b_cap = max(h - l for l, h in spans)
+        assert min(h - l for l, h in spans) == 0 or n_utts >= world          # the world-8 case has empty ranks
+        for step in range(3):                                                 # three batches in flight order: lens(i+1) before audio(i)
+            def batch(i):
+                lens = torch.tensor([(g + 1) * 7 + i for g in range(lo, hi)], dtype=torch.int64)
+                wave = torch.zeros(hi - lo, (int(lens.max()) if hi > lo else 0) + 2)
+                for k, g in enumerate(range(lo, hi)):
+                    wave[k, :lens[k]] = 100 * i + g + 1
+                return lens, wave
+            lens, wave = batch(step)
+            all_lens = dpx.exchange_lens(lens, b_cap=b_cap)
+            assert tuple(all_lens.shape) == (world, b_cap + 1)
+            for r, (l, h) in enumerate(spans):
+                assert int(all_lens[r, 0]) == h - l
+                assert all_lens[r, 1:1 + h - l].tolist() == [(g + 1) * 7 + step for g in range(l, h)]
+                assert all(int(v) == 0 for v in all_lens[r, 1 + h - l:])
+            nxt_lens, _ = batch(step + 1)
+            nxt = dpx.exchange_lens(nxt_lens, b_cap=b_cap)                    # channel 1 again, BEFORE this batch's fan-in on channel 2
+            out = dpx.gather_audio(wave, lens, all_lens=all_lens)
+            assert nxt[:, 0].tolist() == [h - l for l, h in spans]
+            if rank == 0:
+                assert len(out) == n_utts
+                for g, w in enumerate(out):
+                    assert w.shape == ((g + 1) * 7 + step,) and bool((w == 100 * step + g + 1).all())
+            else:
+                assert out is None
+        texts = ['x' * n for n in (5, 9, 3, 7, 1, 12, 2, 4, 4, 11, 6, 8, 10)][:n_utts + 3]
+        for model in (_Stub(), _StubDevice()):
+            for bs in (2, 5):
+                res = dp.tts_sharded(model, texts, batch_size=bs, dp=dpx)
+                if rank == 0:
+                    assert all(torch.equal(a, b) for a, b in zip(res, _Stub().tts(texts))) and len(res) == len(texts)
+                else:
+                    assert res is None
+        dpx.close()
+        assert dpx.group_audio is None                                        # the second process group is released
+        with open(os.path.join(tmpdir, f'ok{rank}'), 'w') as f:
+            f.write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world4_uneven_shards_gloo(tmp_path):
+    """10 utterances over 4 ranks: shards of 3 / 3 / 2 / 2."""
+    mp.spawn(_worker_many, args=(4, _free_port(), str(tmp_path), 10), nprocs=4, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(4))
+
+
+def test_dp_world8_ranks_without_utterances_gloo(tmp_path):
+    """5 utterances over 8 ranks (the last batch of a list on an 8-GPU node): ranks 5..7 hold nothing and still take part in both
+    exchanges of the two-channel schedule."""
+    mp.spawn(_worker_many, args=(8, _free_port(), str(tmp_path), 5), nprocs=8, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(8))
+
+
 def test_shard_bounds_cover():
     from ttsamd import dp
     for n in (0, 1, 7, 32, 256, 257):

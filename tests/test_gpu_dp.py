@@ -189,6 +189,23 @@ def test_bench_two_ranks_one_device():
     assert 'ONE device' in out['config']['parallelism']
 
 
+def test_bench_config3_command_line_eight_ranks_one_device():
+    """BASELINE config 3 as the driver will type it on an 8-GPU node -- `bench.py --gpus 8 --scaling strong --batch 256 --precision
+    bf16` -- end to end on the one-device fallback (eight ranks share this GPU over gloo + host staging): 256 utterances dealt
+    32 per rank, the two-channel exchange at world 8, ONE json line whose n_gpus / scaling / global batch are the configuration's.
+    A functional check of the launch path, not a scaling number (the line says so)."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--scaling', 'strong', '--batch', '256',
+                        '--precision', 'bf16', '--steps', '1', '--warmup', '1', '--tokens', '16', '--no-cpu-baseline'],
+                       capture_output=True, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['value'] > 0 and out['scaling'] == 'strong' and out['dtype'] == 'bf16'
+    assert out['config']['global_batch'] == 256 and out['config']['batch_per_gpu'] == 32
+    assert 'ONE device' in out['config']['parallelism']
+
+
 @pytest.mark.parametrize('fault', ['TTSAMD_BENCH_TEST_STALL', 'TTSAMD_BENCH_TEST_DIE'])
 def test_bench_watchdog_restarts_stalled_or_dead_ranks(fault):
     """The parent of a self-launched N > 1 run is the ranks' watchdog: a rank that never reaches the rendezvous (rank 0 then

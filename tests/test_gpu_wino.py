@@ -1,0 +1,106 @@
+"""GPU parity of the Winograd F(2,3) conv kernel of the exact-fp32 engine (csrc/conv_wino.hip) through the C ABI (pytest -m gpu).
+
+Checker: torch conv1d in float64 on the host (the reference's op for FastPitch's conv-FF convs, transformer.py:59-65, and HiFi-GAN's
+k = 3 ResBlock convs, vocoder/hifigan/models.py:30-44).  Stated tolerance: |diff| <= 2e-5 max-abs on O(1) outputs with K = 3 * Cin up
+to 4608 products each -- the same bound the direct fp32 kernel is held to in tests/test_gpu_parity.py (its measured error on these
+shapes is 2-4e-6; Winograd adds one rounding per transformed operand).  The direct kernel (TTSAMD_WINO=0) runs beside it: the two
+must agree to the same bound and -- being different arithmetic -- differ in their last bits, which proves the routing."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    from ttsamd import lib
+    assert lib.load().ttsamd_device_ok() == 1
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('cin,cout,L,B,slope,relu', [
+    (384, 1536, 496, 6, 1.0, True),          # FastPitch conv-FF, first conv (+ ReLU)
+    (1536, 384, 500, 24, 1.0, False),        # ... second conv: 96 chunks
+    (256, 256, 1032, 16, 0.1, False),        # HiFi-GAN stage 1 (leaky-relu on load); odd utterance lengths below
+    (128, 128, 700, 48, 0.1, False),
+    (16, 128, 300, 100, 1.0, False),         # two chunks: prologue = whole ring
+])
+def test_wino_conv_matches_float64_and_the_direct_kernel(dev, monkeypatch, cin, cout, L, B, slope, relu):
+    from ttsamd.engine import conv1d
+    g = torch.Generator().manual_seed(cin + cout + L)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, 3, generator=g) / np.sqrt(cin * 3)
+    b = torch.randn(cout, generator=g) * 0.3
+    # ragged: full length, odd lengths (a pair cut by the utterance end), one ending right after a tile edge, a 1-frame utterance
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2], lens[3] = L, L - 1 if L % 2 == 0 else L - 2, 129, 1
+    lens_d = lens.to(dev)
+    monkeypatch.setenv('TTSAMD_WINO', '1')
+    y_w = conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens_d, in_slope=slope, relu_out=relu).cpu()
+    monkeypatch.setenv('TTSAMD_WINO', '0')
+    y_d = conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens_d, in_slope=slope, relu_out=relu).cpu()
+    worst_w = worst_d = 0.0
+    for i in range(B):
+        n = int(lens[i])
+        xi = F.leaky_relu(x[i:i + 1, :, :n].double(), slope)
+        ref = F.conv1d(xi, w.double(), b.double(), padding=1)[0]
+        if relu:
+            ref = torch.relu(ref)
+        worst_w = max(worst_w, float((y_w[i, :, :n].double() - ref).abs().max()))
+        worst_d = max(worst_d, float((y_d[i, :, :n].double() - ref).abs().max()))
+        assert float(y_w[i, :, n:].abs().max() if n < L else 0.0) == 0.0, 'positions past the utterance must stay untouched'
+    print(f'cin={cin} cout={cout}: Winograd max-abs {worst_w:.2e}, direct {worst_d:.2e}')
+    assert worst_w < 2e-5 and worst_d < 2e-5
+    assert not torch.equal(y_w, y_d), 'TTSAMD_WINO=1 must route these shapes to the Winograd kernel'
+
+
+def test_wino_is_deterministic_and_skips_small_problems(dev, monkeypatch):
+    from ttsamd.engine import conv1d
+    g = torch.Generator().manual_seed(1)
+    x, w = torch.randn(8, 384, 496, generator=g), torch.randn(1536, 384, 3, generator=g) / 34.0
+    monkeypatch.setenv('TTSAMD_WINO', '1')
+    a, b2 = conv1d(x.to(dev), w.to(dev)), conv1d(x.to(dev), w.to(dev))
+    assert torch.equal(a, b2)
+    # short sequences (the 64-token encoder) and grids under one block per CU keep the direct kernel: same bits either way
+    xs = torch.randn(4, 384, 64, generator=g)
+    monkeypatch.setenv('TTSAMD_WINO', '0')
+    d = conv1d(xs.to(dev), w.to(dev))
+    monkeypatch.setenv('TTSAMD_WINO', '1')
+    assert torch.equal(conv1d(xs.to(dev), w.to(dev)), d)
+
+
+@pytest.mark.parametrize('cin,cout,L,B,mode', [(1536, 384, 496, 24, 0), (256, 256, 1032, 16, 1), (256, 256, 520, 40, 2)])
+def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout, L, B, mode):
+    """The epilogue that FastPitch's second conv-FF conv (conv + residual, transformer.py:83-86) and the c2 convs of HiFi-GAN's
+    ResBlocks (x + conv, summed over the three branches and divided, vocoder/hifigan/models.py:46-53,116-122) use: the residual -- and
+    in the accumulate modes the previous y -- enters through the accumulators (res[2j] -> M0, -res[2j + 1] -> M3).  Ragged, odd
+    lengths; against float64 and against the direct kernel's own preload epilogue."""
+    from ttsamd.engine import conv1d
+    g = torch.Generator().manual_seed(cin + L + mode)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, 3, generator=g) / np.sqrt(cin * 3)
+    b = torch.randn(cout, generator=g) * 0.3
+    res = torch.randn(B, cout, L, generator=g)
+    y0 = torch.randn(B, cout, L, generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2] = L, L - 1, 131
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TTSAMD_WINO', flag)
+        y = y0.clone().to(dev)
+        conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), in_slope=0.1, res=res.to(dev), mode=mode, div=3.0, y=y)
+        outs[flag] = y.cpu()
+    worst = {'1': 0.0, '0': 0.0}
+    for i in range(B):
+        n = int(lens[i])
+        v = F.conv1d(F.leaky_relu(x[i:i + 1, :, :n].double(), 0.1), w.double(), b.double(), padding=1)[0] + res[i, :, :n].double()
+        ref = v if mode == 0 else (y0[i, :, :n].double() + v if mode == 1 else (y0[i, :, :n].double() + v) / 3.0)
+        for flag in ('1', '0'):
+            worst[flag] = max(worst[flag], float((outs[flag][i, :, :n].double() - ref).abs().max()))
+            assert torch.equal(outs[flag][i, :, n:], y0[i, :, n:]), 'positions past the utterance must stay untouched'
+    print(f'cin={cin} mode={mode}: Winograd max-abs {worst["1"]:.2e}, direct {worst["0"]:.2e}')
+    assert worst["1"] < 5e-5 and worst["0"] < 5e-5                      # K = 4608 products per output at cin = 1536
+    assert not torch.equal(outs['1'], outs['0'])

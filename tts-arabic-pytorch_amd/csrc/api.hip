@@ -315,13 +315,34 @@ int32_t ttsamd_tagger_forward(void* handle, const int64_t* ids, int32_t batch, i
 }
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {
-    return 2 * (int64_t)cin * k * cout_padded(cout);   // fp32 packed + bf16 hi/lo planes
+    // fp32 packed + bf16 hi/lo planes (+ k = 3: the four Winograd filters, conv_wino.hip)
+    return 2 * (int64_t)cin * k * cout_padded(cout) + (k == 3 ? (int64_t)cin * 4 * cout_padded(cout) : 0);
 }
 
-int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t batch,
-                      int32_t cin, int32_t cout, int32_t k, int32_t dilation, int32_t lin, float in_slope,
-                      int32_t relu_out, float* y, float* packed, void* stream) {
+// [Cout][Cin][3] -> the Winograd F(2,3) filters in the packed 4-tap layout [cin/8][4][2][cp][4] (same values as pack_wino_weight)
+__global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cout, int cin, int cp, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)cin * 4 * cp;
+    if (i >= n) return;
+    const int pq = (int)(i & 3);
+    const int64_t r = i >> 2;
+    const int co = (int)(r % cp);
+    const int64_t r2 = r / cp;
+    const int kk = (int)(r2 & 1), t = (int)((r2 >> 1) & 3), o = (int)(r2 >> 3);
+    float v = 0.f;
+    if (co < cout) {
+        const float* g = w + ((int64_t)co * cin + (8 * o + 2 * pq + kk)) * 3;
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        v = t == 0 ? (float)g0 : (t == 1 ? (float)((g0 + g1 + g2) * 0.5) : (t == 2 ? (float)((g0 - g1 + g2) * 0.5) : (float)g2));
+    }
+    out[i] = v;
+}
+
+int32_t ttsamd_conv1d_ex(const float* x, const float* w, const float* bias, const float* res, const int64_t* lens, int32_t batch,
+                         int32_t cin, int32_t cout, int32_t k, int32_t dilation, int32_t lin, float in_slope,
+                         int32_t relu_out, int32_t mode, float div, float* y, float* packed, void* stream) {
     TTS_REQUIRE(x && w && y && packed, "conv1d: null argument");
+    TTS_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || div != 0.f), "conv1d: bad mode / div");
     hipStream_t s = (hipStream_t)stream;
     const int cp = cout_padded(cout);
     const int64_t n = (int64_t)cin * k * cp;
@@ -339,15 +360,29 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
         TTS_CHECK_HIP(hipGetLastError());
         p.w_bf16 = planes;
     }
+    if (k == 3 && p.precision == 0 && cin % 8 == 0) {
+        float* wino = packed + 2 * n;
+        const int64_t nw = (int64_t)cin * 4 * cp;
+        hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, cout, cin, cp, wino);
+        TTS_CHECK_HIP(hipGetLastError());
+        p.w_wino = wino;
+    }
     p.y = y; p.y_bs = (int64_t)cout * lin; p.y_cs = lin; p.y_ts = 1;
     p.lens_in = lens; p.lens_out = lens; p.len_in_mul = 1; p.len_out_mul = 1;
     p.Lin = lin; p.Nout = lin; p.Cin = cin; p.Cout = cout; p.CoutP = cp; p.K = k;
     p.dil = dilation; p.pad = (k * dilation - dilation) / 2;
-    p.n_phase = 1; p.in_slope = in_slope; p.relu_out = relu_out; p.mode = 0; p.div = 1.f; p.batch = batch;
+    p.res = res; p.r_bs = (int64_t)cout * lin; p.r_cs = lin;
+    p.n_phase = 1; p.in_slope = in_slope; p.relu_out = relu_out; p.mode = mode; p.div = div; p.batch = batch;
     prof_begin(s, 2.0 * cout * cin * k);
     const int32_t rc = launch_conv(p, s);
     prof_end(s);
     return rc;
+}
+
+int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t batch,
+                      int32_t cin, int32_t cout, int32_t k, int32_t dilation, int32_t lin, float in_slope,
+                      int32_t relu_out, float* y, float* packed, void* stream) {
+    return ttsamd_conv1d_ex(x, w, bias, nullptr, lens, batch, cin, cout, k, dilation, lin, in_slope, relu_out, 0, 1.f, y, packed, stream);
 }
 
 int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,

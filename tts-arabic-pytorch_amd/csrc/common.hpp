@@ -89,6 +89,7 @@ struct ConvParams {
     int32_t x_cs;
     const float* w;      // packed fp32 weights [n_phase][Cin/8][K][2][CoutP][4]
     const void* w_bf16;  // same element order as bf16: plane hi then plane lo (nullptr if not packed)
+    const float* w_wino; // k = 3 only: the Winograd F(2,3) filters as a 4-tap conv [Cin/8][4][2][CoutP][4] (conv_wino.hip; nullptr = none)
     int32_t precision;   // 0 fp32 MFMA, 1 bf16 MFMA, 2 split bf16 (3 MFMAs per product)
     const float* bias;   // [>=Cout] or nullptr
     float* y;            // (b,co,q) at y + b*y_bs + co*y_cs + q*y_ts + phase
@@ -153,6 +154,10 @@ bool fused_pair2_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, 
 int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const float* w1, const float* b1, const float* w2,
                            const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
                            int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream);
+// Winograd F(2,3) path of the k = 3, dilation-1 convs (conv_wino.hip): routing test, launcher, host-side filter transform + packing
+bool wino_wanted(const ConvParams& p);
+int32_t launch_wino(const ConvParams& p, hipStream_t stream);
+void pack_wino_weight(const float* w, int cout, int cin, float* out);   // out: cin * 4 * cout_padded(cout) floats
 // Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]
 void pack_conv_weight(const float* w, int cout, int cin, int k, float* out);
 // torch ConvTranspose1d [Cin][Cout][Kt] (Kt = 2u, stride u, padding p) -> [u][Cin][2][CoutP]

@@ -411,19 +411,21 @@ class TaggerEngine:
         return probs
 
 
-def conv1d(x, w, bias=None, lens=None, dilation=1, in_slope=1.0, relu_out=False):
-    """Kernel-level entry (parity tests / roofline bench): y = conv1d(lrelu(x), w) + b, 'same' padding."""
+def conv1d(x, w, bias=None, lens=None, dilation=1, in_slope=1.0, relu_out=False, res=None, mode=0, div=1.0, y=None):
+    """Kernel-level entry (parity tests / roofline bench): y = act(conv1d(lrelu(x), w) + b [+ res]), 'same' padding;
+    mode 1 / 2: y <- y + that / (y + that) / div (the ResBlock sum of HiFi-GAN); res may be y itself (in place)."""
     lib = _require_gpu()
     x = x.contiguous().float()
     w = w.contiguous().float()
     B, cin, lin = x.shape
     cout, cin2, k = w.shape
     assert cin == cin2
-    y = torch.zeros(B, cout, lin, dtype=torch.float32, device=x.device)
+    if y is None:
+        y = torch.zeros(B, cout, lin, dtype=torch.float32, device=x.device)
     packed = torch.empty(lib.ttsamd_conv1d_packed_floats(cout, cin, k), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        L.check(lib.ttsamd_conv1d(_ptr(x), _ptr(w), _ptr(bias), _ptr(lens), B, cin, cout, k, dilation, lin,
-                                  float(in_slope), int(relu_out), _ptr(y), _ptr(packed), _stream()), 'conv1d')
+        L.check(lib.ttsamd_conv1d_ex(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(lens), B, cin, cout, k, dilation, lin,
+                                     float(in_slope), int(relu_out), int(mode), float(div), _ptr(y), _ptr(packed), _stream()), 'conv1d')
     return y
 
 

@@ -88,6 +88,7 @@ SYMBOLS = {
     'ttsamd_tagger_forward': (_I32, [_P, _P, _I32, _I32, _P, _P, _I64, _P]),
     'ttsamd_conv1d_packed_floats': (_I64, [_I32, _I32, _I32]),
     'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
+    'ttsamd_conv1d_ex': (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _I32, _F, _P, _P, _P]),
     'ttsamd_resblock_pair': (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P]),
     'ttsamd_bfo_pack': (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),
     'ttsamd_bfo_unpack': (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),
