@@ -413,14 +413,21 @@ bool wino_wanted(const ConvParams& p) {
     return blocks >= 256 && p.Nout >= 256;       // (short sequences -- FastPitch's 64-token encoder -- would leave half of a 128-output tile empty)
 }
 
-int32_t launch_wino(const ConvParams& p, hipStream_t stream) {
-    using G = WinoGeo<2, 2, 2>;                                 // 128 co x 128 outputs (64 pairs)
+template <int MT, int WM, int WN>
+static int32_t launch_wino_cfg(const ConvParams& p, hipStream_t stream) {
+    using G = WinoGeo<MT, WM, WN>;
     dim3 grid((p.Nout + G::NT_BLK - 1) / G::NT_BLK, p.CoutP / G::CO_BLK, p.batch);
     ConvParams q = p;
     q.ksplit = 1;
     q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
-    if (p.res != nullptr) return launch_wino_epi<2, 2, 2, 3>(q, grid, stream);
-    return launch_wino_epi<2, 2, 2, 0>(q, grid, stream);
+    if (p.res != nullptr) return launch_wino_epi<MT, WM, WN, 3>(q, grid, stream);
+    return launch_wino_epi<MT, WM, WN, 0>(q, grid, stream);
+}
+
+int32_t launch_wino(const ConvParams& p, hipStream_t stream) {
+    // 128 co x 128 outputs (64 pairs).  (A 128 co x 64 outputs tile for launches under two blocks per CU -- FastPitch's 1536 -> 384 conv
+    // at batch 32 is 384 blocks -- measured slower: 75.04 vs 74.45 ms per step; everything on it: 76.67.)
+    return launch_wino_cfg<2, 2, 2>(p, stream);
 }
 
 // host: torch Conv1d weight [Cout][Cin][3] -> the four transformed filters as a 4-tap conv in the engine's packed layout
