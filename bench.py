@@ -155,7 +155,9 @@ def cpu_baseline_all_cores(tokens, threads=8, seconds=12.0):
     ctx = mp.get_context('spawn')
     t0 = time.perf_counter()
     with ctx.Pool(n) as pool:
-        res = pool.map(_cpu_worker, [(w, n, threads, tokens, seconds) for w in range(n)])
+        # bounded: worker start-up (a cold `import torch`, weight synthesis) has taken minutes on a loaded host; the leg is a context
+        # figure, not worth more than ~1.5 min of the bench's wall time (TimeoutError -> the caller records the error string)
+        res = pool.map_async(_cpu_worker, [(w, n, threads, tokens, seconds) for w in range(n)]).get(timeout=90.0 + seconds)
     wall = time.perf_counter() - t0
     samples, utts, slowest = sum(r[0] for r in res), sum(r[1] for r in res), max(r[2] for r in res)
     return {'value': samples / slowest, 'unit': 'audio samples/s', 'cores': n * threads, 'workers': n, 'threads_per_worker': threads,
@@ -783,23 +785,37 @@ def main():
             out['exchange_ms_per_step'] = xch_ms          # C2 audio fan-in (pack + transfer), max over ranks; the length exchange
             out['exchange_note'] = ('HIP events around the packed audio fan-in on each rank, max over ranks; the all-gather of the '
                                     'lengths rides in the step\'s one host synchronisation')
+        t_sec = time.perf_counter()
+        sections = {}
+
+        def lap(name):
+            nonlocal t_sec
+            now = time.perf_counter()
+            sections[name] = round(now - t_sec, 1)
+            t_sec = now
+
         if world == 1 and not args.no_small and B > 8:
             out['configs'] = [small_config(1), small_config(8)]
+            lap('batch 1 / 8')
             if args.precision == 'f32' and args.pipeline and B == 32:
                 out['configs'].append(small_config(B, pipelined=False, name='C2 (this line\'s workload) on the ONE-stream schedule: every '
                                                                            'launch of a step on the caller\'s stream, same work and results'))
             if not args.no_extra:
-                out['configs'] += extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync)
+                out['configs'] += extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync, lap)
         if world == 1 and not args.no_extra:
             out['d2h'] = d2h_probe(wave, dec_lens, hop)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(fp_sd, hg_sd, Lt)
+            lap('cpu_baseline')
             try:
                 out['cpu_baseline']['all_cores'] = cpu_baseline_all_cores(Lt)
             except Exception as e:                               # noqa: BLE001
                 out['cpu_baseline']['all_cores'] = {'error': str(e)[:300]}
+            lap('cpu_baseline.all_cores')
         elif world > 1:
             out['cpu_baseline'] = None
+        if sections:
+            out['bench_sections_s'] = sections        # wall seconds of the sub-results behind this line (the timed K steps are not in it)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
@@ -826,7 +842,7 @@ def d2h_probe(wave, dec_lens, hop):
             'gb_per_s': nbytes / ts[len(ts) // 2] / 1e9, 'what': 'padded [B, n_max] fp32 wave -> pinned host buffer, one copy per batch'}
 
 
-def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync):
+def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync, lap=lambda name: None):
     """The other BASELINE configs as driver-visible sub-results (each: ms_per_step, audio samples/s, a wall-time roofline):
     C3  the per-GPU share (B = 256 / 8 = 32) of the bf16 configuration;
     C4  Tacotron2 autoregressive decode + HiFi-GAN, batch 8, 448 forced decoder steps (the gate is biased shut so the work is
@@ -878,6 +894,7 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
     except Exception as e:                                       # noqa: BLE001
         res.append({'config': 'C3 split-bf16', 'error': str(e)[:300]})
     torch.cuda.empty_cache()
+    lap('C3 (bf16 32 / 8 / 1 / 256, bf16x3 32 / 256)')
     n = max(args.steps, 10)
     hgf = hifigan_flops_per_frame(HIFIGAN_CONFIG)
     # ---- C4
@@ -930,6 +947,7 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
         del taco
     except Exception as e:                                       # noqa: BLE001  (a sub-result must not take the headline line down)
         res.append({'config': 'C4 Tacotron2 + HiFi-GAN', 'error': str(e)[:300]})
+    lap('C4')
     # ---- C5
     try:
         cfg4 = dict(NET_CONFIG, n_speakers=4, speaker_emb_weight=1.0)
@@ -1003,6 +1021,7 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
                     'parity': 'denoiser unpinned at the torchaudio boundary (golden made with a torch.stft stand-in; SURVEY §8c)'})
     except Exception as e:                                       # noqa: BLE001
         res.append({'config': 'C2 with denoise=0.005', 'error': str(e)[:300]})
+    lap('C5 + C2 denoise')
     # ---- C1: the reference's own case (inference.py:55-58) -- the 100 lines of data/infer_text.txt through FastPitch2Wave.tts
     try:
         res += c1_configs(dev)
@@ -1052,8 +1071,9 @@ def c1_configs(dev):
                     'batch': bs, 'ms_total': el * 1e3, 'ms_per_utterance': el * 1e3 / len(lines), 'value': ns / el, 'unit': 'audio samples/s',
                     'rtf': el / (ns / SAMPLE_RATE), 'samples': ns, 'utterances': len(lines), 'dtype': 'f32',
                     'timing': 'median of 3 whole calls, host wall time incl. tokenisation and the device -> host copies',
-                    'schedule': 'three HIP streams over the chunks of the list (FastPitch2Wave._tts_list_pipelined): tokenise + FastPitch of chunk '
-                                'k+1 under vocoder + denoiser of chunk k, D2H on a third stream'})
+                    'schedule': 'three HIP streams over the chunks of the list (FastPitch2Wave._tts_list_pipelined): tokenise + FastPitch of the next '
+                                'chunks (each chunk = the reference\'s padded batch of `batch_size` lines) under vocoder + denoiser of the previous '
+                                'ones, D2H on a third stream; the batch-independent vocoder takes the mels of up to 16 utterances per ragged call'})
     return res
 
 

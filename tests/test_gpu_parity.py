@@ -725,10 +725,12 @@ def test_two_stream_pipeline_bit_identical(dev, synth_weights, fastpitch_engine,
         assert torch.equal(dl, dl_ref) and torch.equal(w, w_ref)
 
 
-def test_dropin_tts_list_pipeline_bit_identical(dev, golden, checkpoints, monkeypatch, capsys):
-    """`FastPitch2Wave.tts(list)` over several chunks runs as a three-stream pipeline (FastPitch of chunk k + 1 under the
-    vocoder of chunk k, D2H on a third stream): same waves, bit for bit, as the one-stream loop, for batch_size 1 (tts_single
-    per line) and 2 (tts_batch), denoiser on; prints both timings."""
+def test_dropin_tts_list_pipeline_matches_the_one_stream_loop(dev, golden, checkpoints, monkeypatch, capsys):
+    """`FastPitch2Wave.tts(list)` over several chunks runs as a three-stream pipeline (FastPitch of the next chunks under the vocoder
+    of the previous ones, D2H on a third stream) whose vocoder takes the mels of up to 16 utterances per ragged call: same lengths
+    and -- the vocoder being batch-independent up to its fp32 summation order -- the same waves as the one-stream loop to 1e-5
+    (north-star tolerance 1e-4), for batch_size 1 (tts_single per line), 2 and 5 (tts_batch), denoiser on; prints both timings.
+    (Both paths are checked against the oracle: test_dropin_tts_matches_reference, test_config1_all_100_lines_batch_size_1.)"""
     import time
     from models.fastpitch import FastPitch2Wave
     lines = _lines(golden, range(24))
@@ -744,7 +746,7 @@ def test_dropin_tts_list_pipeline_bit_identical(dev, golden, checkpoints, monkey
         a, b = res['0'][0], res['1'][0]
         assert len(a) == len(b) == len(lines)
         for x, y in zip(a, b):
-            assert x.device.type == 'cpu' and torch.equal(x, y)
+            assert x.device.type == 'cpu' and x.shape == y.shape and float((x - y).abs().max()) < 1e-5
         with capsys.disabled():
             print(f'\n[tts list, {len(lines)} lines, batch_size {bs}] one stream {res["0"][1] * 1e3:.1f} ms, pipelined {res["1"][1] * 1e3:.1f} ms')
 

@@ -257,14 +257,22 @@ class FastPitch2Wave(nn.Module):
             wav_list += self.tts_batch(text_input[k:k + batch_size], **kw)
         return wav_list
 
+    # utterances per vocoder call of the list pipeline: chunks of `batch_size` lines go through FastPitch one by one (a chunk is the
+    # reference's padded batch: its results depend on the chunk's composition), their mels are vocoded together
+    _VOCODER_GROUP = 16
+
     @torch.inference_mode()
     def _tts_list_pipelined(self, text_input, batch_size, speed, denoise, speaker_id, vowelizer, pitch_mul, pitch_add,
                             return_mel=False):
         """The list path of `tts` over several chunks, as a three-stage pipeline on three HIP streams: tokenisation + FastPitch
-        of chunk k + 1 (host work and ~150 short launches that leave most CUs idle) run under the vocoder + denoiser of chunk
-        k, whose audio is copied to the host on a third stream.  Every chunk goes through exactly the calls of the one-stream
-        loop (`tts_single` for batch_size 1, `tts_batch` otherwise), each engine sees its own calls in order on its own
-        stream: the waves are bit-identical, only the schedule differs (C1, 100 lines at batch 1: see DESIGN.md)."""
+        of the next chunks (host work and ~150 short launches that leave most CUs idle) run under the vocoder + denoiser of the
+        previous ones, whose audio is copied to the host on a third stream.  FastPitch sees exactly the chunks of the one-stream
+        loop (`ttmel_single` per line for batch_size 1, the padded batch otherwise).  The vocoder is batch-independent -- every
+        layer pads each utterance at its own true edge, so a ragged batch equals the per-utterance loop of the reference
+        (networks.py:340-345; tests: test_hifigan_ragged_batch_matches_unbatched, test_full_size_bench_workload_properties) -- and
+        therefore takes the mels of up to _VOCODER_GROUP utterances in ONE ragged call: at batch_size 1 its launches fill the chip
+        like a batch-16 call instead of 100 batch-1 calls (C1, 100 lines: 861 -> see DESIGN.md).  Waves equal the one-stream loop's
+        within the vocoder's fp32 summation-order noise (1e-6; a larger batch picks other tiles), lengths exactly."""
         dev = self.device
         if getattr(self, '_pipe_streams', None) is None or self._pipe_streams[0].device != dev:
             self._pipe_streams = tuple(torch.cuda.Stream(dev) for _ in range(3))
@@ -272,46 +280,53 @@ class FastPitch2Wave(nn.Module):
         cur = torch.cuda.current_stream(dev)
         for st in (s_fp, s_hg, s_cp):
             st.wait_stream(cur)
-        hop = self.vocoder.engine().hop
+        eng = self.vocoder.engine()
+        hop = eng.hop
         out, pending = [], None
+        group = max(1, self._VOCODER_GROUP // batch_size)           # chunks per vocoder call
 
         def flush(item):
-            wave, n, rev, done = item
+            wave, n, done = item
             s_cp.wait_event(done)
             with torch.cuda.stream(s_cp):
                 wave.record_stream(s_cp)
-                if rev is None:
-                    out.append(wave[0].cpu())                            # blocks the host on THIS chunk's audio only
-                else:
-                    out.extend(wave[j, :n[j]].cpu() for j in rev.tolist())
+                out.extend(wave[j, :n[j]].cpu() for j in range(len(n)))      # blocks the host on THIS group's audio only
 
-        for k in range(0, len(text_input), batch_size):
-            chunk = text_input[k:k + batch_size]
+        chunks = [text_input[k:k + batch_size] for k in range(0, len(text_input), batch_size)]
+        for g0 in range(0, len(chunks), group):
+            mels, lens = [], []                                     # this group's utterances in input order
             with torch.cuda.stream(s_fp):
-                if batch_size == 1:
-                    mel = self.model.ttmel_single(chunk[0], speed, speaker_id, vowelizer, pitch_mul=pitch_mul, pitch_add=pitch_add)
-                    dec_lens = rev = None
+                for chunk in chunks[g0:g0 + group]:
+                    if batch_size == 1:
+                        mel = self.model.ttmel_single(chunk[0], speed, speaker_id, vowelizer, pitch_mul=pitch_mul, pitch_add=pitch_add)
+                        mels.append(mel)
+                        lens.append(int(mel.shape[-1]))
+                    else:
+                        mel, dec_lens, rev = self.model._ttmel_batch_padded(chunk, speed, speaker_id, vowelizer, pitch_mul, pitch_add)
+                        dl = dec_lens.cpu().tolist()                # (FastPitch has synchronised on these lengths already)
+                        for j in rev.tolist():
+                            mels.append(mel[j, :, :dl[j]])
+                            lens.append(int(dl[j]))
+                if len(mels) == 1:
+                    mel_b = mels[0][None]
                 else:
-                    mel, dec_lens, rev = self.model._ttmel_batch_padded(chunk, speed, speaker_id, vowelizer, pitch_mul, pitch_add)
-                    n_host = (dec_lens.cpu() * hop).tolist()             # (FastPitch has synchronised on these lengths already)
+                    mel_b = torch.zeros(len(mels), mels[0].shape[0], max(lens), dtype=mels[0].dtype, device=dev)
+                    for i, m in enumerate(mels):
+                        mel_b[i, :, :lens[i]] = m
+                lens_d = torch.tensor(lens, dtype=torch.int64).to(dev, non_blocking=True)
             s_hg.wait_stream(s_fp)
             with torch.cuda.stream(s_hg):
-                mel.record_stream(s_hg)
-                if batch_size == 1:
-                    wave, n = self.vocoder(mel), None
-                    if denoise > 0:
-                        wave = self.denoiser(wave, denoise)
-                else:
-                    dec_lens.record_stream(s_hg)
-                    wave = self.vocoder.engine().forward(mel, dec_lens)
-                    if denoise > 0:
-                        wave = self.denoiser.forward_batch(wave, dec_lens * hop, denoise, nsamples_min=min(n_host))
-                    n = n_host
+                mel_b.record_stream(s_hg)
+                lens_d.record_stream(s_hg)
+                wave = eng.forward(mel_b, lens_d)
+                n_host = [t * hop for t in lens]
+                if denoise > 0:
+                    wave = self.denoiser.forward_batch(wave, lens_d * hop, denoise, nsamples_min=min(n_host))
                 done = torch.cuda.Event()
                 done.record(s_hg)
             if pending is not None:
                 flush(pending)
-            pending = (wave, n, rev, done)
+            pending = (wave, n_host, done)
         if pending is not None:
             flush(pending)
         cur.wait_stream(s_hg)
