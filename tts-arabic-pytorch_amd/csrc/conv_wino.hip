@@ -426,7 +426,8 @@ static int32_t launch_wino_cfg(const ConvParams& p, hipStream_t stream) {
 
 int32_t launch_wino(const ConvParams& p, hipStream_t stream) {
     // 128 co x 128 outputs (64 pairs).  (A 128 co x 64 outputs tile for launches under two blocks per CU -- FastPitch's 1536 -> 384 conv
-    // at batch 32 is 384 blocks -- measured slower: 75.04 vs 74.45 ms per step; everything on it: 76.67.)
+    // at batch 32 is 384 blocks -- measured slower: 75.04 vs 74.45 ms per step; everything on it: 76.67.  A 64 co x 128 outputs tile,
+    // three blocks per CU: 74.61 vs 74.22-74.35; everything on it: 75.44.)
     return launch_wino_cfg<2, 2, 2>(p, stream);
 }
 
