@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r4'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r5'
 # bench line (with cpu_baseline and the batch-1 / batch-8 sub-results), rocprofv3 kernel stats of the same command,
 # FETCH_SIZE / WRITE_SIZE calibration on known-bytes kernels, separate PMC passes, the other precisions and configs.
 set -u
-R=${1:-r4}
+R=${1:-r5}
 O=gpurun_out/collect_$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -24,6 +24,18 @@ TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYC
 FRAMES=$(python3 -c "import json;print(json.load(open('$O/final_bench_line.json'))['config']['frames_per_step_rank0'])")
 python3 profiles/traffic_from_pmc.py $O/pmc_fetch $O/pmc_write $O/conv_log.csv $FRAMES $O/traffic_calib.json > $O/traffic.json
 for p in bf16x3 bf16; do python3 bench.py --precision $p --no-cpu-baseline --no-extra > $O/${p}_bench_line.json 2>> $O/bench.err; done
+python3 bench.py --precision bf16x3 --no-pipeline --no-cpu-baseline --no-small --no-extra > $O/bf16x3_one_stream_bench_line.json 2>> $O/bench.err
+# config 3 inside the 1e-3 / 1e-4 tolerance (split bf16 on the octet engine, round 5): kernel stats (one stream), MFMA counters, per-layer table
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/xstats1 -- python3 bench.py --precision bf16x3 --no-pipeline --steps 5 --warmup 2 --no-cpu-baseline --no-small --no-extra > $O/xstats1.log 2>&1
+TTSAMD_HIFIGAN_STREAMS=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/xpmc_mfma -- python3 bench.py --precision bf16x3 --no-pipeline --steps 1 --warmup 1 --no-cpu-baseline --no-small --no-extra > $O/xpmc_mfma.log 2>&1
+python3 profiles/summarize.py $(ls $O/xstats1/*/*kernel_trace.csv | head -1) > $O/bf16x3_by_grid_one_stream.txt
+python3 profiles/pmc_summarize.py $O/xpmc_mfma > $O/bf16x3_pmc_mfma_by_kernel.txt
+cp $(ls $O/xstats1/*/*kernel_stats.csv | head -1) $O/bf16x3_kernel_stats_one_stream.csv
+python3 tools/bfo_bench.py --x3 --json $O/bfo3_layers.json > $O/bfo3_layers.txt 2>> $O/bench.err
+rm -rf $O/xstats1 $O/xpmc_mfma
+# fp32 with the direct k = 3 kernel instead of Winograd F(2,3): the same-box A/B behind DESIGN.md section 4
+python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_on_bench_line.json 2>> $O/bench.err
+TTSAMD_WINO=0 python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_off_bench_line.json 2>> $O/bench.err
 # bf16 runs the two-stream schedule by default (FastPitch of step i+1 under HiFi-GAN of step i); the one-stream line of the same work:
 python3 bench.py --precision bf16 --no-pipeline --no-cpu-baseline --no-small --no-extra > $O/bf16_one_stream_bench_line.json 2>> $O/bench.err
 # config 3 (bf16 octet engine): kernel stats (three streams / one stream), HBM traffic and MFMA counters of the same command
@@ -43,6 +55,8 @@ python3 tools/bfo_bench.py --json $O/bfo_layers.json > $O/bfo_layers.txt 2>> $O/
 rm -rf $O/bstats $O/bstats1 $O/bpmc_fetch $O/bpmc_write $O/bpmc_mfma
 python3 bench.py --gpus 2 --no-cpu-baseline > $O/dp2_one_device_bench_line.json 2>> $O/bench.err
 python3 tools/taco_bench.py > $O/taco_b8.json 2>> $O/bench.err
+# the full-size parity numbers (every utterance vs the oracle on the GPU: f32 / bf16x3 / bf16, B = 256 bf16 / bf16x3, configs 1, 4, 5)
+python3 -m pytest tests/test_gpu_fullsize.py -m gpu -q -s 2>&1 | grep -E "full-size|config|passed|failed" > $O/fullsize_parity.txt
 # round 4: the fused ResBlock pair kernels of the fp32 engine one launch at a time, the device-count probe, the torch-ROCm baseline (opt-in test)
 python3 tools/fused_pair_bench.py > $O/fused_pair_layers.txt 2>> $O/bench.err
 python3 tools/devcount_probe.py > $O/devcount_probe.txt 2>&1
