@@ -752,8 +752,12 @@ def main():
                 'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
-                    'kernel': ('MFMA conv engine: conv1d_mfma_f32 + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
+                    'kernel': ('MFMA conv engine: conv1d_mfma_f32 + conv1d_wino_f32 (Winograd F(2,3), k = 3 dilation-1 launches) + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
+            if args.precision == 'f32':
+                roof['flops_basis'] = ('UN-REDUCED algorithmic FLOPs (2 Cout Cin K per valid output position).  The Winograd F(2,3) launches '
+                                       '(FastPitch conv-FF, HiFi-GAN C = 128 / 256 k = 3 dilation-1 convs: 1.1 of the 9.5 TFLOP of a step) issue 2/3 '
+                                       'of those as MFMAs; TTSAMD_WINO=0 runs the direct kernels (profiles/r5/wino_off_bench_line.json)')
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
                      'traffic_algorithmic': traffic_alg, 'traffic_ratio': (traffic / traffic_alg) if (traffic and traffic_alg) else None,
                      'launches': int(n_launch), 'sections': int(n_sections),

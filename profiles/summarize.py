@@ -8,7 +8,7 @@ rows = defaultdict(lambda: [0, 0])
 conv_iv = []          # (start, end) of every MFMA conv launch: their UNION is the conv engine's busy time
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        if any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'resblock_chain', 'convt_mfma', 'bfo_conv1d', 'bfo_convt')):
+        if any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'conv1d_wino', 'resblock_pair', 'resblock_chain', 'convt_mfma', 'bfo_conv1d', 'bfo_convt', 'bfo3_conv1d', 'bfo3_convt')):
             conv_iv.append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
         key = (r['Kernel_Name'][:100], int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']),
                int(r['Grid_Size_Y']), int(r['Grid_Size_Z']), r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size'])
@@ -27,7 +27,7 @@ if conv_iv:
         else:
             cur_e = max(cur_e, b)
     union += cur_e - cur_s
-    print(f'MFMA conv launches (conv1d_mfma / resblock_pair / convt_mfma / bfo_*): {len(conv_iv)}, sum of durations {sum(b - a for a, b in conv_iv) / 1e6:.3f} ms, '
+    print(f'MFMA conv launches (conv1d_mfma / conv1d_wino / resblock_pair / convt_mfma / bfo_* / bfo3_*): {len(conv_iv)}, sum of durations {sum(b - a for a, b in conv_iv) / 1e6:.3f} ms, '
           f'union of their intervals (busy time of the conv engine; the three ResBlock branches of a HiFi-GAN stage '
           f'overlap on three streams) {union / 1e6:.3f} ms')
 print(f'{"total_ms":>10} {"calls":>6} {"avg_us":>10} {"%":>6}  blocks(x,y,z) vgpr agpr lds  kernel')
