@@ -44,7 +44,6 @@ struct BfoPairParams {
     float mid_slope;       // leaky-relu between c1 and c2 (0.1)
     float out_slope;       // y = leaky_relu(v, out_slope); 1 = raw
     int32_t compact;              // set by the launcher: ragged batch, blocks take the lin-th LIVE tile (common.hpp: live_tile)
-    int32_t turnstile;            // set by the launcher: take the CU's phase turnstile around the window staging (bfo.hpp)
     unsigned long long* timing;   // tools/bfo_pair_bench -DBFO_TIMING only: [blocks][16] shader-clock stamps (nullptr otherwise)
 };
 
@@ -171,32 +170,6 @@ __device__ __forceinline__ bfo_i2 bfo_act4(float v0, float v1, float v2, float v
     w.x = bfo_pk(bfo_vmax(v0, sa.x), bfo_vmax(v1, sa.y)) & mask;
     w.y = bfo_pk(bfo_vmax(v2, sb.x), bfo_vmax(v3, sb.y)) & mask;
     return w;
-}
-
-// ---- per-CU phase turnstile (a scheduling HINT, never needed for correctness) ------------------------------------------------------
-// The narrow pairs spend as long in their memory phases (window loads, output stores: a CU sustains ~11 B per cycle on that path) as in
-// their MFMAs, and the two blocks a CU holds drift into the same phase: both stream (the other CUs' blocks too: HBM saturated) or both
-// multiply (HBM idle), so a launch takes memory time PLUS matrix time instead of the larger of the two.  A block therefore takes its
-// CU's turnstile before it issues its window loads and gives it back once they have landed: the partner block's loads queue up behind
-// its own MFMA phase instead of beside the first block's loads.  One word per CU in global memory (the two blocks of a CU sit behind
-// the same L2), taken by lane 0 of wave 0 with a returning atomic and a BOUNDED spin -- a word left set by an aborted launch costs
-// every later block its spin budget, never a hang.
-extern __device__ int g_bfo_turnstile[1024];
-__device__ __forceinline__ int bfo_cu_slot() {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    return (int)(((xcc & 7u) << 7) | ((hwid >> 8) & 0x7fu));          // XCC, then SE / SH / CU id bits of HW_ID
-}
-__device__ __forceinline__ void bfo_turnstile_take(const int slot, const int tid) {
-    if (tid == 0) {
-        int spins = 0;
-        while (atomicCAS(&g_bfo_turnstile[slot], 0, 1) != 0 && ++spins < 4096) __builtin_amdgcn_s_sleep(4);
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void bfo_turnstile_give(const int slot, const int tid) {
-    if (tid == 0) __hip_atomic_store(&g_bfo_turnstile[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One conv over an LDS-resident window: acc[j] += sum_{h, tap} A(h, tap) x B(h, tap, column tile j).

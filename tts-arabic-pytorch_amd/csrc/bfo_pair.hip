@@ -24,8 +24,6 @@
 
 namespace ttsamd {
 
-__device__ int g_bfo_turnstile[1024];
-
 // 32-column tiles per wave: 8 (256 columns), or 4 -- half the window, 3-4 blocks per CU -- for k = 3 at C <= 64 (152 -> 137 us at
 // C = 64, 118 -> 111 at C = 32 with the deeper weight ring below; no change at C = 128: tools/bfo_pair_bench) and for small
 // batches, where 256-column tiles leave CUs without a block (batch 1: 115 blocks at C = 128)
@@ -84,8 +82,6 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
     const bfo_i4 xrs = bfo_rsrc((const char*)p.x + (int64_t)b * NO * L * 16, (unsigned)NO * L * 16);
 
     // ---- stage the window: all loads first, then the LDS writes
-    const int ts_slot = p.turnstile ? bfo_cu_slot() : -1;
-    if (ts_slot >= 0) bfo_turnstile_take(ts_slot, tid);
     {
         bfo_i4 xv[NXI];
 #pragma unroll
@@ -103,7 +99,6 @@ __global__ __launch_bounds__(256, (NT_ <= 4 ? 3 : 2)) void bfo_resblock_pair(con
         }
     }
     __syncthreads();
-    if (ts_slot >= 0) bfo_turnstile_give(ts_slot, tid);
     BFO_STAMP(1)
 
     const int wv = (kk * C + 32 * wm + l31) * 16;           // this lane's A fragment inside a (h, tap) step
@@ -232,7 +227,6 @@ static int32_t bfo_launch_pair_nt(const BfoPairParams& p, hipStream_t stream) {
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
     BfoPairParams q = p;
     q.compact = compact_order(p.lens, p.batch) ? 1 : 0;
-    { const char* e = getenv("TTSAMD_BFO_TURNSTILE"); q.turnstile = (e && e[0] == '1') ? 1 : 0; }
     hipLaunchKernelGGL((bfo_resblock_pair<K, C, NT>), grid, dim3(256), G::LDS, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
