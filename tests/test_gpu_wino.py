@@ -1,4 +1,5 @@
-"""GPU parity of the Winograd F(2,3) conv kernel of the exact-fp32 engine (csrc/conv_wino.hip) through the C ABI (pytest -m gpu).
+"""GPU parity of the Winograd F(2,3) conv kernels of the exact-fp32 engine (csrc/conv_wino.hip: k = 3; csrc/conv_wino2.hip: k = 3 / 7 / 11
+as sums of three-tap sub-filters and single taps) through the C ABI (pytest -m gpu).
 
 Checker: torch conv1d in float64 on the host (the reference's op for FastPitch's conv-FF convs, transformer.py:59-65, and HiFi-GAN's
 k = 3 ResBlock convs, vocoder/hifigan/models.py:30-44).  Stated tolerance: |diff| <= 2e-5 max-abs on O(1) outputs with K = 3 * Cin up
@@ -38,6 +39,7 @@ def test_wino_conv_matches_float64_and_the_direct_kernel(dev, monkeypatch, cin, 
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2], lens[3] = L, L - 1 if L % 2 == 0 else L - 2, 129, 1
     lens_d = lens.to(dev)
+    monkeypatch.setenv('TTSAMD_WINO2', '6')           # k = 3 on conv_wino.hip (the decomposition kernel's k = 3 is tested below)
     monkeypatch.setenv('TTSAMD_WINO', '1')
     y_w = conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens_d, in_slope=slope, relu_out=relu).cpu()
     monkeypatch.setenv('TTSAMD_WINO', '0')
@@ -61,6 +63,7 @@ def test_wino_is_deterministic_and_skips_small_problems(dev, monkeypatch):
     from ttsamd.engine import conv1d
     g = torch.Generator().manual_seed(1)
     x, w = torch.randn(8, 384, 496, generator=g), torch.randn(1536, 384, 3, generator=g) / 34.0
+    monkeypatch.setenv('TTSAMD_WINO2', '6')
     monkeypatch.setenv('TTSAMD_WINO', '1')
     a, b2 = conv1d(x.to(dev), w.to(dev)), conv1d(x.to(dev), w.to(dev))
     assert torch.equal(a, b2)
@@ -88,6 +91,7 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2] = L, L - 1, 131
     outs = {}
+    monkeypatch.setenv('TTSAMD_WINO2', '6')
     for flag in ('1', '0'):
         monkeypatch.setenv('TTSAMD_WINO', flag)
         y = y0.clone().to(dev)
@@ -103,4 +107,45 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
             assert torch.equal(outs[flag][i, :, n:], y0[i, :, n:]), 'positions past the utterance must stay untouched'
     print(f'cin={cin} mode={mode}: Winograd max-abs {worst["1"]:.2e}, direct {worst["0"]:.2e}')
     assert worst["1"] < 5e-5 and worst["0"] < 5e-5                      # K = 4608 products per output at cin = 1536
+    assert not torch.equal(outs['1'], outs['0'])
+
+
+@pytest.mark.parametrize('k,cin,cout,L,B,mode', [
+    (3, 256, 256, 1032, 16, None), (3, 1536, 384, 496, 24, 0),
+    (7, 256, 256, 1032, 16, None), (7, 256, 256, 1028, 16, 1), (7, 128, 128, 2052, 16, 2),
+    (11, 256, 256, 1032, 16, None), (11, 256, 256, 1028, 16, 2), (11, 128, 128, 2052, 16, 1), (7, 32, 128, 700, 48, None),
+])
+def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, cin, cout, L, B, mode):
+    """conv_wino2.hip: a k-tap filter as k // 3 three-tap F(2,3) sub-filters + k % 3 single taps accumulating into the same four planes
+    (HiFi-GAN's k = 7 / 11 ResBlock convs at dilation 1, vocoder/hifigan/models.py:30-44).  Float64 checker, ragged odd lengths, with
+    and without the residual / accumulate epilogues; the direct kernel beside it."""
+    from ttsamd.engine import conv1d
+    g = torch.Generator().manual_seed(k * 1000 + cin + L)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
+    b = torch.randn(cout, generator=g) * 0.3
+    res = torch.randn(B, cout, L, generator=g) if mode is not None else None
+    y0 = torch.randn(B, cout, L, generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2], lens[3] = L, L - 1, 131, 1
+    outs = {}
+    monkeypatch.setenv('TTSAMD_WINO2', '7')
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TTSAMD_WINO', flag)
+        y = y0.clone().to(dev)
+        conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), in_slope=0.1, res=None if res is None else res.to(dev),
+               mode=mode or 0, div=3.0, y=y)
+        outs[flag] = y.cpu()
+    worst = {'1': 0.0, '0': 0.0}
+    for i in range(B):
+        n = int(lens[i])
+        v = F.conv1d(F.leaky_relu(x[i:i + 1, :, :n].double(), 0.1), w.double(), b.double(), padding=(k - 1) // 2)[0]
+        if res is not None:
+            v = v + res[i, :, :n].double()
+        ref = v if not mode else (y0[i, :, :n].double() + v if mode == 1 else (y0[i, :, :n].double() + v) / 3.0)
+        for flag in ('1', '0'):
+            worst[flag] = max(worst[flag], float((outs[flag][i, :, :n].double() - ref).abs().max()))
+            assert torch.equal(outs[flag][i, :, n:], y0[i, :, n:]), 'positions past the utterance must stay untouched'
+    print(f'k={k} cin={cin} mode={mode}: decomposition max-abs {worst["1"]:.2e}, direct {worst["0"]:.2e}')
+    assert worst["1"] < 5e-5 and worst["0"] < 5e-5
     assert not torch.equal(outs['1'], outs['0'])

@@ -1,0 +1,43 @@
+"""Kernel-level A/B of the fp32 conv kernels on HiFi-GAN's dilation-1 shapes: direct (TTSAMD_WINO=0), Winograd F(2,3) (k = 3) and the
+decomposition kernel (TTSAMD_WINO2 mask).  Run under rocprofv3 --kernel-trace --stats for per-kernel durations; prints wall-clock per call.
+gpurun -- 'python3 tools/wino_bench.py'"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tts-arabic-pytorch_amd'))
+from ttsamd import lib  # noqa: E402
+from ttsamd.engine import _ptr, _stream  # noqa: E402
+
+dev = torch.device('cuda:0')
+L = lib.load()
+B, T = 32, 640
+for C, mul in ((256, 8), (128, 64)):
+    for k in (3, 7, 11):
+        n = T * mul
+        x = torch.randn(B, C, n, device=dev)
+        res = torch.randn(B, C, n, device=dev)
+        w = torch.randn(C, C, k, device=dev) / (C * k) ** 0.5
+        b = torch.zeros(C, device=dev)
+        y = torch.empty_like(x)
+        packed = torch.empty(L.ttsamd_conv1d_packed_floats(C, C, k), dtype=torch.float32, device=dev)
+        for name, env in (('direct', {'TTSAMD_WINO': '0'}), ('wino', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '0'}),
+                          ('wino2', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '7'})):
+            if name == 'wino' and k != 3:
+                continue
+            os.environ.update(env)
+            def call():
+                lib.check(L.ttsamd_conv1d_ex(_ptr(x), _ptr(w), _ptr(b), _ptr(res), None, B, C, C, k, 1, n, 0.1, 0, 0, 1.0, _ptr(y),
+                                             _ptr(packed), _stream()), 'conv1d')
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                call()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 100
+            fl = 2.0 * C * C * k * n * B
+            print(f'C={C} k={k} L={n} {name:7s} {ms:7.3f} ms/call (incl. weight packing)  {fl / ms / 1e9:7.1f} TFLOP/s un-reduced')

@@ -315,25 +315,35 @@ int32_t ttsamd_tagger_forward(void* handle, const int64_t* ids, int32_t batch, i
 }
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {
-    // fp32 packed + bf16 hi/lo planes (+ k = 3: the four Winograd filters, conv_wino.hip)
-    return 2 * (int64_t)cin * k * cout_padded(cout) + (k == 3 ? (int64_t)cin * 4 * cout_padded(cout) : 0);
+    // fp32 packed + bf16 hi/lo planes (+ k = 3 / 7 / 11: the Winograd group filters, conv_wino.hip / conv_wino2.hip)
+    return 2 * (int64_t)cin * k * cout_padded(cout) + ((k == 3 || k == 7 || k == 11) ? (int64_t)cin * wino2_groups(k) * cout_padded(cout) : 0);
 }
 
-// [Cout][Cin][3] -> the Winograd F(2,3) filters in the packed 4-tap layout [cin/8][4][2][cp][4] (same values as pack_wino_weight)
-__global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cout, int cin, int cp, float* __restrict__ out) {
+// [Cout][Cin][k] -> the Winograd group filters in the packed NG-tap layout [cin/8][NG][2][cp][4] (same values as pack_wino2_weight:
+// sub-filter s: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2; single tap t: g_t, -g_t)
+__global__ void pack_wino2_weight_kernel(const float* __restrict__ w, int cout, int cin, int k, int cp, float* __restrict__ out) {
+    const int ns = k / 3, ng = 4 * ns + 2 * (k - 3 * ns);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n = (int64_t)cin * 4 * cp;
+    const int64_t n = (int64_t)cin * ng * cp;
     if (i >= n) return;
     const int pq = (int)(i & 3);
     const int64_t r = i >> 2;
     const int co = (int)(r % cp);
     const int64_t r2 = r / cp;
-    const int kk = (int)(r2 & 1), t = (int)((r2 >> 1) & 3), o = (int)(r2 >> 3);
+    const int kk = (int)(r2 & 1);
+    const int64_t r3 = r2 >> 1;
+    const int t = (int)(r3 % ng), o = (int)(r3 / ng);
     float v = 0.f;
     if (co < cout) {
-        const float* g = w + ((int64_t)co * cin + (8 * o + 2 * pq + kk)) * 3;
-        const double g0 = g[0], g1 = g[1], g2 = g[2];
-        v = t == 0 ? (float)g0 : (t == 1 ? (float)((g0 + g1 + g2) * 0.5) : (t == 2 ? (float)((g0 - g1 + g2) * 0.5) : (float)g2));
+        const float* g = w + ((int64_t)co * cin + (8 * o + 2 * pq + kk)) * k;
+        if (t < 4 * ns) {
+            const int s = t >> 2, j = t & 3;
+            const double g0 = g[3 * s], g1 = g[3 * s + 1], g2 = g[3 * s + 2];
+            v = j == 0 ? (float)g0 : (j == 1 ? (float)((g0 + g1 + g2) * 0.5) : (j == 2 ? (float)((g0 - g1 + g2) * 0.5) : (float)g2));
+        } else {
+            const int l = (t - 4 * ns) >> 1;
+            v = ((t - 4 * ns) & 1) ? -g[3 * ns + l] : g[3 * ns + l];
+        }
     }
     out[i] = v;
 }
@@ -360,10 +370,10 @@ int32_t ttsamd_conv1d_ex(const float* x, const float* w, const float* bias, cons
         TTS_CHECK_HIP(hipGetLastError());
         p.w_bf16 = planes;
     }
-    if (k == 3 && p.precision == 0 && cin % 8 == 0) {
+    if ((k == 3 || k == 7 || k == 11) && p.precision == 0 && cin % 8 == 0) {
         float* wino = packed + 2 * n;
-        const int64_t nw = (int64_t)cin * 4 * cp;
-        hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, cout, cin, cp, wino);
+        const int64_t nw = (int64_t)cin * wino2_groups(k) * cp;
+        hipLaunchKernelGGL(pack_wino2_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, cout, cin, k, cp, wino);
         TTS_CHECK_HIP(hipGetLastError());
         p.w_wino = wino;
     }

@@ -158,6 +158,11 @@ int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const flo
 bool wino_wanted(const ConvParams& p);
 int32_t launch_wino(const ConvParams& p, hipStream_t stream);
 void pack_wino_weight(const float* w, int cout, int cin, float* out);   // out: cin * 4 * cout_padded(cout) floats
+// ... and its generalisation to k = 7 / 11 as sums of F(2,3) sub-filters + single taps (conv_wino2.hip): NG = wino2_groups(k) operand
+// groups per octet, weights [Cin/8][NG][2][CoutP][4] (k = 3: identical to pack_wino_weight)
+int wino2_groups(int k);
+int32_t launch_wino2(const ConvParams& p, hipStream_t stream);
+void pack_wino2_weight(const float* w, int cout, int cin, int k, float* out);   // out: cin * wino2_groups(k) * cout_padded(cout) floats
 // Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]
 void pack_conv_weight(const float* w, int cout, int cin, int k, float* out);
 // torch ConvTranspose1d [Cin][Cout][Kt] (Kt = 2u, stride u, padding p) -> [u][Cin][2][CoutP]

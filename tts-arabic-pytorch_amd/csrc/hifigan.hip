@@ -26,7 +26,7 @@ struct ConvW {
     int64_t w16_off = 0, w_n = 0;  // bf16 planes (hi, lo) in the uint16 blob; packed element count
     int64_t wo_off = -1;           // bf16 octet engine (bfo.hpp): [Cin/16][K][2][CoutP][8] in the same uint16 blob (-1: not packed)
     int64_t wo3_off = -1;          // its split-bf16 mode (bfo3.hpp): [Cin/16][K][2][CoutP][hi 8 | lo 8]
-    int64_t ww_off = -1;           // k = 3: Winograd F(2,3) filters as a 4-tap conv in the fp32 blob (conv_wino.hip; -1: none)
+    int64_t ww_off = -1;           // k = 3 / 7 / 11: Winograd F(2,3) (sub-)filters + single taps as an NG-tap conv in the fp32 blob (conv_wino2.hip; -1: none)
     int cin = 0, cout = 0, k = 0;
 };
 
@@ -205,11 +205,11 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
     blob.resize(blob.size() + (size_t)cin * k * cout_padded(cout));
     pack_conv_weight(w.data(), cout, cin, k, blob.data() + cw.w_off);
     add_bf16(blob, blob16, cw, (int64_t)cin * k * cout_padded(cout));
-    if (k == 3 && cin % 8 == 0 && cout % 128 == 0) {
+    if ((k == 3 || k == 7 || k == 11) && cin % 8 == 0 && cout % 128 == 0) {
         blob.resize(align_up((int64_t)blob.size(), 64));
         cw.ww_off = (int64_t)blob.size();
-        blob.resize(blob.size() + (size_t)cin * 4 * cout_padded(cout));
-        pack_wino_weight(w.data(), cout, cin, blob.data() + cw.ww_off);
+        blob.resize(blob.size() + (size_t)cin * wino2_groups(k) * cout_padded(cout));
+        pack_wino2_weight(w.data(), cout, cin, k, blob.data() + cw.ww_off);
     }
     if (cin % 8 == 0 && cout % 32 == 0) {
         blob16.resize(align_up((int64_t)blob16.size(), 64));
