@@ -110,17 +110,19 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
     assert not torch.equal(outs['1'], outs['0'])
 
 
-@pytest.mark.parametrize('k,cin,cout,L,B,mode', [
-    (3, 256, 256, 1032, 16, None), (3, 1536, 384, 496, 24, 0),
-    (7, 256, 256, 1032, 16, None), (7, 256, 256, 1028, 16, 1), (7, 128, 128, 2052, 16, 2),
-    (11, 256, 256, 1032, 16, None), (11, 256, 256, 1028, 16, 2), (11, 128, 128, 2052, 16, 1), (7, 32, 128, 700, 48, None),
+@pytest.mark.parametrize('k,d,cin,cout,L,B,mode', [
+    (3, 1, 256, 256, 1032, 16, None), (3, 1, 1536, 384, 496, 24, 0),
+    (7, 1, 256, 256, 1032, 16, None), (7, 1, 256, 256, 1028, 16, 1), (7, 1, 128, 128, 2052, 16, 2),
+    (11, 1, 256, 256, 1032, 16, None), (11, 1, 256, 256, 1028, 16, 2), (11, 1, 128, 128, 2052, 16, 1), (7, 1, 32, 128, 700, 48, None),
+    (3, 3, 256, 256, 1032, 16, None), (3, 5, 128, 128, 2052, 16, None), (7, 3, 256, 256, 1028, 16, None), (7, 5, 128, 128, 2052, 16, 1),
+    (11, 3, 128, 128, 2052, 16, None), (11, 5, 256, 256, 1032, 16, None), (11, 5, 256, 256, 1028, 16, 2),
 ])
-def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, cin, cout, L, B, mode):
+def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, mode):
     """conv_wino2.hip: a k-tap filter as k // 3 three-tap F(2,3) sub-filters + k % 3 single taps accumulating into the same four planes
-    (HiFi-GAN's k = 7 / 11 ResBlock convs at dilation 1, vocoder/hifigan/models.py:30-44).  Float64 checker, ragged odd lengths, with
-    and without the residual / accumulate epilogues; the direct kernel beside it."""
+    (HiFi-GAN's ResBlock convs, vocoder/hifigan/models.py:30-44); at dilation d = 3 / 5 the output pair is (q, q + d) and a tile holds
+    120 outputs.  Float64 checker, ragged odd lengths, with and without the residual / accumulate epilogues; the direct kernel beside it."""
     from ttsamd.engine import conv1d
-    g = torch.Generator().manual_seed(k * 1000 + cin + L)
+    g = torch.Generator().manual_seed(k * 1000 + cin + L + d)
     x = torch.randn(B, cin, L, generator=g)
     w = torch.randn(cout, cin, k, generator=g) / np.sqrt(cin * k)
     b = torch.randn(cout, generator=g) * 0.3
@@ -129,23 +131,23 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, cin, cout, L, B, mode
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2], lens[3] = L, L - 1, 131, 1
     outs = {}
-    monkeypatch.setenv('TTSAMD_WINO2', '7')
+    monkeypatch.setenv('TTSAMD_WINO2', '15')
     for flag in ('1', '0'):
         monkeypatch.setenv('TTSAMD_WINO', flag)
         y = y0.clone().to(dev)
-        conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), in_slope=0.1, res=None if res is None else res.to(dev),
+        conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), dilation=d, in_slope=0.1, res=None if res is None else res.to(dev),
                mode=mode or 0, div=3.0, y=y)
         outs[flag] = y.cpu()
     worst = {'1': 0.0, '0': 0.0}
     for i in range(B):
         n = int(lens[i])
-        v = F.conv1d(F.leaky_relu(x[i:i + 1, :, :n].double(), 0.1), w.double(), b.double(), padding=(k - 1) // 2)[0]
+        v = F.conv1d(F.leaky_relu(x[i:i + 1, :, :n].double(), 0.1), w.double(), b.double(), padding=d * (k - 1) // 2, dilation=d)[0]
         if res is not None:
             v = v + res[i, :, :n].double()
         ref = v if not mode else (y0[i, :, :n].double() + v if mode == 1 else (y0[i, :, :n].double() + v) / 3.0)
         for flag in ('1', '0'):
             worst[flag] = max(worst[flag], float((outs[flag][i, :, :n].double() - ref).abs().max()))
             assert torch.equal(outs[flag][i, :, n:], y0[i, :, n:]), 'positions past the utterance must stay untouched'
-    print(f'k={k} cin={cin} mode={mode}: decomposition max-abs {worst["1"]:.2e}, direct {worst["0"]:.2e}')
+    print(f'k={k} d={d} cin={cin} mode={mode}: decomposition max-abs {worst["1"]:.2e}, direct {worst["0"]:.2e}')
     assert worst["1"] < 5e-5 and worst["0"] < 5e-5
     assert not torch.equal(outs['1'], outs['0'])

@@ -51,19 +51,27 @@ __device__ __host__ constexpr int wino2_plane(int g) {
     return g < 4 * (K / 3) ? (g & 3) : (((g - 4 * (K / 3)) & 1) ? 3 : 0);
 }
 
+// outputs per tile at dilation d (see the kernel)
+__device__ __host__ constexpr int wino2_tile(int d) { return d == 1 ? 128 : 120; }
+
 template <int K, int NOCT_, int NSTAGE_, int EPI>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     using G = Wino2Geo<K, NOCT_, NSTAGE_>;
     constexpr int MT = G::MT, WN = G::WN, NS = G::NS, NG = G::NG, NOCT = G::NOCT, NSTAGE = G::NSTAGE;
     constexpr int CO_BLK = G::CO_BLK, NPAIR = G::NPAIR, NT_BLK = G::NT_BLK, NGC = G::NGC, PF = G::PF, NPOS = G::NPOS;
+    // DILATION d: the conv over x[q + (t - pad) d] is the dilation-1 conv of every d-th sample, so the output pair of F(2,3) is
+    // (q, q + d): pair pc of a tile sits at column (pc / d) 2 d + pc % d.  d = 1: 64 pairs = 128 outputs per tile; d = 3 / 5: 60 pairs
+    // = 120 outputs (a multiple of 2 d and of 4: tiles stay float4-aligned), the last four pair slots of the MFMA tile idle (6 %).
+    const int dil = p.dil;
+    const int nt_eff = wino2_tile(dil), npair_eff = nt_eff / 2;
     int b = blockIdx.z;
-    int q0 = blockIdx.x * NT_BLK;
+    int q0 = blockIdx.x * nt_eff;
     if (p.compact) {   // dead blocks last (live_tile, common.hpp)
         int tile = 0;
-        if (!live_tile(p.lens_out, p.len_out_mul, p.Nout, NT_BLK, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        if (!live_tile(p.lens_out, p.len_out_mul, p.Nout, nt_eff, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
         b = __builtin_amdgcn_readfirstlane(b);
-        q0 = __builtin_amdgcn_readfirstlane(tile) * NT_BLK;
+        q0 = __builtin_amdgcn_readfirstlane(tile) * nt_eff;
     }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -85,6 +93,8 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
     if (tid < CO_BLK && p.bias) ep_bias = p.bias[min(co_blk0 + tid, p.Cout - 1)];
 
     const int kk = lane >> 5, l31 = lane & 31;
+    const int pe = wn * 32 + l31;                                           // the pair this lane holds in the accumulators
+    const int col_e = dil == 1 ? 2 * pe : (pe / dil) * 2 * dil + pe % dil;  // ... its first column in the tile (the second: + dil)
     constexpr bool preload = EPI == 3;
     f32x16 acc[4][MT];
 
@@ -111,10 +121,11 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
         if (preload) {                                                                                           \
             const int wm_s = __builtin_amdgcn_readfirstlane(wm);                                                 \
             const int row0 = co_blk0 + wm_s * MT * 32;                                                           \
-            const int q = q0 + 2 * (wn * 32 + l31);                                                              \
-            /* q is even and the rows are float4-aligned, so q + 1 never leaves the row; a pair cut by the utterance end loads one value */ \
-            /* that is never stored */                                                                           \
+            const int q = q0 + col_e;                                                                            \
+            /* a pair cut by the utterance end (or an idle pair slot) loads values that are never stored; past the tensor the range */ \
+            /* check returns zeros */                                                                            \
             const int voff = (q < n_out ? q : 0) * 4;                                                            \
+            const int vd = 4 * dil;                                                                              \
             {                                                                                                    \
                 const int r_cs = p.r_cs;                                                                         \
                 const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res + (int64_t)b * p.r_bs), 0, \
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
                         const int so = (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * r_cs * 4;                      \
                         acc[0][i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + vk, so, 0));      \
-                        acc[3][i][r] = -__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + vk + 4, so, 0)); \
+                        acc[3][i][r] = -__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + vk + vd, so, 0)); \
                     }                                                                                            \
             }                                                                                                    \
             if (p.mode != 0) {                                                                                   \
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
                         const int so = (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * y_cs_ * 4;                     \
                         t0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff + vk, so, 0));     \
-                        t1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff + vk + 4, so, 0)); \
+                        t1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff + vk + vd, so, 0)); \
                     }                                                                                            \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
                         acc[0][i][r] = t0[r] + acc[0][i][r];                                                     \
@@ -149,14 +160,15 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
 
 
     // ---- staging.  X item of thread (h, kks, pc) and octet ol: channels 8 (c NOCT + ol) + 2 (2 h + pp) + kks, pp = 0 / 1, at the
-    // NPOS positions q0 + 2 pc - pad + m, m = 0..K -> components 2 h, 2 h + 1 of the float4 of each of the NG planes at [ol][kks][g][pc].
+    // NPOS positions q0 + col(pc) + (m - pad) d, m = 0..K -> components 2 h, 2 h + 1 of the float4 of each of the NG planes at [ol][kks][g][pc].
     // (h, kks) = the wave index: a wave instruction reads ONE channel row, so the row is the base of a raw buffer descriptor (two
     // scalar adds per row and chunk) of in_len * 4 bytes and the load's range check returns the zeros of the halo: left of
     // position 0 (the negative offset wraps) and right of the utterance.  No clamps, no masks.
     const int sh = __builtin_amdgcn_readfirstlane((tid / (2 * NPAIR)) & 1), skk = __builtin_amdgcn_readfirstlane((tid / NPAIR) & 1);
     const int spc = tid % NPAIR;
     float sx[NOCT][2][NPOS];
-    const int xv0 = (q0 + 2 * spc - pad) * 4;
+    const int spe = min(spc, npair_eff - 1);                   // idle pair slots (d > 1) repeat the last pair: never stored
+    const int xv0 = (q0 + (dil == 1 ? 2 * spe : (spe / dil) * 2 * dil + spe % dil) - pad * dil) * 4, xvd = 4 * dil;
     const int ch_off = (4 * sh + skk) * x_cs;                 // channel 2 (2 h) + kks; pp adds 2 rows, the octet 8
 
     constexpr int NLJ = NOCT * 2 * NPOS;       // load jobs per chunk (one value each), activation jobs DA gaps behind them
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
     {                                                                                                \
         const int ol_ = (J) / (2 * NPOS), pp_ = ((J) / NPOS) % 2, m_ = (J) % NPOS;                   \
         const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + (8 * ol_ + 2 * pp_) * x_cs), (unsigned)in_len * 4u);     \
-        sx[ol_][pp_][m_] = bfo_ld4f(xrs_, xv0 + 4 * m_, 0, 0);                                      \
+        sx[ol_][pp_][m_] = bfo_ld4f(xrs_, xv0 + xvd * m_, 0, 0);                                      \
     }
     // leaky-relu on load, once per value (slopes in [0, 1]: max(x, slope x); slope 1 = the identity, exactly)
 #define TTS_ACT_JOB(J)                                                                               \
@@ -287,7 +299,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
             float2 y2;
             y2.x = acc[0][i][r] + acc[1][i][r] + acc[2][i][r];
             y2.y = acc[1][i][r] - acc[2][i][r] - acc[3][i][r];
-            *reinterpret_cast<float2*>(ep + row * NT_BLK + 2 * (wn * 32 + l31)) = y2;
+            if (pe < npair_eff) {
+                ep[row * NT_BLK + col_e] = y2.x;
+                ep[row * NT_BLK + col_e + dil] = y2.y;
+            }
         }
     __syncthreads();
     constexpr int RPI = LPR >= 64 ? 1 : 64 / LPR;                       // rows per wave instruction
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
             for (int cg = 0; cg < CPL; ++cg) {
                 const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
                 const int q = q0 + col;
-                if (q >= n_out) continue;
+                if (q >= n_out || col >= nt_eff) continue;
                 const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
                 float v[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
             for (int cg = 0; cg < CPL; ++cg) {
                 const int col = ((LPR >= 64 ? lane : lane % LPR) + 64 * cg) * 4;
                 const int q = q0 + col;
-                if (q >= n_out) continue;
+                if (q >= n_out || col >= nt_eff) continue;
                 const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
                 float v[4] = {a4.x, a4.y, a4.z, a4.w};
                 float* yp = yb + (int64_t)co * p.y_cs + q;
@@ -396,7 +411,8 @@ static int32_t launch_wino2_epi(const ConvParams& q, dim3 grid, hipStream_t stre
 template <int K, int NOCT, int NSTAGE>
 static int32_t launch_wino2_cfg(const ConvParams& p, hipStream_t stream) {
     using G = Wino2Geo<K, NOCT, NSTAGE>;
-    dim3 grid((p.Nout + G::NT_BLK - 1) / G::NT_BLK, p.CoutP / G::CO_BLK, p.batch);
+    const int nt = wino2_tile(p.dil);
+    dim3 grid((p.Nout + nt - 1) / nt, p.CoutP / G::CO_BLK, p.batch);
     ConvParams q = p;
     q.ksplit = 1;
     q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
