@@ -752,12 +752,22 @@ def main():
                 'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
-                    'kernel': ('MFMA conv engine: conv1d_mfma_f32 + conv1d_wino_f32 (Winograd F(2,3), k = 3 dilation-1 launches) + resblock_pair + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
+                    'kernel': ('MFMA conv engine: conv1d_wino2_f32 (Winograd F(2,3) decomposition, k = 3 / 7 / 11, C >= 128) + conv1d_mfma_f32 + resblock_pair2 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
             if args.precision == 'f32':
-                roof['flops_basis'] = ('UN-REDUCED algorithmic FLOPs (2 Cout Cin K per valid output position).  The Winograd F(2,3) launches '
-                                       '(FastPitch conv-FF, HiFi-GAN C = 128 / 256 k = 3 dilation-1 convs: 1.1 of the 9.5 TFLOP of a step) issue 2/3 '
-                                       'of those as MFMAs; TTSAMD_WINO=0 runs the direct kernels (profiles/r5/wino_off_bench_line.json)')
+                # products the Winograd launches do NOT issue (conv_wino2.hip: k = 3 / 7 / 11 as F(2,3) sub-filters + single taps: 4/6,
+                # 10/14, 16/22 of the direct conv's): every ResBlock conv of HiFi-GAN's C >= 128 stages, FastPitch's decoder conv-FF
+                saved = args.steps * (hifigan_wino_saved_flops_per_frame(HC) * frames +
+                                      NC['out_fft_n_layers'] * 2.0 * NC['symbols_embedding_dim'] * NC['out_fft_conv1d_filter_size'] *
+                                      NC['out_fft_conv1d_kernel_size'] * 2 / 3.0 * (frames + B)) if wino_on() else 0.0
+                issued = (flops - saved) / (max(conv_ms, 1e-9) * 1e-3) / 1e12
+                roof['issued'] = issued
+                roof['frac_issued'] = issued / peak
+                roof['flops_basis'] = ('`achieved` / `frac`: UN-REDUCED algorithmic FLOPs (2 Cout Cin K per valid output position) over kernel time.  '
+                                       '`issued` / `frac_issued`: the same minus the products the Winograd F(2,3) launches do not issue (k = 3 / 7 / 11 '
+                                       'convs as three-tap sub-filters + single taps: 4/6, 10/14, 16/22 of the direct products; HiFi-GAN C = 128 / 256 '
+                                       'ResBlock convs at every dilation, FastPitch decoder conv-FF) = what the MFMA pipe executed against its peak.  '
+                                       'TTSAMD_WINO=0 runs the direct kernels (profiles/r5/wino_off_bench_line.json)')
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
                      'traffic_algorithmic': traffic_alg, 'traffic_ratio': (traffic / traffic_alg) if (traffic and traffic_alg) else None,
                      'launches': int(n_launch), 'sections': int(n_sections),
@@ -1135,6 +1145,25 @@ def hifigan_flops_per_frame(h):
         for kk, dil in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
             f += len(dil) * 2 * (2.0 * ch * ch * kk) * mul
     return f
+
+
+def hifigan_wino_saved_flops_per_frame(h):
+    """Products per mel frame that the Winograd decomposition (csrc/conv_wino2.hip) does not issue: ResBlock convs of the stages with
+    >= 128 channels, kernel sizes 3 / 7 / 11 (4/6, 10/14, 16/22 of the direct conv's products)."""
+    ch, mul, f = h['upsample_initial_channel'], 1, 0.0
+    for u in h['upsample_rates']:
+        ch, mul = ch // 2, mul * u
+        if ch < 128:
+            continue
+        for kk, dil in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+            ng = 4 * (kk // 3) + 2 * (kk % 3)
+            if kk in (3, 7, 11):
+                f += len(dil) * 2 * (2.0 * ch * ch * kk) * mul * (1.0 - ng / (2.0 * kk))
+    return f
+
+
+def wino_on():
+    return os.environ.get('TTSAMD_WINO', '1') != '0' and os.environ.get('TTSAMD_WINO2', '15') == '15'
 
 
 def fastpitch_conv_flops_per_pos(c):
