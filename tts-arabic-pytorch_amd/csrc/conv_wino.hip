@@ -424,7 +424,9 @@ bool wino_wanted(const ConvParams& p) {
     const char* e = getenv("TTSAMD_WINO");                      // 0: the direct kernel (A/B runs, parity tests of both)
     if (e && e[0] == '0') return false;
     const int64_t blocks = (int64_t)((p.Nout + 127) / 128) * (p.CoutP / 128) * p.batch;
-    return blocks >= 256 && p.Nout >= 256;       // (short sequences -- FastPitch's 64-token encoder -- would leave half of a 128-output tile empty)
+    // under ~3/4 of a block per CU the direct kernel's 64 x 64 tiles with split K fill the chip better (batch 1: 3.68 ms per step with
+    // the limit at 200, 3.74 at 100, 3.9-4.0 at 50 / 1 and with the Winograd kernels off; batch 4: 10.0 vs 10.5-11.0: tools/ab_small.sh)
+    return blocks >= 192 && p.Nout >= 256;       // (short sequences -- FastPitch's 64-token encoder -- would leave half of a 128-output tile empty)
 }
 
 template <int MT, int WM, int WN>
