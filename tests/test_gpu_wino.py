@@ -116,6 +116,9 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
     (11, 1, 256, 256, 1032, 16, None), (11, 1, 256, 256, 1028, 16, 2), (11, 1, 128, 128, 2052, 16, 1), (7, 1, 32, 128, 700, 48, None),
     (3, 3, 256, 256, 1032, 16, None), (3, 5, 128, 128, 2052, 16, None), (7, 3, 256, 256, 1028, 16, None), (7, 5, 128, 128, 2052, 16, 1),
     (11, 3, 128, 128, 2052, 16, None), (11, 5, 256, 256, 1032, 16, None), (11, 5, 256, 256, 1028, 16, 2),
+    # Cout = 64: the 64-row x 128-pair variant (k = 11 in two phases of 8 groups); 252- / 240-output tiles at dilation 3 / 5
+    (3, 1, 64, 64, 4100, 12, 1), (3, 3, 64, 64, 4100, 12, None), (7, 1, 64, 64, 4100, 12, 2), (7, 5, 64, 64, 4100, 12, None),
+    (11, 1, 64, 64, 4100, 12, None), (11, 3, 64, 64, 4100, 12, 1), (11, 5, 64, 64, 4100, 12, 2), (11, 1, 128, 64, 4100, 12, 0),
 ])
 def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, mode):
     """conv_wino2.hip: a k-tap filter as k // 3 three-tap F(2,3) sub-filters + k % 3 single taps accumulating into the same four planes
@@ -131,7 +134,7 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, m
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2], lens[3] = L, L - 1, 131, 1
     outs = {}
-    monkeypatch.setenv('TTSAMD_WINO2', '15')
+    monkeypatch.setenv('TTSAMD_WINO2', '31')
     for flag in ('1', '0'):
         monkeypatch.setenv('TTSAMD_WINO', flag)
         y = y0.clone().to(dev)

@@ -14,7 +14,7 @@ from ttsamd.engine import _ptr, _stream  # noqa: E402
 dev = torch.device('cuda:0')
 L = lib.load()
 B, T = 32, 640
-for C, mul in ((256, 8), (128, 64)):
+for C, mul in ((256, 8), (128, 64), (64, 128)):
     for k in (3, 7, 11):
         n = T * mul
         x = torch.randn(B, C, n, device=dev)
@@ -24,8 +24,8 @@ for C, mul in ((256, 8), (128, 64)):
         y = torch.empty_like(x)
         packed = torch.empty(L.ttsamd_conv1d_packed_floats(C, C, k), dtype=torch.float32, device=dev)
         for name, env in (('direct', {'TTSAMD_WINO': '0'}), ('wino', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '0'}),
-                          ('wino2', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '7'})):
-            if name == 'wino' and k != 3:
+                          ('wino2', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '31'})):
+            if name == 'wino' and (k != 3 or C == 64):
                 continue
             os.environ.update(env)
             def call():

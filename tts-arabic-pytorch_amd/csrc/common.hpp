@@ -161,6 +161,7 @@ void pack_wino_weight(const float* w, int cout, int cin, float* out);   // out: 
 // ... and its generalisation to k = 7 / 11 as sums of F(2,3) sub-filters + single taps (conv_wino2.hip): NG = wino2_groups(k) operand
 // groups per octet, weights [Cin/8][NG][2][CoutP][4] (k = 3: identical to pack_wino_weight)
 int wino2_groups(int k);
+int wino2_block_outputs(int coutp, int dil);     // outputs per block of the kernel launch_wino2 picks
 int32_t launch_wino2(const ConvParams& p, hipStream_t stream);
 void pack_wino2_weight(const float* w, int cout, int cin, int k, float* out);   // out: cin * wino2_groups(k) * cout_padded(cout) floats
 // Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]

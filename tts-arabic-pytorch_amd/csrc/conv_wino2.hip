@@ -27,22 +27,44 @@
 namespace ttsamd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int K, int NOCT_, int NSTAGE_>
+template <int K, int NOCT_, int NSTAGE_, int WM_, int NPH_>
 struct Wino2Geo {
-    static constexpr int MT = 2, WM = 2, WN = 2;
+    static constexpr int MT = 2, WM = WM_, WN = 4 / WM_;      // 2 x 2 waves: 128 rows x 64 pairs;  1 x 4: 64 rows x 128 pairs (Cout = 64)
     static constexpr int NS = K / 3, NL = K - 3 * NS, NG = 4 * NS + 2 * NL;   // sub-filters, single taps, operand groups per octet
     static constexpr int NOCT = NOCT_, NSTAGE = NSTAGE_;
-    static constexpr int CO_BLK = WM * MT * 32;               // 128
-    static constexpr int NPAIR = WN * 32;                     // 64 output pairs per block
-    static constexpr int NT_BLK = 2 * NPAIR;                  // 128 outputs per block
-    static constexpr int BUF4 = NOCT * 2 * NG * NPAIR;        // float4s per stage: [octet][kk][group][pair]
-    static constexpr int NGC = NOCT * NG;                     // operand groups per chunk
+    // PHASES: an octet's NG groups in NPH steps of NGP groups, each with its own LDS stage (k = 11 at 128 pairs: 2 x 8 groups, a stage
+    // of all 16 would be 64 KB); a phase stages only the positions its groups touch
+    static constexpr int NPH = NPH_, NGP = NG / NPH_;
+    static constexpr int CO_BLK = WM * MT * 32;
+    static constexpr int NPAIR = WN * 32;                     // output pairs per block
+    static constexpr int NHALF = NPAIR / 64;                  // 64-pair halves a staging thread covers
+    static constexpr int NT_BLK = 2 * NPAIR;                  // outputs per block (dilation 1)
+    static constexpr int BUF4 = NOCT * 2 * NGP * NPAIR;       // float4s per stage: [octet][kk][group of the phase][pair]
+    static constexpr int NGC = NOCT * NGP;                    // operand groups per step
     static constexpr int PF = 2;                              // weight groups in flight ahead of the one being multiplied
-    static constexpr int NPOS = K + 1;                        // input positions a pair touches
-    static_assert(NGC % PF == 0, "queue slots line up across chunks");
+    static constexpr int NM = 4 * MT;                         // MFMAs per operand group
+    static constexpr int NGAP = NGC * NM;                     // gaps (one per MFMA) per step
+    static constexpr int DA = 2 * NM;                         // a value is activated 16 MFMAs (~1000 cycles) after its load was issued
+    // first / last input position (0..K) of the groups [g_lo, g_hi] a phase holds
+    __host__ __device__ static constexpr int gpos(int g, bool last) {
+        return g < 4 * NS ? 3 * (g / 4) + (last ? 3 : 0) : 3 * NS + (g - 4 * NS) / 2 + (last ? 1 : 0);
+    }
+    __host__ __device__ static constexpr int glo(int ph) { return ph * NGP; }
+    __host__ __device__ static constexpr int mlo(int ph) { return gpos(ph * NGP, false); }
+    __host__ __device__ static constexpr int npos(int ph) { return gpos(ph * NGP + NGP - 1, true) - mlo(ph) + 1; }
+    static constexpr int NPOSP = npos(0) > npos(NPH - 1) ? npos(0) : npos(NPH - 1);
+    __host__ __device__ static constexpr int nlj(int ph) { return NOCT * 2 * NHALF * npos(ph); }      // load jobs (one value each) of a phase
+    static constexpr int NWJ = NGC * NHALF;                   // write jobs (one plane of one half each)
+    static constexpr int LPG = 3 * (NOCT * 2 * NHALF * NPOSP) > NGAP ? 2 : 1;                          // loads per gap
+    __host__ __device__ static constexpr int tw0(int ph) { return (nlj(ph) + LPG - 1) / LPG + DA; }    // first gap with every value activated
+    __host__ __device__ static constexpr int ws(int ph) { return (NGAP - tw0(ph)) / NWJ; }             // one plane write every ws gaps after it
+    static_assert(NG % NPH == 0 && (NPH == 1 || (NOCT == 1 && (NGP % 4 == 0))), "phases split at sub-filter boundaries");
+    static_assert(NGC % PF == 0, "queue slots line up across steps");
+    static_assert(ws(0) >= 1 && ws(NPH - 1) >= 1, "one write job per gap at most");
     static_assert((size_t)NSTAGE * BUF4 * 16 <= 80 * 1024, "two blocks per CU");
-    static_assert(4 * NPAIR == 256, "one X item per thread and octet");
+    static_assert(NPH == 1 || NSTAGE == 2, "phases alternate between two stages");
 };
 
 // plane (accumulator) a group feeds: (s, i) -> i;  single tap l: its y[2j] half -> 0, its y[2j + 1] half -> 3
@@ -51,20 +73,21 @@ __device__ __host__ constexpr int wino2_plane(int g) {
     return g < 4 * (K / 3) ? (g & 3) : (((g - 4 * (K / 3)) & 1) ? 3 : 0);
 }
 
-// outputs per tile at dilation d (see the kernel)
-__device__ __host__ constexpr int wino2_tile(int d) { return d == 1 ? 128 : 120; }
+// outputs per tile at dilation d (see the kernel): the largest multiple of 2 d and of 4 in 2 * npair
+__device__ __host__ constexpr int wino2_tile(int d, int npair) { return (2 * npair / ((d & 1) ? 4 * d : 2 * d)) * ((d & 1) ? 4 * d : 2 * d); }
 
-template <int K, int NOCT_, int NSTAGE_, int EPI>
+template <int K, int NOCT_, int NSTAGE_, int WM_, int NPH_, int EPI>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
-    using G = Wino2Geo<K, NOCT_, NSTAGE_>;
+    using G = Wino2Geo<K, NOCT_, NSTAGE_, WM_, NPH_>;
     constexpr int MT = G::MT, WN = G::WN, NS = G::NS, NG = G::NG, NOCT = G::NOCT, NSTAGE = G::NSTAGE;
-    constexpr int CO_BLK = G::CO_BLK, NPAIR = G::NPAIR, NT_BLK = G::NT_BLK, NGC = G::NGC, PF = G::PF, NPOS = G::NPOS;
+    constexpr int CO_BLK = G::CO_BLK, NPAIR = G::NPAIR, NT_BLK = G::NT_BLK, NGC = G::NGC, PF = G::PF;
+    constexpr int NHALF = G::NHALF, NGP = G::NGP, NPH = G::NPH, NPOSP = G::NPOSP, NM = G::NM, DA = G::DA, LPG = G::LPG, NWJ = G::NWJ;
     // DILATION d: the conv over x[q + (t - pad) d] is the dilation-1 conv of every d-th sample, so the output pair of F(2,3) is
-    // (q, q + d): pair pc of a tile sits at column (pc / d) 2 d + pc % d.  d = 1: 64 pairs = 128 outputs per tile; d = 3 / 5: 60 pairs
-    // = 120 outputs (a multiple of 2 d and of 4: tiles stay float4-aligned), the last four pair slots of the MFMA tile idle (6 %).
+    // (q, q + d): pair pc of a tile sits at column (pc / d) 2 d + pc % d.  d = 1: every pair slot = 128 (256) outputs per tile; d = 3 /
+    // 5: 120 (252 / 240) outputs (a multiple of 2 d and of 4: tiles stay float4-aligned), the last pair slots of the MFMA tile idle.
     const int dil = p.dil;
-    const int nt_eff = wino2_tile(dil), npair_eff = nt_eff / 2;
+    const int nt_eff = wino2_tile(dil, NPAIR), npair_eff = nt_eff / 2;
     int b = blockIdx.z;
     int q0 = blockIdx.x * nt_eff;
     if (p.compact) {   // dead blocks last (live_tile, common.hpp)
@@ -159,123 +182,141 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
     }
 
 
-    // ---- staging.  X item of thread (h, kks, pc) and octet ol: channels 8 (c NOCT + ol) + 2 (2 h + pp) + kks, pp = 0 / 1, at the
-    // NPOS positions q0 + col(pc) + (m - pad) d, m = 0..K -> components 2 h, 2 h + 1 of the float4 of each of the NG planes at [ol][kks][g][pc].
+    // ---- staging.  X item of thread (h, kks, pc), octet ol and 64-pair half hf: channels 8 (c NOCT + ol) + 2 (2 h + pp) + kks, pp = 0 / 1,
+    // at the positions q0 + col(pc + 64 hf) + (m - pad) d, m = the phase's window -> components 2 h, 2 h + 1 of the float4 of each
+    // plane of the phase at [ol][kks][g][pc + 64 hf].
     // (h, kks) = the wave index: a wave instruction reads ONE channel row, so the row is the base of a raw buffer descriptor (two
     // scalar adds per row and chunk) of in_len * 4 bytes and the load's range check returns the zeros of the halo: left of
     // position 0 (the negative offset wraps) and right of the utterance.  No clamps, no masks.
-    const int sh = __builtin_amdgcn_readfirstlane((tid / (2 * NPAIR)) & 1), skk = __builtin_amdgcn_readfirstlane((tid / NPAIR) & 1);
-    const int spc = tid % NPAIR;
-    float sx[NOCT][2][NPOS];
-    const int spe = min(spc, npair_eff - 1);                   // idle pair slots (d > 1) repeat the last pair: never stored
-    const int xv0 = (q0 + (dil == 1 ? 2 * spe : (spe / dil) * 2 * dil + spe % dil) - pad * dil) * 4, xvd = 4 * dil;
+    const int sh = __builtin_amdgcn_readfirstlane((tid >> 7) & 1), skk = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);
+    f32x2 sx[NOCT][NHALF][NPOSP];                            // [pp] = the two channels of the item, packed: one v_pk_add_f32 per plane
+    int xv0[NHALF];
+#pragma unroll
+    for (int hf = 0; hf < NHALF; ++hf) {
+        const int spe = min(lane + 64 * hf, npair_eff - 1);    // idle pair slots (d > 1) repeat the last pair: never stored
+        xv0[hf] = (q0 + (dil == 1 ? 2 * spe : (spe / dil) * 2 * dil + spe % dil) - pad * dil) * 4;
+    }
+    const int xvd = 4 * dil;
     const int ch_off = (4 * sh + skk) * x_cs;                 // channel 2 (2 h) + kks; pp adds 2 rows, the octet 8
 
-    constexpr int NLJ = NOCT * 2 * NPOS;       // load jobs per chunk (one value each), activation jobs DA gaps behind them
-    constexpr int NWJ = NGC;                   // write jobs per chunk (one plane each)
-    constexpr int NM = 4 * MT;                 // MFMAs per operand group
-    constexpr int NGAP = NGC * NM;             // gaps (one per MFMA) per chunk
-    constexpr int DA = 2 * NM;                 // a value is activated 16 MFMAs (~1000 cycles) after its load was issued
-    constexpr int TW0 = NLJ + DA;              // first gap with every value of the chunk activated
-    constexpr int WS = (NGAP - TW0) / NWJ;     // the plane writes are spread over the rest of the chunk, one every WS gaps
-    static_assert(WS >= 1, "one job of a kind per gap");
-#define TTS_LOAD_JOB(J, XSO)                                                                         \
+    // load job J of phase PH -> (octet, half, position, pp): the two channels of a value pair in consecutive jobs
+#define TTS_JOB_IDX(PH, J)                                                                           \
+        const int np_ = G::npos(PH);                                                                 \
+        const int ol_ = (J) / (2 * NHALF * np_), hf_ = ((J) / (2 * np_)) % NHALF, mi_ = ((J) / 2) % np_, pp_ = (J) % 2;
+#define TTS_LOAD_JOB(PH, J, XSO)                                                                     \
     {                                                                                                \
-        const int ol_ = (J) / (2 * NPOS), pp_ = ((J) / NPOS) % 2, m_ = (J) % NPOS;                   \
+        TTS_JOB_IDX(PH, J)                                                                           \
         const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + (8 * ol_ + 2 * pp_) * x_cs), (unsigned)in_len * 4u);     \
-        sx[ol_][pp_][m_] = bfo_ld4f(xrs_, xv0 + xvd * m_, 0, 0);                                      \
+        sx[ol_][hf_][mi_][pp_] = bfo_ld4f(xrs_, xv0[hf_] + xvd * (G::mlo(PH) + mi_), 0, 0);         \
     }
-    // leaky-relu on load, once per value (slopes in [0, 1]: max(x, slope x); slope 1 = the identity, exactly)
-#define TTS_ACT_JOB(J)                                                                               \
-    {                                                                                                \
-        const int ol_ = (J) / (2 * NPOS), pp_ = ((J) / NPOS) % 2, m_ = (J) % NPOS;                   \
-        sx[ol_][pp_][m_] = fmaxf(sx[ol_][pp_][m_], sx[ol_][pp_][m_] * in_slope);                     \
+    // leaky-relu on load, once per value pair, after its second load (slopes in [0, 1]: max(x, slope x); slope 1 = the identity, exactly)
+#define TTS_ACT_JOB(PH, J)                                                                           \
+    if ((J) & 1) {                                                                                   \
+        TTS_JOB_IDX(PH, J)                                                                           \
+        (void)pp_;                                                                                   \
+        const f32x2 w_ = sx[ol_][hf_][mi_] * in_slope;                                               \
+        sx[ol_][hf_][mi_].x = fmaxf(sx[ol_][hf_][mi_].x, w_.x);                                      \
+        sx[ol_][hf_][mi_].y = fmaxf(sx[ol_][hf_][mi_].y, w_.y);                                      \
     }
     // plane g of octet ol from the staged values: (s, i) -> the F(2,3) input transform of positions 3 s + {0..3}; single tap l ->
-    // the value at position 3 NS + l (for y[2j]) or 3 NS + l + 1 (for y[2j + 1])
-#define TTS_WRITE_JOB(J, WR)                                                                         \
+    // the value at position 3 NS + l (for y[2j]) or 3 NS + l + 1 (for y[2j + 1]).  Job J -> (octet, group of the phase, half)
+#define TTS_SX(M) sx[ol_][hf_][(M) - G::mlo(PH_)]
+#define TTS_WRITE_JOB(PH, J, WR)                                                                     \
     {                                                                                                \
-        const int ol_ = (J) / NG, g_ = (J) % NG;                                                     \
-        float2 v2;                                                                                   \
+        const int PH_ = (PH);                                                                        \
+        const int hf_ = (J) % NHALF, ol_ = ((J) / NHALF) / NGP, gl_ = ((J) / NHALF) % NGP, g_ = G::glo(PH_) + gl_;   \
+        f32x2 v2;                                                                                    \
         if (g_ < 4 * NS) {                                                                           \
             const int s3 = 3 * (g_ / 4), i_ = g_ % 4;                                                \
-            if (i_ == 0) { v2.x = sx[ol_][0][s3] - sx[ol_][0][s3 + 2]; v2.y = sx[ol_][1][s3] - sx[ol_][1][s3 + 2]; }                 \
-            else if (i_ == 1) { v2.x = sx[ol_][0][s3 + 1] + sx[ol_][0][s3 + 2]; v2.y = sx[ol_][1][s3 + 1] + sx[ol_][1][s3 + 2]; }    \
-            else if (i_ == 2) { v2.x = sx[ol_][0][s3 + 2] - sx[ol_][0][s3 + 1]; v2.y = sx[ol_][1][s3 + 2] - sx[ol_][1][s3 + 1]; }    \
-            else { v2.x = sx[ol_][0][s3 + 1] - sx[ol_][0][s3 + 3]; v2.y = sx[ol_][1][s3 + 1] - sx[ol_][1][s3 + 3]; }                 \
+            if (i_ == 0) v2 = TTS_SX(s3) - TTS_SX(s3 + 2);                                           \
+            else if (i_ == 1) v2 = TTS_SX(s3 + 1) + TTS_SX(s3 + 2);                                  \
+            else if (i_ == 2) v2 = TTS_SX(s3 + 2) - TTS_SX(s3 + 1);                                  \
+            else v2 = TTS_SX(s3 + 1) - TTS_SX(s3 + 3);                                               \
         } else {                                                                                     \
-            const int m_ = 3 * NS + (g_ - 4 * NS) / 2 + ((g_ - 4 * NS) & 1);                         \
-            v2.x = sx[ol_][0][m_]; v2.y = sx[ol_][1][m_];                                            \
+            v2 = TTS_SX(3 * NS + (g_ - 4 * NS) / 2 + ((g_ - 4 * NS) & 1));                           \
         }                                                                                            \
-        (WR)[2 * ((ol_ * 2 * NG + g_) * NPAIR)] = v2;                                                \
+        (WR)[2 * ((ol_ * 2 * NGP + gl_) * NPAIR + 64 * hf_)] = v2;                                   \
     }
 
-    const float4* sB = smem4 + kk * NG * NPAIR + wn * 32 + l31;       // + stage * BUF4 + (ol * 2 NG + g) * NPAIR
-    float2* sW = reinterpret_cast<float2*>(smem4 + skk * NG * NPAIR + spc) + sh;     // + 2 (stage * BUF4 + (ol * 2 NG + g) * NPAIR)
+    const float4* sB = smem4 + kk * NGP * NPAIR + wn * 32 + l31;      // + stage * BUF4 + (ol * 2 NGP + g) * NPAIR
+    f32x2* sW = reinterpret_cast<f32x2*>(smem4 + skk * NGP * NPAIR + lane) + sh;    // + 2 (stage * BUF4 + (ol * 2 NGP + g) * NPAIR + 64 hf)
     float4 bq[2];
 
-    // prologue: fill NSTAGE - 1 stages, fetch the first B operand
+    // prologue: fill NSTAGE - 1 stages (steps 0 .. NSTAGE - 2: phase st % NPH of chunk st / NPH), fetch the first B operand
     {
 #pragma unroll
         for (int st = 0; st < NSTAGE - 1; ++st) {
-            const int xso = min(st, n_chunks - 1) * 8 * NOCT * x_cs;
+            const int ph = st % NPH;
+            const int xso = min(st / NPH, n_chunks - 1) * 8 * NOCT * x_cs;
 #pragma unroll
-            for (int J = 0; J < NLJ; ++J) TTS_LOAD_JOB(J, xso)
+            for (int J = 0; J < G::nlj(ph); ++J) TTS_LOAD_JOB(ph, J, xso)
             if (st == 0) TTS_INIT_ACC()
 #pragma unroll
-            for (int J = 0; J < NLJ; ++J) TTS_ACT_JOB(J)
-            float2* wr = sW + 2 * st * G::BUF4;
+            for (int J = 0; J < G::nlj(ph); ++J) TTS_ACT_JOB(ph, J)
+            f32x2* wr = sW + 2 * st * G::BUF4;
 #pragma unroll
-            for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(J, wr)
+            for (int J = 0; J < NWJ; ++J) TTS_WRITE_JOB(ph, J, wr)
         }
     }
     __syncthreads();
     bq[0] = sB[0];
 
-    int stage = 0;  // c % NSTAGE
+    int stage = 0;  // step % NSTAGE
     for (int c = 0; c < n_chunks; ++c) {
-        const int cl = min(c + NSTAGE - 1, n_chunks - 1);       // tail: the last chunk is re-staged into a dead stage (branch-free body)
-        const int xso = cl * 8 * NOCT * x_cs;
-        const int stage_next = (stage + 1 == NSTAGE) ? 0 : stage + 1;
-        const int stage_fill = (stage == 0) ? NSTAGE - 1 : stage - 1;
-        float2* wr = sW + 2 * stage_fill * G::BUF4;
-        const float4* rd = sB + stage * G::BUF4;
-        const int sn = (c + 1 < n_chunks) ? stage_next : stage;
 #pragma unroll
-        for (int g = 0; g < NGC; ++g) {
-            const int cur = g & 1, nxt = cur ^ 1;
-            f32x4 a4[MT];
+        for (int ph = 0; ph < NPH; ++ph) {
+            // the step being staged: NSTAGE - 1 ahead (tail: the last chunk is re-staged into a dead stage -- branch-free body)
+            const int tph = (ph + NSTAGE - 1) % NPH;
+            const int xso = min(c + (ph + NSTAGE - 1) / NPH, n_chunks - 1) * 8 * NOCT * x_cs;
+            const int stage_next = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+            const int stage_fill = (stage == 0) ? NSTAGE - 1 : stage - 1;
+            f32x2* wr = sW + 2 * stage_fill * G::BUF4;
+            const float4* rd = sB + stage * G::BUF4;
+            const int sn = (c + 1 < n_chunks || ph + 1 < NPH) ? stage_next : stage;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a4[mt] = aq[g % PF][mt];
-            // refill the queue slot with the group PF ahead
+            for (int g = 0; g < NGC; ++g) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                const int plane = wino2_plane<K>(G::glo(ph) + g % NGP);
+                f32x4 a4[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) aq[g % PF][mt] = __builtin_bit_cast(f32x4, bfo_ld16(wrs, wv + 32 * 16 * mt, wso, 0));
-            wso = min(wso + wstep, wlast);
-            // B operand of the next group: same stage, or (three stages) the first group of the next chunk's stage
-            if (g + 1 < NGC) bq[nxt] = rd[(((g + 1) / NG) * 2 * NG + (g + 1) % NG) * NPAIR];
-            else if (NSTAGE >= 3) bq[nxt] = sB[sn * G::BUF4];
-            __builtin_amdgcn_sched_barrier(0);
-            const float bv[4] = {bq[cur].x, bq[cur].y, bq[cur].z, bq[cur].w};
+                for (int mt = 0; mt < MT; ++mt) a4[mt] = aq[g % PF][mt];
+                // refill the queue slot with the group PF ahead
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const int pq = m / MT, i = m % MT;
-                acc[wino2_plane<K>(g % NG)][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][pq], bv[pq], acc[wino2_plane<K>(g % NG)][i], 0, 0, 0);
-                // ---- gap work for chunk c + NSTAGE - 1: one load per gap first, each value activated DA gaps later, then the plane
-                // writes into the stage the previous chunk has left
-                const int t = g * NM + m;
-                if (t < NLJ) TTS_LOAD_JOB(t, xso)
-                if (t >= DA && t - DA < NLJ) TTS_ACT_JOB(t - DA)
-                if (t >= TW0 && (t - TW0) % WS == 0 && (t - TW0) / WS < NWJ) TTS_WRITE_JOB((t - TW0) / WS, wr)
+                for (int mt = 0; mt < MT; ++mt) aq[g % PF][mt] = __builtin_bit_cast(f32x4, bfo_ld16(wrs, wv + 32 * 16 * mt, wso, 0));
+                wso = min(wso + wstep, wlast);
+                // B operand of the next group: same stage, or (three stages) the first group of the next step's stage
+                if (g + 1 < NGC) bq[nxt] = rd[(((g + 1) / NGP) * 2 * NGP + (g + 1) % NGP) * NPAIR];
+                else if (NSTAGE >= 3) bq[nxt] = sB[sn * G::BUF4];
                 __builtin_amdgcn_sched_barrier(0);
+                const float bv[4] = {bq[cur].x, bq[cur].y, bq[cur].z, bq[cur].w};
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int pq = m / MT, i = m % MT;
+                    acc[plane][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][pq], bv[pq], acc[plane][i], 0, 0, 0);
+                    // ---- gap work for the step NSTAGE - 1 ahead: LPG loads per gap first, each value activated DA gaps later, then
+                    // the plane writes into the stage the previous step has left
+                    const int t = g * NM + m;
+#pragma unroll
+                    for (int u = 0; u < LPG; ++u)
+                        if (t * LPG + u < G::nlj(tph)) TTS_LOAD_JOB(tph, t * LPG + u, xso)
+#pragma unroll
+                    for (int u = 0; u < LPG; ++u)
+                        if (t >= DA && (t - DA) * LPG + u < G::nlj(tph)) TTS_ACT_JOB(tph, (t - DA) * LPG + u)
+                    if (t >= G::tw0(tph) && (t - G::tw0(tph)) % G::ws(tph) == 0 && (t - G::tw0(tph)) / G::ws(tph) < NWJ)
+                        TTS_WRITE_JOB(tph, (t - G::tw0(tph)) / G::ws(tph), wr)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            __syncthreads();
+            if (NSTAGE < 3) bq[0] = sB[sn * G::BUF4];            // two stages: the next step's stage has only just been written
+            stage = stage_next;
         }
-        __syncthreads();
-        if (NSTAGE < 3) bq[0] = sB[sn * G::BUF4];            // two stages: the next chunk's stage has only just been written
-        stage = stage_next;
     }
 #undef TTS_INIT_ACC
 #undef TTS_LOAD_JOB
 #undef TTS_ACT_JOB
+#undef TTS_JOB_IDX
+#undef TTS_SX
 #undef TTS_WRITE_JOB
 
     // ---- epilogue: output transform, then the row epilogue of conv_mfma.hip (bias, residual, ReLU, accumulate modes)
@@ -393,41 +434,50 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino2_f32(const Conv
 }
 
 
-template <int K, int NOCT, int NSTAGE, int EPI>
+template <int K, int NOCT, int NSTAGE, int WM, int NPH, int EPI>
 static int32_t launch_wino2_epi(const ConvParams& q, dim3 grid, hipStream_t stream) {
-    using G = Wino2Geo<K, NOCT, NSTAGE>;
+    using G = Wino2Geo<K, NOCT, NSTAGE, WM, NPH>;
     constexpr size_t ring = (size_t)G::NSTAGE * G::BUF4 * sizeof(float4);
     constexpr size_t epi = ((size_t)G::CO_BLK * G::NT_BLK + G::CO_BLK) * sizeof(float);
     constexpr size_t lds = ring > epi ? ring : epi;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static std::atomic<uint64_t> lds_done{0};
-    const auto kern = conv1d_wino2_f32<K, NOCT, NSTAGE, EPI>;
+    const auto kern = conv1d_wino2_f32<K, NOCT, NSTAGE, WM, NPH, EPI>;
     TTS_CHECK_HIP(lds_opt_in((const void*)kern, (int)lds, lds_done));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-template <int K, int NOCT, int NSTAGE>
+template <int K, int NOCT, int NSTAGE, int WM, int NPH>
 static int32_t launch_wino2_cfg(const ConvParams& p, hipStream_t stream) {
-    using G = Wino2Geo<K, NOCT, NSTAGE>;
-    const int nt = wino2_tile(p.dil);
+    using G = Wino2Geo<K, NOCT, NSTAGE, WM, NPH>;
+    const int nt = wino2_tile(p.dil, G::NPAIR);
     dim3 grid((p.Nout + nt - 1) / nt, p.CoutP / G::CO_BLK, p.batch);
     ConvParams q = p;
     q.ksplit = 1;
     q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
-    if (p.res != nullptr) return launch_wino2_epi<K, NOCT, NSTAGE, 3>(q, grid, stream);
-    return launch_wino2_epi<K, NOCT, NSTAGE, 0>(q, grid, stream);
+    if (p.res != nullptr) return launch_wino2_epi<K, NOCT, NSTAGE, WM, NPH, 3>(q, grid, stream);
+    return launch_wino2_epi<K, NOCT, NSTAGE, WM, NPH, 0>(q, grid, stream);
 }
 
 int32_t launch_wino2(const ConvParams& p, hipStream_t stream) {
     // larger chunks (k = 3: 32 channels, two stages; k = 7: 16 channels, two stages) measured equal within the noise (65.2 / 65.6 vs 65.3 ms)
-    if (p.K == 3) return launch_wino2_cfg<3, 2, 3>(p, stream);      // 16-channel chunks: 64 MFMAs per wave between barriers, 48 KB ring
-    if (p.K == 7) return launch_wino2_cfg<7, 1, 3>(p, stream);      // 80 MFMAs, 60 KB ring
-    if (p.K == 11) return launch_wino2_cfg<11, 1, 2>(p, stream);    // 128 MFMAs, 64 KB ring (two stages)
+    if (p.CoutP % 128 == 0) {      // 128 rows x 64 pairs per block
+        if (p.K == 3) return launch_wino2_cfg<3, 2, 3, 2, 1>(p, stream);      // 16-channel chunks: 64 MFMAs per wave between barriers, 48 KB ring
+        if (p.K == 7) return launch_wino2_cfg<7, 1, 3, 2, 1>(p, stream);      // 80 MFMAs, 60 KB ring
+        if (p.K == 11) return launch_wino2_cfg<11, 1, 2, 2, 1>(p, stream);    // 128 MFMAs, 64 KB ring (two stages)
+    } else {                       // Cout = 64: 64 rows x 128 pairs
+        if (p.K == 3) return launch_wino2_cfg<3, 2, 2, 1, 1>(p, stream);      // 64 MFMAs, 64 KB ring
+        if (p.K == 7) return launch_wino2_cfg<7, 1, 2, 1, 1>(p, stream);      // 80 MFMAs, 80 KB ring
+        if (p.K == 11) return launch_wino2_cfg<11, 1, 2, 1, 2>(p, stream);    // two phases of 8 groups: 64 MFMAs each, 64 KB ring
+    }
     set_error("wino2: kernel size %d not built (3, 7, 11)", p.K);
     return TTSAMD_EINVAL;
 }
+
+// outputs per block of the kernel launch_wino2 picks (the routing's block count)
+int wino2_block_outputs(int coutp, int dil) { return wino2_tile(dil, coutp % 128 == 0 ? 64 : 128); }
 
 int wino2_groups(int k) { return 4 * (k / 3) + 2 * (k - 3 * (k / 3)); }
 

@@ -205,7 +205,7 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
     blob.resize(blob.size() + (size_t)cin * k * cout_padded(cout));
     pack_conv_weight(w.data(), cout, cin, k, blob.data() + cw.w_off);
     add_bf16(blob, blob16, cw, (int64_t)cin * k * cout_padded(cout));
-    if ((k == 3 || k == 7 || k == 11) && cin % 8 == 0 && cout % 128 == 0) {
+    if ((k == 3 || k == 7 || k == 11) && cin % 8 == 0 && cout % 64 == 0) {
         blob.resize(align_up((int64_t)blob.size(), 64));
         cw.ww_off = (int64_t)blob.size();
         blob.resize(blob.size() + (size_t)cin * wino2_groups(k) * cout_padded(cout));
