@@ -155,7 +155,7 @@ int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const flo
                            const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
                            int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream);
 // Winograd F(2,3) path of the k = 3, dilation-1 convs (conv_wino.hip): routing test, launcher, host-side filter transform + packing
-bool wino_wanted(const ConvParams& p);
+int wino_route(const ConvParams& p);       // 0: direct kernel, 1: conv1d_wino_f32, 2: conv1d_wino2_f32 (conv_wino.hip)
 int32_t launch_wino(const ConvParams& p, hipStream_t stream);
 void pack_wino_weight(const float* w, int cout, int cin, float* out);   // out: cin * 4 * cout_padded(cout) floats
 // ... and its generalisation to k = 7 / 11 as sums of F(2,3) sub-filters + single taps (conv_wino2.hip): NG = wino2_groups(k) operand

@@ -398,38 +398,39 @@ static int32_t launch_wino_epi(const ConvParams& q, dim3 grid, hipStream_t strea
     return 0;
 }
 
-// what the Winograd kernel can run AND the launcher wants routed to it: exact-fp32, k = 3, dilation 1, "same" padding, Winograd
-// weights present, 128-row tiles, aligned rows (float4 row epilogue, 8-byte residual preload), at least one block per CU of its
-// 128 x 128 tile (smaller problems keep the direct kernel's finer tiles and split K)
-// which kernel sizes take the Winograd-decomposition kernel of conv_wino2.hip (weights from L2 into a register queue, halo zeros from
-// the buffer range check): bit 0 / 1 / 2 = k 3 / 7 / 11, bit 3 = their dilated (3 / 5) convs too, bit 4 = Cout = 64.  Default: all (same-box A/B of the bench step, tools/ab_env.sh:
-// 74.2 ms with none, 73.1 with k = 3, 68.5 with k = 7 + 11, 67.5 with all).  TTSAMD_WINO2=<mask> is read per call (A/B runs, the
-// parity tests of both k = 3 kernels).
-static int wino2_mask() {
-    const char* e = getenv("TTSAMD_WINO2");
-    return e ? atoi(e) : 31;
-}
-
-bool wino_wanted(const ConvParams& p) {
-    const bool k_ok = p.K == 3 || ((p.K == 7 || p.K == 11) && (wino2_mask() & (p.K == 7 ? 2 : 4)));
-    // dilations 3 / 5 (the c1 convs of HiFi-GAN's ResBlocks): the decomposition kernel only, output pairs (q, q + d)
-    const bool d_ok = p.dil == 1 || ((p.dil == 3 || p.dil == 5) && (wino2_mask() & (p.K == 3 ? 1 : (p.K == 7 ? 2 : 4))) && (wino2_mask() & 8) &&
-                                     (p.K != 3 || p.Cin % 16 == 0));
-    if (p.w_wino == nullptr || p.precision != 0 || !k_ok || !d_ok || p.pad != p.dil * (p.K - 1) / 2 || p.n_phase != 1 || p.y_ts != 1) return false;
-    // rows: 128 per block; the decomposition kernel also has a 64-row x 128-pair variant (HiFi-GAN's C = 64 stage)
-    const bool rows64 = p.CoutP % 128 != 0 && p.CoutP % 64 == 0 && (wino2_mask() & 16) && (p.K != 3 || ((wino2_mask() & 1) && p.Cin % 16 == 0));
-    if ((p.CoutP % 128 != 0 && !rows64) || p.Cin % 8 != 0 || p.scale != nullptr || p.relu_out >= 2) return false;
-    if (!(p.in_slope >= 0.f && p.in_slope <= 1.f)) return false;      // conv_wino2.hip activates with max(x, slope x)
+// Routing of an exact-fp32 conv launch: 0 = the direct kernel, 1 = conv1d_wino_f32 (this file: k = 3, dilation 1, 128-row tiles),
+// 2 = conv1d_wino2_f32 (conv_wino2.hip: k = 3 / 7 / 11, dilation 1 / 3 / 5, 128- or 64-row tiles).  Wanted when the Winograd weights
+// are there, the padding is 'same', rows are float4-aligned (row epilogue, residual preload) and the launch has at least 192 blocks.
+// The two switches are read ONCE per launch (A/B runs and the parity tests of all three kernels flip them between calls):
+//   TTSAMD_WINO=0        everything on the direct kernel
+//   TTSAMD_WINO2=<mask>  what the decomposition kernel takes: bit 0 / 1 / 2 = k 3 / 7 / 11, bit 3 = their dilated (3 / 5) convs, bit 4
+//                        = Cout = 64.  Default 31 (same-box A/B of the bench step, tools/ab_env.sh: 74.2 ms with none, 73.1 with k = 3,
+//                        68.5 with k = 7 + 11, 67.5 with the three, 65.6 with dilations, 64.6-65.1 with Cout = 64)
+int wino_route(const ConvParams& p) {
+    if (p.w_wino == nullptr || p.precision != 0 || (p.K != 3 && p.K != 7 && p.K != 11)) return 0;
+    const char* e = getenv("TTSAMD_WINO");
+    if (e && e[0] == '0') return 0;
+    const char* e2 = getenv("TTSAMD_WINO2");
+    const int mask = e2 ? atoi(e2) : 31;
+    const int kbit = p.K == 3 ? 1 : (p.K == 7 ? 2 : 4);
+    const bool rows64 = p.CoutP % 128 != 0;
+    // what the decomposition kernel can take of this launch (its k = 3 chunks are 16 channels)
+    const bool w2 = (mask & kbit) && (p.dil == 1 || (mask & 8)) && (!rows64 || (mask & 16)) && (p.K != 3 || p.Cin % 16 == 0);
+    const bool w1 = p.K == 3 && p.dil == 1 && !rows64;
+    if (!w2 && !w1) return 0;
+    if ((p.dil != 1 && p.dil != 3 && p.dil != 5) || p.pad != p.dil * (p.K - 1) / 2 || p.n_phase != 1 || p.y_ts != 1) return 0;
+    if (p.CoutP % 64 != 0 || p.Cin % 8 != 0 || p.scale != nullptr || p.relu_out >= 2) return 0;
+    if (!(p.in_slope >= 0.f && p.in_slope <= 1.f)) return 0;         // conv_wino2.hip activates with max(x, slope x)
     const bool vec_ok = (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
                         (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0));
-    if (!vec_ok || (int64_t)p.Cout * std::max(std::max(p.r_cs, p.y_cs), 1) * 4 >= ((int64_t)1 << 31)) return false;
-    const char* e = getenv("TTSAMD_WINO");                      // 0: the direct kernel (A/B runs, parity tests of both)
-    if (e && e[0] == '0') return false;
+    if (!vec_ok || (int64_t)p.Cout * std::max(std::max(p.r_cs, p.y_cs), 1) * 4 >= ((int64_t)1 << 31)) return 0;
     const int bo = wino2_block_outputs(p.CoutP, p.dil);
     const int64_t blocks = (int64_t)((p.Nout + bo - 1) / bo) * (p.CoutP / (rows64 ? 64 : 128)) * p.batch;
     // under ~3/4 of a block per CU the direct kernel's 64 x 64 tiles with split K fill the chip better (batch 1: 3.68 ms per step with
-    // the limit at 200, 3.74 at 100, 3.9-4.0 at 50 / 1 and with the Winograd kernels off; batch 4: 10.0 vs 10.5-11.0: tools/ab_small.sh)
-    return blocks >= 192 && p.Nout >= 256;       // (short sequences -- FastPitch's 64-token encoder -- would leave half of a 128-output tile empty)
+    // the limit at 200, 3.74 at 100, 3.9-4.0 at 50 / 1 and with the Winograd kernels off; batch 4: 10.0 vs 10.5-11.0: tools/ab_small.sh);
+    // short sequences (FastPitch's 64-token encoder) would leave half of a 128-output tile empty
+    if (blocks < 192 || p.Nout < 256) return 0;
+    return w2 ? 2 : 1;
 }
 
 template <int MT, int WM, int WN>
@@ -444,7 +445,6 @@ static int32_t launch_wino_cfg(const ConvParams& p, hipStream_t stream) {
 }
 
 int32_t launch_wino(const ConvParams& p, hipStream_t stream) {
-    if (p.K != 3 || p.dil != 1 || p.CoutP % 128 != 0 || ((wino2_mask() & 1) && p.Cin % 16 == 0)) return launch_wino2(p, stream);
     // 128 co x 128 outputs (64 pairs).  (A 128 co x 64 outputs tile for launches under two blocks per CU -- FastPitch's 1536 -> 384 conv
     // at batch 32 is 384 blocks -- measured slower: 75.04 vs 74.45 ms per step; everything on it: 76.67.  A 64 co x 128 outputs tile,
     // three blocks per CU: 74.61 vs 74.22-74.35; everything on it: 75.44.)
