@@ -32,6 +32,8 @@ def _ref_pair(x, w1, b1, w2, b2, dil, lens, slope=0.1):
 CASES = [(c, k, d, v) for c in (32, 64, 128) for k in (3, 7, 11) for d in (1, 3, 5) for v in (2, 3)
          if (d == 5 or (c, k) in ((64, 3), (128, 7)))]             # every (C, k) at the widest dilation, two at all three
 CASES += [(32, k, 3, 1) for k in (3, 7, 11)] + [(64, 3, 5, 1)]      # the first-generation kernel through the same entry
+# variant 4: the second generation with phase B (c2, dilation 1) as Winograd F(2,3) over the even / odd column arrays of the intermediate
+CASES += [(c, k, d, 4) for c in (32, 64) for k in (3, 7, 11) for d in (1, 5)] + [(64, 7, 3, 4)]
 
 
 @pytest.mark.parametrize('C,k,dil,variant', CASES)

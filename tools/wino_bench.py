@@ -14,7 +14,10 @@ from ttsamd.engine import _ptr, _stream  # noqa: E402
 dev = torch.device('cuda:0')
 L = lib.load()
 B, T = 32, 640
+only = [int(a) for a in sys.argv[1:]]
 for C, mul in ((256, 8), (128, 64), (64, 128)):
+    if only and C not in only:
+        continue
     for k in (3, 7, 11):
         n = T * mul
         x = torch.randn(B, C, n, device=dev)

@@ -31,6 +31,7 @@ struct FusedPair2Params {
     float* y;              // [B][C][L]; must not alias x (other blocks read x's halo)
     const float4* w1;      // packed [C/8 oct][K][2][C][4]
     const float4* w2;
+    const float4* w2w;     // WB kernels: conv 2 as Winograd F(2,3) groups, packed [C/8 oct][NGW][2][C][4] (conv_wino2.hip: pack_wino2_weight)
     const float* b1;
     const float* b2;
     const int64_t* lens;   // valid length = lens[b] * len_mul (nullptr -> L)
@@ -50,6 +51,8 @@ struct Fused2Geo {
     static constexpr int TS = (NB - 2 * H) & ~3;               // outputs per block
     static constexpr int TSTR = NB + K - 1;                    // columns of the intermediate incl. the over-read of dead MFMA columns
     static constexpr int NG = NOCT * K;                        // (octet, tap) operand groups per conv
+    static constexpr int NS = K / 3, NL = K - 3 * NS, NGW = 4 * NS + 2 * NL;   // Winograd phase B: sub-filters, single taps, groups per octet
+    static constexpr int TSH = TSTR / 2;                       // ... its intermediate: even / odd columns apart, TSH entries each (TSTR is even)
     static constexpr int PF = 2;                               // weight groups in flight ahead of the one being multiplied
     // octets per unrolled body of the group loop: the whole conv when it is at most ~640 MFMAs per wave, else as many octets as
     // fit (always an even number of groups per body, so the two queue slots line up across iterations; NOCT % UO == 0)
@@ -131,10 +134,90 @@ __device__ __forceinline__ void conv_phase2(f32x16 (&acc)[C / 32][NTW], float4 (
     }
 }
 
-template <int K, int C, int NTW>
+// Phase B as Winograd F(2,3) (conv_wino2.hip's decomposition: k / 3 three-tap sub-filters + k % 3 single taps over the same four
+// planes): the pair of outputs (2 jw, 2 jw + 1) of this lane from the intermediate stored as EVEN / ODD column arrays -- column
+// 2 jw + c is entry jw + c / 2 of array c & 1, so every operand read is contiguous over the lanes (stride-2 reads of an interleaved
+// row would be 2-way bank conflicts).  Per sub-filter: four float4 reads (x0..x3, one bundle ahead), V = x0 - x2, x1 + x2, x2 - x1,
+// x1 - x3 as packed adds, then its four groups of 4 MT MFMAs: 0.25 / MT reads and 0.5 / MT VALU per MFMA, 4/6, 10/14, 16/22 of the
+// direct phase's MFMAs.  `sb` = row (octet 0, this lane's kk), entry jw of the even array; rows are 2 TSH entries apart.
+template <int K, int C>
+__device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][C / 32], float4 (&aq)[2][C / 32], const float4* sb,
+                                                 const float4* __restrict__ wl) {
+    using G = Fused2Geo<K, C, 2>;
+    constexpr int NOCT = G::NOCT, MT = G::MT, PF = G::PF, NS = G::NS, NL = G::NL, NGW = G::NGW, TSH = G::TSH;
+    constexpr int NBU = NS + NL;                               // operand bundles per octet (a sub-filter: 4 entries, a single tap: 2)
+    constexpr int NGT = NOCT * NGW;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    // entry of intermediate column 2 jw + c
+#define TTS_ENT(SBO, CC) (SBO)[((CC) & 1) * TSH + ((CC) >> 1)]
+    float4 bq[2][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bq[0][m] = TTS_ENT(sb, m);     // bundle 0 of octet 0 = sub-filter 0 (every k has one)
+#pragma unroll 1
+    for (int o = 0; o < NOCT; ++o) {
+        const float4* sbo = sb + o * 4 * TSH;                  // (2 rows of 2 TSH per octet)
+        const float4* sbn = sb + min(o + 1, NOCT - 1) * 4 * TSH;
+#pragma unroll
+        for (int u = 0; u < NBU; ++u) {
+            const int cur = u & 1, nxt = cur ^ 1;              // (NBU odd would flip the slots between octets: both k = 7 and 11 have NBU = 3 / 5 ... handled by `cur` below)
+            // next bundle's reads: the next sub-filter / tap of this octet, or sub-filter 0 of the next octet
+            {
+                const int un = u + 1;
+                if (un < NS) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) bq[nxt][m] = TTS_ENT(sbo, 3 * un + m);
+                } else if (un < NBU) {
+                    bq[nxt][0] = TTS_ENT(sbo, 3 * NS + (un - NS));
+                    bq[nxt][1] = TTS_ENT(sbo, 3 * NS + (un - NS) + 1);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) bq[nxt][m] = TTS_ENT(sbn, m);
+                }
+            }
+            f32x4v x[4], v[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) x[m] = f32x4v{bq[cur][m].x, bq[cur][m].y, bq[cur][m].z, bq[cur][m].w};
+            const bool sub = u < NS;
+            if (sub) { v[0] = x[0] - x[2]; v[1] = x[1] + x[2]; v[2] = x[2] - x[1]; v[3] = x[1] - x[3]; }
+            else { v[0] = x[0]; v[1] = x[1]; }
+            const int ng = sub ? 4 : 2;                        // groups of this bundle
+            const int g0 = sub ? 4 * u : 4 * NS + 2 * (u - NS);
+#pragma unroll
+            for (int i = 0; i < ng; ++i) {
+                const int g = g0 + i;                          // group of the octet; its plane: (s, i) -> i, a tap's halves -> 0 and 3
+                const int plane = sub ? i : (i ? 3 : 0);
+                const int slot = g % PF;                       // NGW is even: the slots line up across octets
+                float4 a4[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a4[mt] = aq[slot][mt];
+                {
+                    const int gn = min(o * NGW + g + PF, NGT - 1);         // (past the last group: an L1 hit, unused)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) aq[slot][mt] = wl[(int64_t)gn * 2 * C + 32 * mt];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const float av = pq == 0 ? a4[mt].x : (pq == 1 ? a4[mt].y : (pq == 2 ? a4[mt].z : a4[mt].w));
+                        acc[plane][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v[i][pq], acc[plane][mt], 0, 0, 0);
+                    }
+            }
+        }
+        if (NBU & 1) {   // an odd number of bundles per octet: the prefetched first bundle of the next octet sits in slot 1 -> move it
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bq[0][m] = bq[1][m];
+        }
+    }
+#undef TTS_ENT
+}
+
+template <int K, int C, int NTW, bool WB>
 __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_pair2(const FusedPair2Params p) {
     using G = Fused2Geo<K, C, NTW>;
-    constexpr int NOCT = G::NOCT, MT = G::MT, H = G::H, NB = G::NB, TS = G::TS, TSTR = G::TSTR, PF = G::PF;
+    constexpr int NOCT = G::NOCT, MT = G::MT, H = G::H, NB = G::NB, TS = G::TS, TSTR = G::TSTR, PF = G::PF, TSH = G::TSH;
+    static_assert(!WB || NTW == 2, "Winograd phase B: a wave's 64 columns are its 32 output pairs");
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int kk = lane >> 5, l31 = lane & 31;
@@ -169,7 +252,7 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
     // ---- weight queue: group g = (octet, tap) of conv 1 sits at w1 + g * 2C, this lane's fragment of row tile mt at
     // + kk * C + 32 mt + l31.  The first PF groups go out before anything else.
     const float4* __restrict__ wl1 = p.w1 + kk * C + l31;
-    const float4* __restrict__ wl2 = p.w2 + kk * C + l31;
+    const float4* __restrict__ wl2 = (WB ? p.w2w : p.w2) + kk * C + l31;
     float4 aq[PF][MT];
 #pragma unroll
     for (int g = 0; g < PF; ++g)
@@ -222,6 +305,90 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 #endif
     conv_phase2<K, C, NTW, true>(acc, aq, Xs + kk * W1 + colw, W1, dil, wl1, wl2, slope);
 
+    float* ep = reinterpret_cast<float*>(smem4);               // [C][NB]: the epilogue's row buffer (the intermediate is dead by then)
+    if constexpr (WB) {
+        // ---- Winograd phase B: four planes per row tile for this lane's output pair (2 jw, 2 jw + 1); the residual (raw x out of
+        // the window, exact) and the running ResBlock sum enter as x[2 jw] -> P0, -x[2 jw + 1] -> P3
+        const int jw = wid * 32 + l31;
+        f32x16 accw[4][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int colx = 2 * jw + H + pad1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accw[1][mt][r] = 0.f; accw[2][mt][r] = 0.f; }
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const float* src = reinterpret_cast<const float*>(Xs + ((4 * mt + oc) * 2 + k2) * W1 + colx) + 2 * kk;
+                    const float2 r0 = *reinterpret_cast<const float2*>(src);
+                    const float2 r1 = *reinterpret_cast<const float2*>(src + 4);
+                    accw[0][mt][4 * oc + k2] = r0.x;
+                    accw[0][mt][4 * oc + k2 + 2] = r0.y;
+                    accw[3][mt][4 * oc + k2] = -r1.x;
+                    accw[3][mt][4 * oc + k2 + 2] = -r1.y;
+                }
+        }
+        if (p.mode != 0) {
+            const int n = 2 * jw, q = q0 + n;
+            const int voff = ((n < TS && q < len) ? q : 0) * 4 + 4 * kk * L * 4;        // (q even, rows float4-aligned: q + 1 stays in the row)
+            const auto ys = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)b * C * L, 0, C * L * 4, 0x00020000);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 t0, t1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * mt + (r & 3) + 8 * (r >> 2)) * L * 4;
+                    t0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff, so, 0));
+                    t1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff + 4, so, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    accw[0][mt][r] = t0[r] + accw[0][mt][r];
+                    accw[3][mt][r] = accw[3][mt][r] - t1[r];
+                }
+            }
+        }
+        __syncthreads();                                       // every wave is done with the window
+
+        // ---- intermediate -> LDS: lrelu(acc) (b1 is in), zero outside the utterance, even / odd columns apart: column c of row
+        // (octet, k2) is entry (c & 1) TSH + (c >> 1) of the row's 2 TSH
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int col = wid * 32 * NTW + l31 + 32 * j;
+            const int pos = q0 - H + col;
+            const bool live = pos >= 0 && pos < len;
+            const int ent = (col & 1) * TSH + (col >> 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int r = 4 * oc + k2;
+                        float v0 = acc[mt][j][r], v1 = acc[mt][j][r + 2];
+                        v0 = lrelu_max(v0, slope);
+                        v1 = lrelu_max(v1, slope);
+                        const float2 w2v = live ? make_float2(v0, v1) : make_float2(0.f, 0.f);
+                        *reinterpret_cast<float2*>(reinterpret_cast<float*>(Xs + ((4 * mt + oc) * 2 + k2) * 2 * TSH + ent) + 2 * kk) = w2v;
+                    }
+        }
+        __syncthreads();
+
+        conv_phase2_wino<K, C>(accw, aq, Xs + kk * 2 * TSH + jw, wl2);
+
+        // ---- output transform into the row buffer: y[2 jw] = P0 + P1 + P2, y[2 jw + 1] = P1 - P2 - P3
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float2 y2;
+                y2.x = accw[0][mt][r] + accw[1][mt][r] + accw[2][mt][r];
+                y2.y = accw[1][mt][r] - accw[2][mt][r] - accw[3][mt][r];
+                *reinterpret_cast<float2*>(ep + (32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk) * NB + 2 * jw) = y2;
+            }
+    } else {
     // ---- residual out of the window (raw x, exact): register r of tile (mt, j) is channel 32mt + (r&3) + 8(r>>2) + 4kk at
     // position q0 + colw + 32j = window column colw + 32j + H + pad1; registers (r, r+2), r&3 in {0,1}, are components
     // (2kk, 2kk+1) of entry (4mt + (r>>2), r&1, col): one 8-byte read for the two.
@@ -294,16 +461,16 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 
     // ---- epilogue: + b2 [, / div], transposed through LDS (the intermediate is dead after the barrier), float4 row stores
     __syncthreads();
-    float* ep = reinterpret_cast<float*>(smem4);               // [C][NB]
-    const bool do_div = p.mode == 2;
-    const float div = p.div;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ep[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk) * NB + colw + 32 * j] = acc2[mt][j][r];
+    }
     __syncthreads();
+    const bool do_div = p.mode == 2;
+    const float div = p.div;
     float* __restrict__ yb = p.y + (int64_t)b * C * L;
     constexpr int LPR = NB / 4;                                 // lanes per row (64 or 32)
     constexpr int RPW = 64 / LPR;                               // rows per wave instruction
@@ -337,13 +504,13 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 }
 
 
-template <int K, int C, int NTW>
+template <int K, int C, int NTW, bool WB>
 static int32_t launch_fused2_k(const FusedPair2Params& p, hipStream_t stream) {
     using G = Fused2Geo<K, C, NTW>;
     static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
-    TTS_CHECK_HIP(lds_opt_in((const void*)resblock_pair2<K, C, NTW>, (int)G::lds_bytes(DMAX), lds_done));
+    TTS_CHECK_HIP(lds_opt_in((const void*)resblock_pair2<K, C, NTW, WB>, (int)G::lds_bytes(DMAX), lds_done));
     dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
-    hipLaunchKernelGGL((resblock_pair2<K, C, NTW>), grid, dim3(256), G::lds_bytes(p.dil), stream, p);
+    hipLaunchKernelGGL((resblock_pair2<K, C, NTW, WB>), grid, dim3(256), G::lds_bytes(p.dil), stream, p);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -360,22 +527,28 @@ bool fused_pair2_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, 
 
 int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const float* w1, const float* b1, const float* w2,
                            const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
-                           int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream) {
+                           int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream, const float* w2_wino) {
     TTS_REQUIRE(fused_pair2_supported(channels, k, dil, L, x, y, ntw),
                 "fused ResBlock pair (direct weights): unsupported geometry (C=%d, k=%d, dil=%d, L=%d, ntw=%d)", channels, k, dil, L, ntw);
     TTS_REQUIRE(slope > 0.f && slope <= 1.f, "fused ResBlock pair: leaky-relu slope %g outside (0, 1]", (double)slope);
-    conv_log(ntw == 2 ? "fused_pair2" : "fused_pair2n", k, channels, channels, L, batch, 1, mode, len_mul, lens != nullptr, 1);
+    // w2_wino (conv 2 as Winograd groups, pack_wino2_weight): phase B on F(2,3) -- 256-column blocks of C = 32 / 64 only
+    const bool wb = w2_wino != nullptr && ntw == 2 && channels <= 64;
+    conv_log(wb ? "fused_pair2w" : (ntw == 2 ? "fused_pair2" : "fused_pair2n"), k, channels, channels, L, batch, 1, mode, len_mul, lens != nullptr, 1);
     FusedPair2Params p;
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.y = y;
     p.w1 = reinterpret_cast<const float4*>(w1); p.w2 = reinterpret_cast<const float4*>(w2);
+    p.w2w = reinterpret_cast<const float4*>(w2_wino);
     p.b1 = b1; p.b2 = b2; p.lens = lens; p.len_mul = len_mul; p.L = L; p.dil = dil; p.batch = batch;
     p.mode = mode; p.div = div; p.slope = slope;
     p.compact = compact_order(lens, batch) ? 1 : 0;
 #ifdef TTS_F2_EXP
     if (const char* e = exp_env("TTSAMD_F2_EXP")) p.exp = atoi(e);
 #endif
-#define TTS_F2(KK, CC, NN) if (k == KK && channels == CC && ntw == NN) return launch_fused2_k<KK, CC, NN>(p, stream);
+#define TTS_F2W(KK, CC) if (wb && k == KK && channels == CC) return launch_fused2_k<KK, CC, 2, true>(p, stream);
+    TTS_F2W(3, 32) TTS_F2W(7, 32) TTS_F2W(11, 32) TTS_F2W(3, 64) TTS_F2W(7, 64) TTS_F2W(11, 64)
+#undef TTS_F2W
+#define TTS_F2(KK, CC, NN) if (k == KK && channels == CC && ntw == NN) return launch_fused2_k<KK, CC, NN, false>(p, stream);
     TTS_F2(3, 32, 2) TTS_F2(7, 32, 2) TTS_F2(11, 32, 2)
     TTS_F2(3, 64, 2) TTS_F2(7, 64, 2) TTS_F2(11, 64, 2)
     TTS_F2(3, 128, 2) TTS_F2(7, 128, 2) TTS_F2(11, 128, 2)
