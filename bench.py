@@ -752,7 +752,7 @@ def main():
                 'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
-                    'kernel': ('MFMA conv engine: conv1d_wino2_f32 (Winograd F(2,3) decomposition, k = 3 / 7 / 11, C >= 128) + conv1d_mfma_f32 + resblock_pair2 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
+                    'kernel': ('MFMA conv engine: conv1d_wino2_f32 (Winograd F(2,3) decomposition, k = 3 / 7 / 11) + resblock_pair2 (fused C = 32 / 64 pairs, phase B on F(2,3)) + conv1d_mfma_f32 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
             if args.precision == 'f32':
                 # products the Winograd launches do NOT issue (conv_wino2.hip: k = 3 / 7 / 11 as F(2,3) sub-filters + single taps: 4/6,
@@ -765,8 +765,9 @@ def main():
                 roof['frac_issued'] = issued / peak
                 roof['flops_basis'] = ('`achieved` / `frac`: UN-REDUCED algorithmic FLOPs (2 Cout Cin K per valid output position) over kernel time.  '
                                        '`issued` / `frac_issued`: the same minus the products the Winograd F(2,3) launches do not issue (k = 3 / 7 / 11 '
-                                       'convs as three-tap sub-filters + single taps: 4/6, 10/14, 16/22 of the direct products; HiFi-GAN C = 128 / 256 '
-                                       'ResBlock convs at every dilation, FastPitch decoder conv-FF) = what the MFMA pipe executed against its peak.  '
+                                       'convs as three-tap sub-filters + single taps: 4/6, 10/14, 16/22 of the direct products; HiFi-GAN C >= 128 ResBlock convs and the C = 64 '
+                                       'k = 11 pairs at every dilation, the c2 conv of the fused C = 32 / 64 pairs, FastPitch decoder conv-FF) = what the MFMA pipe '
+                                       'executed against its peak.  '
                                        'TTSAMD_WINO=0 runs the direct kernels (profiles/r5/wino_off_bench_line.json)')
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
                      'traffic_algorithmic': traffic_alg, 'traffic_ratio': (traffic / traffic_alg) if (traffic and traffic_alg) else None,
@@ -1148,22 +1149,24 @@ def hifigan_flops_per_frame(h):
 
 
 def hifigan_wino_saved_flops_per_frame(h):
-    """Products per mel frame that the Winograd decomposition (csrc/conv_wino2.hip) does not issue: ResBlock convs of the stages with
-    >= 128 channels, kernel sizes 3 / 7 / 11 (4/6, 10/14, 16/22 of the direct conv's products)."""
+    """Products per mel frame that the Winograd kernels do not issue (kernel sizes 3 / 7 / 11: 4/6, 10/14, 16/22 of the direct conv's
+    products): every ResBlock conv of the stages with >= 128 channels and the un-fused C = 64 k = 11 pairs (csrc/conv_wino2.hip), the c2
+    conv -- phase B -- of the fused C = 32 / 64 pairs (csrc/resblock_fused2.hip).  Default routing (hifigan.hip: kFused2Mask)."""
     ch, mul, f = h['upsample_initial_channel'], 1, 0.0
     for u in h['upsample_rates']:
         ch, mul = ch // 2, mul * u
-        if ch < 128:
-            continue
         for kk, dil in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+            if kk not in (3, 7, 11) or ch < 32:
+                continue
             ng = 4 * (kk // 3) + 2 * (kk % 3)
-            if kk in (3, 7, 11):
-                f += len(dil) * 2 * (2.0 * ch * ch * kk) * mul * (1.0 - ng / (2.0 * kk))
+            fused = ch == 32 or (ch == 64 and kk in (3, 7))
+            convs = len(dil) * (1 if fused else 2)          # fused pairs: the c2 conv only
+            f += convs * (2.0 * ch * ch * kk) * mul * (1.0 - ng / (2.0 * kk))
     return f
 
 
 def wino_on():
-    return os.environ.get('TTSAMD_WINO', '1') != '0' and os.environ.get('TTSAMD_WINO2', '15') == '15'
+    return os.environ.get('TTSAMD_WINO', '1') != '0' and os.environ.get('TTSAMD_WINO2', '31') == '31' and os.environ.get('TTSAMD_FUSED2_WB', '1') != '0'
 
 
 def fastpitch_conv_flops_per_pos(c):

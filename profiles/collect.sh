@@ -35,7 +35,7 @@ python3 tools/bfo_bench.py --x3 --json $O/bfo3_layers.json > $O/bfo3_layers.txt 
 rm -rf $O/xstats1 $O/xpmc_mfma
 # fp32 with the direct k = 3 kernel instead of Winograd F(2,3): the same-box A/B behind DESIGN.md section 4
 python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_on_bench_line.json 2>> $O/bench.err
-TTSAMD_WINO=0 python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_off_bench_line.json 2>> $O/bench.err
+TTSAMD_WINO=0 TTSAMD_FUSED2_WB=0 python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_off_bench_line.json 2>> $O/bench.err
 # bf16 runs the two-stream schedule by default (FastPitch of step i+1 under HiFi-GAN of step i); the one-stream line of the same work:
 python3 bench.py --precision bf16 --no-pipeline --no-cpu-baseline --no-small --no-extra > $O/bf16_one_stream_bench_line.json 2>> $O/bench.err
 # config 3 (bf16 octet engine): kernel stats (three streams / one stream), HBM traffic and MFMA counters of the same command
