@@ -34,6 +34,9 @@ CASES = [(c, k, d, v) for c in (32, 64, 128) for k in (3, 7, 11) for d in (1, 3,
 CASES += [(32, k, 3, 1) for k in (3, 7, 11)] + [(64, 3, 5, 1)]      # the first-generation kernel through the same entry
 # variant 4: the second generation with phase B (c2, dilation 1) as Winograd F(2,3) over the even / odd column arrays of the intermediate
 CASES += [(c, k, d, 4) for c in (32, 64) for k in (3, 7, 11) for d in (1, 5)] + [(64, 7, 3, 4)]
+# variant 5: phase A too (output pairs (n, n + d): 256 / 252 / 250 intermediate columns per block at d = 1 / 3 / 5), window staged activated,
+# residual from memory in the row epilogue
+CASES += [(c, k, d, 5) for c in (32, 64) for k in (3, 7, 11) for d in (1, 3, 5)]
 
 
 @pytest.mark.parametrize('C,k,dil,variant', CASES)
@@ -44,6 +47,8 @@ def test_resblock_pair_kernel_vs_float64(C, k, dil, variant):
     # block outputs: 256 - (k-1) & ~3 (variant 1 / 2), 128 - (k-1) & ~3 (variant 3): lengths around one and two blocks, one
     # utterance ending inside the halo of a block edge, one shorter than the kernel, one empty
     ts = ((128 if variant == 3 else 256) - (k - 1)) & ~3
+    if variant == 5:
+        ts = (2 * dil * (128 // dil) - (k - 1)) & ~3
     lens = [2 * ts + 8, ts + 4, ts - 4, ts, 4, 0, 3 * ts - 12]
     Lx = max(lens)
     x = torch.randn(len(lens), C, Lx, generator=g)

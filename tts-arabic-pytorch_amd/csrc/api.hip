@@ -412,23 +412,25 @@ int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const fl
     prof_begin(s, fl);
     if (variant == 1) {
         rc = launch_fused_pair(channels, x, y, packed, b1, packed + n, b2, k, dil, lens, len_mul, L, batch, mode, div, slope, s);
-    } else if (variant == 2 || variant == 3 || variant == 4) {
-        const float* w2w = nullptr;
-        if (variant == 4) {       // 256-column blocks with phase B on Winograd F(2,3): conv 2's groups behind the two direct packings
-            TTS_REQUIRE((k == 3 || k == 7 || k == 11) && channels <= 64, "resblock_pair: variant 4 is built for C = 32 / 64, k = 3 / 7 / 11");
-            float* wino = packed + 2 * n;
+    } else if (variant >= 2 && variant <= 5) {
+        const float *w2w = nullptr, *w1w = nullptr;
+        if (variant >= 4) {       // 256-column blocks with phase B (4) or both phases (5) on Winograd F(2,3): the groups behind the direct packings
+            TTS_REQUIRE((k == 3 || k == 7 || k == 11) && channels <= 64, "resblock_pair: variants 4 / 5 are built for C = 32 / 64, k = 3 / 7 / 11");
             const int64_t nw = (int64_t)channels * wino2_groups(k) * channels;
-            hipLaunchKernelGGL(pack_wino2_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w2, channels, channels, k,
-                               channels, wino);
-            TTS_CHECK_HIP(hipGetLastError());
-            w2w = wino;
+            for (int i = 0; i < (variant == 5 ? 2 : 1); ++i) {
+                float* wino = packed + 2 * n + i * nw;
+                hipLaunchKernelGGL(pack_wino2_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, i == 0 ? w2 : w1, channels,
+                                   channels, k, channels, wino);
+                TTS_CHECK_HIP(hipGetLastError());
+                (i == 0 ? w2w : w1w) = wino;
+            }
         }
         rc = launch_fused_pair2(channels, x, y, packed, b1, packed + n, b2, k, dil, lens, len_mul, L, batch, mode, div, slope,
-                                variant == 3 ? 1 : 2, s, w2w);
+                                variant == 3 ? 1 : 2, s, w2w, w1w);
     } else if (variant == -1) {
         rc = 0;                                    // the two weight re-layout launches only (tools/fused_pair_bench.py subtracts them)
     } else {
-        set_error("resblock_pair: variant %d (1: first generation, 2 / 3: second generation with 256- / 128-column blocks, 4: 256 columns + Winograd phase B; `packed` then holds 2 C C k + C NG C floats)", variant);
+        set_error("resblock_pair: variant %d (1: first generation, 2 / 3: second generation with 256- / 128-column blocks, 4 / 5: 256 columns + Winograd phase B / both phases; `packed` then holds 2 C C k + 2 C NG C floats)", variant);
         rc = TTSAMD_EINVAL;
     }
     prof_end(s);

@@ -153,8 +153,10 @@ int32_t launch_fused_pair(int32_t channels, const float* x, float* y, const floa
 bool fused_pair2_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, const float* x, const float* y, int32_t ntw);
 int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const float* w1, const float* b1, const float* w2,
                            const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
-                           int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream, const float* w2_wino = nullptr);
-// (w2_wino: conv 2 as Winograd F(2,3) groups -- pack_wino2_weight; C = 32 / 64, ntw = 2: phase B of the pair runs on them)
+                           int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream, const float* w2_wino = nullptr,
+                           const float* w1_wino = nullptr);
+// (w2_wino: conv 2 as Winograd F(2,3) groups -- pack_wino2_weight; C = 32 / 64, ntw = 2: phase B of the pair runs on them; w1_wino:
+// conv 1 likewise -> phase A too)
 // Winograd F(2,3) path of the k = 3, dilation-1 convs (conv_wino.hip): routing test, launcher, host-side filter transform + packing
 int wino_route(const ConvParams& p);       // 0: direct kernel, 1: conv1d_wino_f32, 2: conv1d_wino2_f32 (conv_wino.hip)
 int32_t launch_wino(const ConvParams& p, hipStream_t stream);

@@ -78,7 +78,7 @@ static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
 // getenv calls, each a window for a concurrent setenv from another host thread (os.environ writes in Python do exactly that).
 struct Fused2Switches {
     bool on = true, mask_forced = false, small_on = false;
-    bool wino_b = true;            // phase B of the C = 32 / 64 pairs as Winograd F(2,3) (TTSAMD_FUSED2_WB=0: direct)
+    bool wino_b = true, wino_a = true;   // phase B / phase A + B of the C = 32 / 64 pairs as Winograd F(2,3) (TTSAMD_FUSED2_WB=0: both direct, =1: phase B only)
     unsigned mask = kFused2Mask, mask_n1 = kFused2MaskN1;
 };
 static bool parse_hex_mask(const char* txt, unsigned& out) {
@@ -100,6 +100,7 @@ static int32_t read_fused2_switches(Fused2Switches& sw) {
         TTS_REQUIRE(parse_hex_mask(m, sw.mask_n1), "TTSAMD_FUSED2_MASK_N1='%s' is not a hex mask of 9 bits", m);
     const char* wb = std::getenv("TTSAMD_FUSED2_WB");
     sw.wino_b = !(wb && wb[0] == '0');
+    sw.wino_a = sw.wino_b && !(wb && wb[0] == '1');
     const char* se = exp_env("TTSAMD_FUSED2_SMALL");
     sw.small_on = se && se[0] == '1';
     return 0;
@@ -662,7 +663,8 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
                         const int32_t frc = ntw2 != 0
                             ? launch_fused_pair2(w1.cin, src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
                                                  h->dev + w2.b_off, w1.k, d, lens, mul, L, B, mode, (float)cfg.n_kernels, 0.1f, ntw2, st,
-                                                 (f2sw.wino_b && w2.ww_off >= 0) ? h->dev + w2.ww_off : nullptr)
+                                                 (f2sw.wino_b && w2.ww_off >= 0) ? h->dev + w2.ww_off : nullptr,
+                                                 (f2sw.wino_a && w1.ww_off >= 0) ? h->dev + w1.ww_off : nullptr)
                             : launch_fused_pair(w1.cin, src, dst, h->dev + w1.w_off, h->dev + w1.b_off, h->dev + w2.w_off,
                                                 h->dev + w2.b_off, w1.k, d, lens, mul, L, B, mode, (float)cfg.n_kernels, 0.1f, st);
                         if (!in_section) prof_end(st);

@@ -31,7 +31,8 @@ struct FusedPair2Params {
     float* y;              // [B][C][L]; must not alias x (other blocks read x's halo)
     const float4* w1;      // packed [C/8 oct][K][2][C][4]
     const float4* w2;
-    const float4* w2w;     // WB kernels: conv 2 as Winograd F(2,3) groups, packed [C/8 oct][NGW][2][C][4] (conv_wino2.hip: pack_wino2_weight)
+    const float4* w1w;     // WM = 2 kernels: conv 1 as Winograd groups too
+    const float4* w2w;     // WM >= 1 kernels: conv 2 as Winograd F(2,3) groups, packed [C/8 oct][NGW][2][C][4] (conv_wino2.hip: pack_wino2_weight)
     const float* b1;
     const float* b2;
     const int64_t* lens;   // valid length = lens[b] * len_mul (nullptr -> L)
@@ -61,6 +62,10 @@ struct Fused2Geo {
     static_assert(NOCT % UO == 0 && (UO * K) % PF == 0, "unrolled body of the group loop");
     // resident blocks per CU the register budget is declared for (the LDS window decides at run time whether they fit)
     static constexpr int WAVES = (C == 128 && NTW == 2) ? 1 : (C == 32 ? 4 : 2);
+    // Winograd phase A at dilation d: output pairs (n, n + d), 128 pair slots of which d * (128 / d) tile the columns in groups of 2 d
+    // -> 256 / 252 / 250 intermediate columns at d = 1 / 3 / 5, outputs per block = those minus the halo, a multiple of 4
+    __host__ __device__ static constexpr int npa(int d) { return d * (128 / d); }
+    __host__ __device__ static constexpr int ts_wa(int d) { return (2 * npa(d) - 2 * H) & ~3; }
     static size_t lds_bytes(int dil) { return (size_t)2 * NOCT * (NB + (K - 1) * dil) * sizeof(float4); }
 };
 
@@ -140,23 +145,26 @@ __device__ __forceinline__ void conv_phase2(f32x16 (&acc)[C / 32][NTW], float4 (
 // row would be 2-way bank conflicts).  Per sub-filter: four float4 reads (x0..x3, one bundle ahead), V = x0 - x2, x1 + x2, x2 - x1,
 // x1 - x3 as packed adds, then its four groups of 4 MT MFMAs: 0.25 / MT reads and 0.5 / MT VALU per MFMA, 4/6, 10/14, 16/22 of the
 // direct phase's MFMAs.  `sb` = row (octet 0, this lane's kk), entry jw of the even array; rows are 2 TSH entries apart.
-template <int K, int C>
+// EO = false (phase A on the activated window): column c of the pair's sub-sequence is entry c * cstep (= the dilation) of a row of
+// `rstride` entries; `wnext`: the conv that follows (its first PF groups refill the queue at the tail), nullptr = none.
+template <int K, int C, bool EO>
 __device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][C / 32], float4 (&aq)[2][C / 32], const float4* sb,
-                                                 const float4* __restrict__ wl) {
+                                                 const float4* __restrict__ wl, const int rstride, const int cstep,
+                                                 const float4* __restrict__ wnext) {
     using G = Fused2Geo<K, C, 2>;
     constexpr int NOCT = G::NOCT, MT = G::MT, PF = G::PF, NS = G::NS, NL = G::NL, NGW = G::NGW, TSH = G::TSH;
     constexpr int NBU = NS + NL;                               // operand bundles per octet (a sub-filter: 4 entries, a single tap: 2)
     constexpr int NGT = NOCT * NGW;
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     // entry of intermediate column 2 jw + c
-#define TTS_ENT(SBO, CC) (SBO)[((CC) & 1) * TSH + ((CC) >> 1)]
+#define TTS_ENT(SBO, CC) (SBO)[EO ? ((CC) & 1) * TSH + ((CC) >> 1) : (CC) * cstep]
     float4 bq[2][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) bq[0][m] = TTS_ENT(sb, m);     // bundle 0 of octet 0 = sub-filter 0 (every k has one)
 #pragma unroll 1
     for (int o = 0; o < NOCT; ++o) {
-        const float4* sbo = sb + o * 4 * TSH;                  // (2 rows of 2 TSH per octet)
-        const float4* sbn = sb + min(o + 1, NOCT - 1) * 4 * TSH;
+        const float4* sbo = sb + o * 2 * rstride;              // (2 rows per octet)
+        const float4* sbn = sb + min(o + 1, NOCT - 1) * 2 * rstride;
 #pragma unroll
         for (int u = 0; u < NBU; ++u) {
             const int cur = u & 1, nxt = cur ^ 1;              // (NBU odd would flip the slots between octets: both k = 7 and 11 have NBU = 3 / 5 ... handled by `cur` below)
@@ -191,9 +199,11 @@ __device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][C / 32], float
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a4[mt] = aq[slot][mt];
                 {
-                    const int gn = min(o * NGW + g + PF, NGT - 1);         // (past the last group: an L1 hit, unused)
+                    const int gn = o * NGW + g + PF;                       // (past the last group of the last conv: an L1 hit, unused)
+                    const float4* __restrict__ src = gn < NGT ? wl + (int64_t)gn * 2 * C
+                                                              : (wnext ? wnext + (int64_t)(gn - NGT) * 2 * C : wl + (int64_t)(NGT - 1) * 2 * C);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) aq[slot][mt] = wl[(int64_t)gn * 2 * C + 32 * mt];
+                    for (int mt = 0; mt < MT; ++mt) aq[slot][mt] = src[32 * mt];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -213,11 +223,15 @@ __device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][C / 32], float
 #undef TTS_ENT
 }
 
-template <int K, int C, int NTW, bool WB>
+// WM = 0: both convs direct; 1: phase B (c2, dilation 1) as Winograd F(2,3); 2: phase A too -- then the window is staged ACTIVATED (one
+// leaky-relu per value instead of one per use) and the residual comes from global memory in the row epilogue (an L2 hit).
+template <int K, int C, int NTW, int WM>
 __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_pair2(const FusedPair2Params p) {
     using G = Fused2Geo<K, C, NTW>;
-    constexpr int NOCT = G::NOCT, MT = G::MT, H = G::H, NB = G::NB, TS = G::TS, TSTR = G::TSTR, PF = G::PF, TSH = G::TSH;
+    constexpr int NOCT = G::NOCT, MT = G::MT, H = G::H, NB = G::NB, TSTR = G::TSTR, PF = G::PF, TSH = G::TSH;
+    constexpr bool WB = WM >= 1, WA = WM == 2;
     static_assert(!WB || NTW == 2, "Winograd phase B: a wave's 64 columns are its 32 output pairs");
+    const int TS = WA ? G::ts_wa(p.dil) : G::TS;               // outputs per block
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int kk = lane >> 5, l31 = lane & 31;
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 
     // ---- weight queue: group g = (octet, tap) of conv 1 sits at w1 + g * 2C, this lane's fragment of row tile mt at
     // + kk * C + 32 mt + l31.  The first PF groups go out before anything else.
-    const float4* __restrict__ wl1 = p.w1 + kk * C + l31;
+    const float4* __restrict__ wl1 = (WA ? p.w1w : p.w1) + kk * C + l31;
     const float4* __restrict__ wl2 = (WB ? p.w2w : p.w2) + kk * C + l31;
     float4 aq[PF][MT];
 #pragma unroll
@@ -284,10 +298,95 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
         }
 #pragma unroll
         for (int u = 0; u < NE; ++u)
-            if (eo[u] >= 0) Xs[eo[u]] = ok[u] ? make_float4(v[u][0], v[u][1], v[u][2], v[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (eo[u] >= 0) {
+                if (WA) {
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) v[u][pc] = lrelu_max(v[u][pc], slope);
+                }
+                Xs[eo[u]] = ok[u] ? make_float4(v[u][0], v[u][1], v[u][2], v[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
     }
     __syncthreads();
 
+    float* ep = reinterpret_cast<float*>(smem4);               // [C][NB]: the epilogue's row buffer (the intermediate is dead by then)
+    if constexpr (WA) {
+        // ---- BOTH phases as Winograd F(2,3).  Phase A: pair slot jw of the block -> intermediate columns (na, na + dil), na =
+        // (jw / d) 2 d + jw % d; slots past d (128 / d) idle.  Planes start from b1 -> P0, -b1 -> P3.
+        const int jw = wid * 32 + l31;
+        const int npa = G::npa(dil);
+        const int pa = min(jw, npa - 1);
+        const int na = dil == 1 ? 2 * pa : (pa / dil) * 2 * dil + pa % dil;
+        {
+            f32x16 accA[4][MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bv = p.b1[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk];
+                    accA[0][mt][r] = bv; accA[1][mt][r] = 0.f; accA[2][mt][r] = 0.f; accA[3][mt][r] = -bv;
+                }
+            conv_phase2_wino<K, C, false>(accA, aq, Xs + kk * W1 + na, wl1, W1, dil, wl2);
+            __syncthreads();                                   // every wave is done with the window
+            // intermediate -> LDS: lrelu(y), zero outside the utterance, even / odd columns apart (phase B's layout)
+            if (jw < npa) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int col = na + hh * dil;
+                    const int pos = q0 - H + col;
+                    const bool live = pos >= 0 && pos < len;
+                    const int ent = (col & 1) * TSH + (col >> 1);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+                            for (int k2 = 0; k2 < 2; ++k2) {
+                                const int r = 4 * oc + k2;
+                                float v0 = hh ? accA[1][mt][r] - accA[2][mt][r] - accA[3][mt][r] : accA[0][mt][r] + accA[1][mt][r] + accA[2][mt][r];
+                                float v1 = hh ? accA[1][mt][r + 2] - accA[2][mt][r + 2] - accA[3][mt][r + 2]
+                                              : accA[0][mt][r + 2] + accA[1][mt][r + 2] + accA[2][mt][r + 2];
+                                v0 = lrelu_max(v0, slope);
+                                v1 = lrelu_max(v1, slope);
+                                const float2 w2v = live ? make_float2(v0, v1) : make_float2(0.f, 0.f);
+                                *reinterpret_cast<float2*>(reinterpret_cast<float*>(Xs + ((4 * mt + oc) * 2 + k2) * 2 * TSH + ent) + 2 * kk) = w2v;
+                            }
+                }
+            }
+            __syncthreads();
+        }
+        // phase B planes: zero, + the running ResBlock sum (y[2 jw] -> P0, -y[2 jw + 1] -> P3); the residual joins in the row epilogue
+        f32x16 accw[4][MT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[g][mt][r] = 0.f;
+        if (p.mode != 0) {
+            const int n = 2 * jw, q = q0 + n;
+            const int voff = ((n < TS && q < len) ? q : 0) * 4 + 4 * kk * L * 4;
+            const auto ys = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)b * C * L, 0, C * L * 4, 0x00020000);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * mt + (r & 3) + 8 * (r >> 2)) * L * 4;
+                    accw[0][mt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff, so, 0));
+                    accw[3][mt][r] = -__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff + 4, so, 0));
+                }
+        }
+        conv_phase2_wino<K, C, true>(accw, aq, Xs + kk * 2 * TSH + jw, wl2, 2 * TSH, 0, nullptr);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float2 y2;
+                y2.x = accw[0][mt][r] + accw[1][mt][r] + accw[2][mt][r];
+                y2.y = accw[1][mt][r] - accw[2][mt][r] - accw[3][mt][r];
+                *reinterpret_cast<float2*>(ep + (32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk) * NB + 2 * jw) = y2;
+            }
+    } else {
     const int colw = wid * 32 * NTW + l31;                     // this lane's MFMA column (j = 0), + 32 j
     // phase A accumulators start from b1 (row = channel 32mt + (r&3) + 8(r>>2) + 4kk)
     f32x16 acc[MT][NTW];
@@ -305,7 +404,6 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 #endif
     conv_phase2<K, C, NTW, true>(acc, aq, Xs + kk * W1 + colw, W1, dil, wl1, wl2, slope);
 
-    float* ep = reinterpret_cast<float*>(smem4);               // [C][NB]: the epilogue's row buffer (the intermediate is dead by then)
     if constexpr (WB) {
         // ---- Winograd phase B: four planes per row tile for this lane's output pair (2 jw, 2 jw + 1); the residual (raw x out of
         // the window, exact) and the running ResBlock sum enter as x[2 jw] -> P0, -x[2 jw + 1] -> P3
@@ -375,7 +473,7 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
         }
         __syncthreads();
 
-        conv_phase2_wino<K, C>(accw, aq, Xs + kk * 2 * TSH + jw, wl2);
+        conv_phase2_wino<K, C, true>(accw, aq, Xs + kk * 2 * TSH + jw, wl2, 2 * TSH, 0, nullptr);
 
         // ---- output transform into the row buffer: y[2 jw] = P0 + P1 + P2, y[2 jw + 1] = P1 - P2 - P3
         __syncthreads();
@@ -468,6 +566,7 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 #pragma unroll
             for (int r = 0; r < 16; ++r) ep[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk) * NB + colw + 32 * j] = acc2[mt][j][r];
     }
+    }
     __syncthreads();
     const bool do_div = p.mode == 2;
     const float div = p.div;
@@ -485,6 +584,17 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
         if (n >= TS || q >= len) continue;
         const float4 v4 = *reinterpret_cast<const float4*>(ep + ch * NB + n);
         float vv[4] = {v4.x + bs, v4.y + bs, v4.z + bs, v4.w + bs};
+        if (WA) {      // the residual: raw x from memory (the window was staged activated); q is a multiple of 4, rows are float4-aligned
+            const float* xp = xb + (int64_t)ch * L + q;
+            if (q + 3 < len) {
+                const float4 x4 = *reinterpret_cast<const float4*>(xp);
+                vv[0] += x4.x; vv[1] += x4.y; vv[2] += x4.z; vv[3] += x4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q + e < len) vv[e] += xp[e];
+            }
+        }
         if (do_div) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) vv[e] = vv[e] / div;
@@ -504,13 +614,14 @@ __global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_p
 }
 
 
-template <int K, int C, int NTW, bool WB>
+template <int K, int C, int NTW, int WM>
 static int32_t launch_fused2_k(const FusedPair2Params& p, hipStream_t stream) {
     using G = Fused2Geo<K, C, NTW>;
     static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
-    TTS_CHECK_HIP(lds_opt_in((const void*)resblock_pair2<K, C, NTW, WB>, (int)G::lds_bytes(DMAX), lds_done));
-    dim3 grid((p.L + G::TS - 1) / G::TS, 1, p.batch);
-    hipLaunchKernelGGL((resblock_pair2<K, C, NTW, WB>), grid, dim3(256), G::lds_bytes(p.dil), stream, p);
+    TTS_CHECK_HIP(lds_opt_in((const void*)resblock_pair2<K, C, NTW, WM>, (int)G::lds_bytes(DMAX), lds_done));
+    const int ts = WM == 2 ? G::ts_wa(p.dil) : G::TS;
+    dim3 grid((p.L + ts - 1) / ts, 1, p.batch);
+    hipLaunchKernelGGL((resblock_pair2<K, C, NTW, WM>), grid, dim3(256), G::lds_bytes(p.dil), stream, p);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -527,28 +638,33 @@ bool fused_pair2_supported(int32_t channels, int32_t k, int32_t dil, int32_t L, 
 
 int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const float* w1, const float* b1, const float* w2,
                            const float* b2, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L, int32_t batch,
-                           int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream, const float* w2_wino) {
+                           int32_t mode, float div, float slope, int32_t ntw, hipStream_t stream, const float* w2_wino,
+                           const float* w1_wino) {
     TTS_REQUIRE(fused_pair2_supported(channels, k, dil, L, x, y, ntw),
                 "fused ResBlock pair (direct weights): unsupported geometry (C=%d, k=%d, dil=%d, L=%d, ntw=%d)", channels, k, dil, L, ntw);
     TTS_REQUIRE(slope > 0.f && slope <= 1.f, "fused ResBlock pair: leaky-relu slope %g outside (0, 1]", (double)slope);
     // w2_wino (conv 2 as Winograd groups, pack_wino2_weight): phase B on F(2,3) -- 256-column blocks of C = 32 / 64 only
+    // ... + w1_wino: phase A too (dilations 1 / 3 / 5: 256 / 252 / 250 intermediate columns per block)
     const bool wb = w2_wino != nullptr && ntw == 2 && channels <= 64;
-    conv_log(wb ? "fused_pair2w" : (ntw == 2 ? "fused_pair2" : "fused_pair2n"), k, channels, channels, L, batch, 1, mode, len_mul, lens != nullptr, 1);
+    const bool wa = wb && w1_wino != nullptr && (dil == 1 || dil == 3 || dil == 5);
+    conv_log(wa ? "fused_pair2ww" : wb ? "fused_pair2w" : (ntw == 2 ? "fused_pair2" : "fused_pair2n"), k, channels, channels, L, batch, 1, mode, len_mul, lens != nullptr, 1);
     FusedPair2Params p;
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.y = y;
     p.w1 = reinterpret_cast<const float4*>(w1); p.w2 = reinterpret_cast<const float4*>(w2);
     p.w2w = reinterpret_cast<const float4*>(w2_wino);
+    p.w1w = reinterpret_cast<const float4*>(w1_wino);
     p.b1 = b1; p.b2 = b2; p.lens = lens; p.len_mul = len_mul; p.L = L; p.dil = dil; p.batch = batch;
     p.mode = mode; p.div = div; p.slope = slope;
     p.compact = compact_order(lens, batch) ? 1 : 0;
 #ifdef TTS_F2_EXP
     if (const char* e = exp_env("TTSAMD_F2_EXP")) p.exp = atoi(e);
 #endif
-#define TTS_F2W(KK, CC) if (wb && k == KK && channels == CC) return launch_fused2_k<KK, CC, 2, true>(p, stream);
+#define TTS_F2W(KK, CC) if (wa && k == KK && channels == CC) return launch_fused2_k<KK, CC, 2, 2>(p, stream); \
+                        if (wb && k == KK && channels == CC) return launch_fused2_k<KK, CC, 2, 1>(p, stream);
     TTS_F2W(3, 32) TTS_F2W(7, 32) TTS_F2W(11, 32) TTS_F2W(3, 64) TTS_F2W(7, 64) TTS_F2W(11, 64)
 #undef TTS_F2W
-#define TTS_F2(KK, CC, NN) if (k == KK && channels == CC && ntw == NN) return launch_fused2_k<KK, CC, NN, false>(p, stream);
+#define TTS_F2(KK, CC, NN) if (k == KK && channels == CC && ntw == NN) return launch_fused2_k<KK, CC, NN, 0>(p, stream);
     TTS_F2(3, 32, 2) TTS_F2(7, 32, 2) TTS_F2(11, 32, 2)
     TTS_F2(3, 64, 2) TTS_F2(7, 64, 2) TTS_F2(11, 64, 2)
     TTS_F2(3, 128, 2) TTS_F2(7, 128, 2) TTS_F2(11, 128, 2)
