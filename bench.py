@@ -752,7 +752,7 @@ def main():
                 'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
-                    'kernel': ('MFMA conv engine: conv1d_wino2_f32 (Winograd F(2,3) decomposition, k = 3 / 7 / 11) + resblock_pair2 (fused C = 32 / 64 pairs, phase B on F(2,3)) + conv1d_mfma_f32 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
+                    'kernel': ('MFMA conv engine: conv1d_wino2_f32 (Winograd F(2,3) decomposition, k = 3 / 7 / 11) + resblock_pair2 (fused C = 32 / 64 pairs, both phases on F(2,3)) + conv1d_mfma_f32 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
             if args.precision == 'f32':
                 # products the Winograd launches do NOT issue (conv_wino2.hip: k = 3 / 7 / 11 as F(2,3) sub-filters + single taps: 4/6,
@@ -765,8 +765,8 @@ def main():
                 roof['frac_issued'] = issued / peak
                 roof['flops_basis'] = ('`achieved` / `frac`: UN-REDUCED algorithmic FLOPs (2 Cout Cin K per valid output position) over kernel time.  '
                                        '`issued` / `frac_issued`: the same minus the products the Winograd F(2,3) launches do not issue (k = 3 / 7 / 11 '
-                                       'convs as three-tap sub-filters + single taps: 4/6, 10/14, 16/22 of the direct products; HiFi-GAN C >= 128 ResBlock convs and the C = 64 '
-                                       'k = 11 pairs at every dilation, the c2 conv of the fused C = 32 / 64 pairs, FastPitch decoder conv-FF) = what the MFMA pipe '
+                                       'convs as three-tap sub-filters + single taps: 4/6, 10/14, 16/22 of the direct products; every ResBlock conv of HiFi-GAN '
+                                       '(C >= 128 un-fused, C = 32 / 64 inside the fused pairs), FastPitch decoder conv-FF) = what the MFMA pipe '
                                        'executed against its peak.  '
                                        'TTSAMD_WINO=0 runs the direct kernels (profiles/r5/wino_off_bench_line.json)')
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
@@ -1150,8 +1150,8 @@ def hifigan_flops_per_frame(h):
 
 def hifigan_wino_saved_flops_per_frame(h):
     """Products per mel frame that the Winograd kernels do not issue (kernel sizes 3 / 7 / 11: 4/6, 10/14, 16/22 of the direct conv's
-    products): every ResBlock conv of the stages with >= 128 channels and the un-fused C = 64 k = 11 pairs (csrc/conv_wino2.hip), the c2
-    conv -- phase B -- of the fused C = 32 / 64 pairs (csrc/resblock_fused2.hip).  Default routing (hifigan.hip: kFused2Mask)."""
+    products): every ResBlock conv -- the stages with >= 128 channels on csrc/conv_wino2.hip, both phases of the fused C = 32 / 64 pairs
+    (csrc/resblock_fused2.hip).  Default routing (hifigan.hip: kFused2Mask)."""
     ch, mul, f = h['upsample_initial_channel'], 1, 0.0
     for u in h['upsample_rates']:
         ch, mul = ch // 2, mul * u
@@ -1159,9 +1159,7 @@ def hifigan_wino_saved_flops_per_frame(h):
             if kk not in (3, 7, 11) or ch < 32:
                 continue
             ng = 4 * (kk // 3) + 2 * (kk % 3)
-            fused = ch == 32 or (ch == 64 and kk in (3, 7))
-            convs = len(dil) * (1 if fused else 2)          # fused pairs: the c2 conv only
-            f += convs * (2.0 * ch * ch * kk) * mul * (1.0 - ng / (2.0 * kk))
+            f += len(dil) * 2 * (2.0 * ch * ch * kk) * mul * (1.0 - ng / (2.0 * kk))
     return f
 
 
