@@ -225,8 +225,11 @@ __device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][C / 32], float
 
 // WM = 0: both convs direct; 1: phase B (c2, dilation 1) as Winograd F(2,3); 2: phase A too -- then the window is staged ACTIVATED (one
 // leaky-relu per value instead of one per use) and the residual comes from global memory in the row epilogue (an L2 hit).
+#ifndef TTS_F2_WA32_WAVES
+#define TTS_F2_WA32_WAVES 3     /* resident blocks per CU the C = 32 kernels with both phases on Winograd are compiled for: 170 registers, no spills (4: 128 registers, 40-56 bytes of scratch at k = 7 / 11; 61.80 vs 61.94 ms per step) */
+#endif
 template <int K, int C, int NTW, int WM>
-__global__ __launch_bounds__(256, (Fused2Geo<K, C, NTW>::WAVES)) void resblock_pair2(const FusedPair2Params p) {
+__global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fused2Geo<K, C, NTW>::WAVES)) void resblock_pair2(const FusedPair2Params p) {
     using G = Fused2Geo<K, C, NTW>;
     constexpr int NOCT = G::NOCT, MT = G::MT, H = G::H, NB = G::NB, TSTR = G::TSTR, PF = G::PF, TSH = G::TSH;
     constexpr bool WB = WM >= 1, WA = WM == 2;
