@@ -1,20 +1,23 @@
-// Winograd F(2,3) DECOMPOSITION of the longer dilation-1 filters of the exact-fp32 engine: a k = 7 / 11 Conv1d is the sum of
-// NS = k / 3 three-tap sub-filters (each one F(2,3): 4 products per output pair instead of 6) and NL = k - 3 NS single taps
-// (2 products per pair): 10 instead of 14 products per pair at k = 7 (0.71), 16 instead of 22 at k = 11 (0.73), 4 instead of 6 at
-// k = 3 -- with the transforms of F(2,3) only (entries 0, +-1, +-1/2: fp32-safe; a direct F(2,7) / F(2,11) is not).  The output
-// transform is linear and the same for every sub-filter, so ALL groups of a conv accumulate into the same four planes
-//     P_i += U_{s,i} V_{s,i}   (sub-filter s, i = 0..3),      P_0 += g_t x[2j - pad + t],  P_3 += (-g_t) x[2j + 1 - pad + t]   (single tap t)
-//     y[2j] = P_0 + P_1 + P_2,   y[2j + 1] = P_1 - P_2 - P_3
-// and the kernel is the one of conv_wino.hip with NG = 4 NS + 2 NL operand groups per octet.  Serves the c2 convs of HiFi-GAN's
-// un-fused k = 7 / 11 ResBlock pairs and their c1 convs at dilation 1 (vocoder/hifigan/models.py:30-53): two thirds of the 45 ms the
-// k >= 7 launches take in a 76 ms step.
+// Winograd F(2,3) DECOMPOSITION kernel of the exact-fp32 engine: a k = 3 / 7 / 11 Conv1d is the sum of NS = k / 3 three-tap
+// sub-filters (each one F(2,3): 4 products per output pair instead of 6) and NL = k - 3 NS single taps (2 products per pair):
+// 4 instead of 6 products per pair at k = 3, 10 instead of 14 at k = 7 (0.71), 16 instead of 22 at k = 11 (0.73) -- with the
+// transforms of F(2,3) only (entries 0, +-1, +-1/2: fp32-safe; a direct F(2,7) / F(2,11) is not).  The output transform is linear
+// and the same for every sub-filter, so ALL groups of a conv accumulate into the same four planes
+//     P_i += U_{s,i} V_{s,i}   (sub-filter s, i = 0..3),      P_0 += g_t x[q + (t - pad) d],  P_3 += (-g_t) x[q + d + (t - pad) d]   (single tap t)
+//     y[q] = P_0 + P_1 + P_2,   y[q + d] = P_1 - P_2 - P_3          (dilation d: the output pair is (q, q + d))
+// Serves every ResBlock conv of HiFi-GAN's stages with 128 / 256 channels and the un-fused ones with 64 (vocoder/hifigan/models.py:
+// 30-53) and FastPitch's conv-FF convs (transformer.py:59-65); routing: wino_route (conv_wino.hip).  tests/test_wino_decomposition_cpu.py
+// states the arithmetic in numpy, tests/test_gpu_wino.py checks the kernel against float64.
 //
-// What differs from conv_wino.hip:
+// Anatomy (what differs from the round's first Winograd kernel, conv_wino.hip):
 //   * the WEIGHTS DO NOT GO THROUGH LDS (NG x 2 x 128 float4 per octet would be 40-64 KB per stage): a wave reads its own A fragments
 //     -- one 16-byte load per lane and (group, 32-row tile), 1 KB contiguous per wave instruction, the packed layout
 //     [Cin/8][NG][2][CoutP][4] is the operand order -- from L2 into a register queue PF groups ahead (as resblock_fused2.hip);
-//   * LDS = the transformed / shifted input planes only: [octet][kk][NG][pair] float4, 16-32 KB per stage;
-//   * a thread stages 2 channels x (K + 1) positions per octet and writes its two float4 components of the NG planes.
+//   * LDS = the transformed / shifted input planes only: [octet][kk][group][pair] float4, 16-40 KB per stage;
+//   * staging without clamps or masks: a wave instruction reads one channel row, the row is the base of a raw buffer descriptor and the
+//     range check returns the halo zeros; leaky-relu once per loaded value pair, planes as packed adds -- 0.8 VALU per MFMA (the first
+//     version, activation and mask inside every plane expression: 3.1, and no faster than the direct kernel);
+//   * 128 rows x 64 pairs per block (2 x 2 waves), or 64 rows x 128 pairs (1 x 4) for Cout = 64 with k = 11 in two PHASES of 8 groups.
 #include <cstdlib>
 #include <cstring>
 
