@@ -37,6 +37,7 @@ CASES += [(c, k, d, 4) for c in (32, 64) for k in (3, 7, 11) for d in (1, 5)] + 
 # variant 5: phase A too (output pairs (n, n + d): 256 / 252 / 250 intermediate columns per block at d = 1 / 3 / 5), window staged activated,
 # residual from memory in the row epilogue
 CASES += [(c, k, d, 5) for c in (32, 64) for k in (3, 7, 11) for d in (1, 3, 5)]
+CASES += [(128, 3, 1, 5), (128, 3, 3, 5), (128, 3, 5, 5), (128, 7, 3, 5), (128, 11, 5, 5)]      # C = 128: the 8-wave block (two row halves)
 
 
 @pytest.mark.parametrize('C,k,dil,variant', CASES)

@@ -415,7 +415,8 @@ int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const fl
     } else if (variant >= 2 && variant <= 5) {
         const float *w2w = nullptr, *w1w = nullptr;
         if (variant >= 4) {       // 256-column blocks with phase B (4) or both phases (5) on Winograd F(2,3): the groups behind the direct packings
-            TTS_REQUIRE((k == 3 || k == 7 || k == 11) && channels <= 64, "resblock_pair: variants 4 / 5 are built for C = 32 / 64, k = 3 / 7 / 11");
+            TTS_REQUIRE((k == 3 || k == 7 || k == 11) && (channels <= 64 || (variant == 5 && channels == 128)),
+                        "resblock_pair: variants 4 / 5 are built for C = 32 / 64 (5: and 128), k = 3 / 7 / 11");
             const int64_t nw = (int64_t)channels * wino2_groups(k) * channels;
             for (int i = 0; i < (variant == 5 ? 2 : 1); ++i) {
                 float* wino = packed + 2 * n + i * nw;

@@ -16,11 +16,11 @@
 namespace ttsamd {
 
 // default routing of the second-generation fused pair (fused2_choice below), set from same-box A/B runs of the bench workload
-constexpr unsigned kFused2Mask = 0x03F;       // C = 32 and C = 64: k = 3 / 7 / 11.  (C = 64 k = 11 joined when both phases of the pair went to Winograd
-                                              // F(2,3): 61.93 vs 62.45 ms per step; C = 128 k = 3 left the list in round 5: un-fused, its convs run on
-                                              // the Winograd decomposition kernel -- 74.59 vs 74.92-75.03 ms, tools/ab_env.sh)
-constexpr unsigned kFused2MaskN1 = 0x040;     // 128-column blocks: C = 128, k = 3 (two blocks per CU).  (C = 64, k = 3 left in round 5: the 256-column
-                                              // kernel has the Winograd phase B -- 63.45 vs 63.65 ms per step)
+constexpr unsigned kFused2Mask = 0x07F;       // C = 32 and C = 64: k = 3 / 7 / 11; C = 128: k = 3.  Both convs of these pairs run on Winograd F(2,3) inside the
+                                              // launch (resblock_pair2<..., WM = 2>; C = 128: the 8-wave block).  Same-box A/B (tools/ab_env.sh): C = 64
+                                              // k = 11 fused 61.93 vs 62.45 ms per step; C = 128 k = 3 fused 63.90 vs 64.06 (its un-fused k = 3 launches sit
+                                              // at both roofs), + k = 7 64.23, + k = 11 65.36 (MFMA-bound either way: the halo recompute costs more)
+constexpr unsigned kFused2MaskN1 = 0x000;     // 128-column blocks (the direct-arithmetic kernels only): none by default
 constexpr int64_t kFused2SmallColumns = 2 * 256 * 252;   // batch x positions under which a stage counts as a small problem
 
 struct ConvW {

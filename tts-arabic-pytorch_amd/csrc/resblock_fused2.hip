@@ -147,12 +147,13 @@ __device__ __forceinline__ void conv_phase2(f32x16 (&acc)[C / 32][NTW], float4 (
 // direct phase's MFMAs.  `sb` = row (octet 0, this lane's kk), entry jw of the even array; rows are 2 TSH entries apart.
 // EO = false (phase A on the activated window): column c of the pair's sub-sequence is entry c * cstep (= the dilation) of a row of
 // `rstride` entries; `wnext`: the conv that follows (its first PF groups refill the queue at the tail), nullptr = none.
-template <int K, int C, bool EO>
-__device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][C / 32], float4 (&aq)[2][C / 32], const float4* sb,
+// MTW: 32-row tiles this wave owns (C / 32, or half of them in the 8-wave C = 128 kernel: `wl` then points at its first row).
+template <int K, int C, bool EO, int MTW>
+__device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][MTW], float4 (&aq)[2][MTW], const float4* sb,
                                                  const float4* __restrict__ wl, const int rstride, const int cstep,
                                                  const float4* __restrict__ wnext) {
     using G = Fused2Geo<K, C, 2>;
-    constexpr int NOCT = G::NOCT, MT = G::MT, PF = G::PF, NS = G::NS, NL = G::NL, NGW = G::NGW, TSH = G::TSH;
+    constexpr int NOCT = G::NOCT, MT = MTW, PF = G::PF, NS = G::NS, NL = G::NL, NGW = G::NGW, TSH = G::TSH;
     constexpr int NBU = NS + NL;                               // operand bundles per octet (a sub-filter: 4 entries, a single tap: 2)
     constexpr int NGT = NOCT * NGW;
     typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -228,16 +229,24 @@ __device__ __forceinline__ void conv_phase2_wino(f32x16 (&acc)[4][C / 32], float
 #ifndef TTS_F2_WA32_WAVES
 #define TTS_F2_WA32_WAVES 3     /* resident blocks per CU the C = 32 kernels with both phases on Winograd are compiled for: 170 registers, no spills (4: 128 registers, 40-56 bytes of scratch at k = 7 / 11; 61.80 vs 61.94 ms per step) */
 #endif
+// C = 128 with both phases on Winograd: EIGHT waves per block (two row halves x four column groups) -- four planes x 128 rows do not
+// fit one wave's registers; one block per CU (the 136 KB window).
+template <int C, int WM>
+constexpr int f2_row_halves() { return (WM == 2 && C == 128) ? 2 : 1; }
+
 template <int K, int C, int NTW, int WM>
-__global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fused2Geo<K, C, NTW>::WAVES)) void resblock_pair2(const FusedPair2Params p) {
+__global__ __launch_bounds__((256 * f2_row_halves<C, WM>()), ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fused2Geo<K, C, NTW>::WAVES))
+void resblock_pair2(const FusedPair2Params p) {
     using G = Fused2Geo<K, C, NTW>;
     constexpr int NOCT = G::NOCT, MT = G::MT, H = G::H, NB = G::NB, TSTR = G::TSTR, PF = G::PF, TSH = G::TSH;
     constexpr bool WB = WM >= 1, WA = WM == 2;
+    constexpr int RH = f2_row_halves<C, WM>(), MTW = MT / RH, NTH = 256 * RH;       // row halves, row tiles per wave, threads per block
     static_assert(!WB || NTW == 2, "Winograd phase B: a wave's 64 columns are its 32 output pairs");
     const int TS = WA ? G::ts_wa(p.dil) : G::TS;               // outputs per block
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int kk = lane >> 5, l31 = lane & 31;
+    const int cg = wid & 3, mt0 = RH == 2 ? MTW * (wid >> 2) : 0;      // column group; first 32-row tile of this wave
     int b = blockIdx.z;
     int q0 = blockIdx.x * TS;
     if (p.compact) {   // ragged batch: dead blocks last (common.hpp: live_tile)
@@ -268,19 +277,19 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
 
     // ---- weight queue: group g = (octet, tap) of conv 1 sits at w1 + g * 2C, this lane's fragment of row tile mt at
     // + kk * C + 32 mt + l31.  The first PF groups go out before anything else.
-    const float4* __restrict__ wl1 = (WA ? p.w1w : p.w1) + kk * C + l31;
-    const float4* __restrict__ wl2 = (WB ? p.w2w : p.w2) + kk * C + l31;
-    float4 aq[PF][MT];
+    const float4* __restrict__ wl1 = (WA ? p.w1w : p.w1) + kk * C + l31 + 32 * mt0;
+    const float4* __restrict__ wl2 = (WB ? p.w2w : p.w2) + kk * C + l31 + 32 * mt0;
+    float4 aq[PF][MTW];
 #pragma unroll
     for (int g = 0; g < PF; ++g)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) aq[g][mt] = wl1[g * 2 * C + 32 * mt];
+        for (int mt = 0; mt < MTW; ++mt) aq[g][mt] = wl1[g * 2 * C + 32 * mt];
 
     // ---- the window: entry e = (o, kk_e, col), four scalar loads (consecutive lanes = consecutive positions), zero outside
     // the utterance, written raw.  ALL of a thread's loads go out before its first LDS write (nothing else is live yet: up to
     // 4 NE registers): one memory round trip for the whole window instead of one per batch of entries.
     {
-        constexpr int NE = (2 * NOCT * (NB + (K - 1) * DMAX) + 255) / 256;     // entries per thread at the widest dilation
+        constexpr int NE = (2 * NOCT * (NB + (K - 1) * DMAX) + NTH - 1) / NTH;     // entries per thread at the widest dilation
         const int n_ent = 2 * NOCT * W1;
         float v[NE][4];
         int eo[NE];
@@ -292,11 +301,11 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
             const int pos = x0 + col;
             const int okc = min(okk, 2 * NOCT - 1);
             ok[u] = pos >= 0 && pos < len;
-            eo[u] = tid + 256 * u < n_ent ? okc * W1 + col : -1;
+            eo[u] = tid + NTH * u < n_ent ? okc * W1 + col : -1;
             const float* src = xb + (int64_t)((okc >> 1) * 8 + (okc & 1)) * L + min(max(pos, 0), max(len - 1, 0));
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) v[u][pc] = src[(int64_t)2 * pc * L];
-            col += 256;
+            col += NTH;
             while (col >= W1) { col -= W1; ++okk; }
         }
 #pragma unroll
@@ -315,20 +324,20 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
     if constexpr (WA) {
         // ---- BOTH phases as Winograd F(2,3).  Phase A: pair slot jw of the block -> intermediate columns (na, na + dil), na =
         // (jw / d) 2 d + jw % d; slots past d (128 / d) idle.  Planes start from b1 -> P0, -b1 -> P3.
-        const int jw = wid * 32 + l31;
+        const int jw = cg * 32 + l31;
         const int npa = G::npa(dil);
         const int pa = min(jw, npa - 1);
         const int na = dil == 1 ? 2 * pa : (pa / dil) * 2 * dil + pa % dil;
         {
-            f32x16 accA[4][MT];
+            f32x16 accA[4][MTW];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bv = p.b1[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk];
+                    const float bv = p.b1[32 * (mt0 + mt) + (r & 3) + 8 * (r >> 2) + 4 * kk];
                     accA[0][mt][r] = bv; accA[1][mt][r] = 0.f; accA[2][mt][r] = 0.f; accA[3][mt][r] = -bv;
                 }
-            conv_phase2_wino<K, C, false>(accA, aq, Xs + kk * W1 + na, wl1, W1, dil, wl2);
+            conv_phase2_wino<K, C, false, MTW>(accA, aq, Xs + kk * W1 + na, wl1, W1, dil, wl2);
             __syncthreads();                                   // every wave is done with the window
             // intermediate -> LDS: lrelu(y), zero outside the utterance, even / odd columns apart (phase B's layout)
             if (jw < npa) {
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
                     const bool live = pos >= 0 && pos < len;
                     const int ent = (col & 1) * TSH + (col >> 1);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                         for (int oc = 0; oc < 4; ++oc)
 #pragma unroll
@@ -351,18 +360,18 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
                                 v0 = lrelu_max(v0, slope);
                                 v1 = lrelu_max(v1, slope);
                                 const float2 w2v = live ? make_float2(v0, v1) : make_float2(0.f, 0.f);
-                                *reinterpret_cast<float2*>(reinterpret_cast<float*>(Xs + ((4 * mt + oc) * 2 + k2) * 2 * TSH + ent) + 2 * kk) = w2v;
+                                *reinterpret_cast<float2*>(reinterpret_cast<float*>(Xs + ((4 * (mt0 + mt) + oc) * 2 + k2) * 2 * TSH + ent) + 2 * kk) = w2v;
                             }
                 }
             }
             __syncthreads();
         }
         // phase B planes: zero, + the running ResBlock sum (y[2 jw] -> P0, -y[2 jw + 1] -> P3); the residual joins in the row epilogue
-        f32x16 accw[4][MT];
+        f32x16 accw[4][MTW];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accw[g][mt][r] = 0.f;
         if (p.mode != 0) {
@@ -370,24 +379,24 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
             const int voff = ((n < TS && q < len) ? q : 0) * 4 + 4 * kk * L * 4;
             const auto ys = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)b * C * L, 0, C * L * 4, 0x00020000);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int so = (32 * mt + (r & 3) + 8 * (r >> 2)) * L * 4;
+                    const int so = (32 * (mt0 + mt) + (r & 3) + 8 * (r >> 2)) * L * 4;
                     accw[0][mt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff, so, 0));
                     accw[3][mt][r] = -__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, voff + 4, so, 0));
                 }
         }
-        conv_phase2_wino<K, C, true>(accw, aq, Xs + kk * 2 * TSH + jw, wl2, 2 * TSH, 0, nullptr);
+        conv_phase2_wino<K, C, true, MTW>(accw, aq, Xs + kk * 2 * TSH + jw, wl2, 2 * TSH, 0, nullptr);
         __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float2 y2;
                 y2.x = accw[0][mt][r] + accw[1][mt][r] + accw[2][mt][r];
                 y2.y = accw[1][mt][r] - accw[2][mt][r] - accw[3][mt][r];
-                *reinterpret_cast<float2*>(ep + (32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk) * NB + 2 * jw) = y2;
+                *reinterpret_cast<float2*>(ep + (32 * (mt0 + mt) + (r & 3) + 8 * (r >> 2) + 4 * kk) * NB + 2 * jw) = y2;
             }
     } else {
     const int colw = wid * 32 * NTW + l31;                     // this lane's MFMA column (j = 0), + 32 j
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
         }
         __syncthreads();
 
-        conv_phase2_wino<K, C, true>(accw, aq, Xs + kk * 2 * TSH + jw, wl2, 2 * TSH, 0, nullptr);
+        conv_phase2_wino<K, C, true, MT>(accw, aq, Xs + kk * 2 * TSH + jw, wl2, 2 * TSH, 0, nullptr);
 
         // ---- output transform into the row buffer: y[2 jw] = P0 + P1 + P2, y[2 jw + 1] = P1 - P2 - P3
         __syncthreads();
@@ -580,8 +589,8 @@ __global__ __launch_bounds__(256, ((WM == 2 && C == 32) ? TTS_F2_WA32_WAVES : Fu
     const int rsub = lane / LPR;
     const int wid_u = __builtin_amdgcn_readfirstlane(wid);
 #pragma unroll 4
-    for (int it = 0; it < C / (4 * RPW); ++it) {
-        const int ch = (wid_u + 4 * it) * RPW + rsub;
+    for (int it = 0; it < C / (4 * RH * RPW); ++it) {
+        const int ch = (wid_u + 4 * RH * it) * RPW + rsub;
         const float bs = p.b2[ch];
         const int q = q0 + n;
         if (n >= TS || q >= len) continue;
@@ -624,7 +633,7 @@ static int32_t launch_fused2_k(const FusedPair2Params& p, hipStream_t stream) {
     TTS_CHECK_HIP(lds_opt_in((const void*)resblock_pair2<K, C, NTW, WM>, (int)G::lds_bytes(DMAX), lds_done));
     const int ts = WM == 2 ? G::ts_wa(p.dil) : G::TS;
     dim3 grid((p.L + ts - 1) / ts, 1, p.batch);
-    hipLaunchKernelGGL((resblock_pair2<K, C, NTW, WM>), grid, dim3(256), G::lds_bytes(p.dil), stream, p);
+    hipLaunchKernelGGL((resblock_pair2<K, C, NTW, WM>), grid, dim3(256 * f2_row_halves<C, WM>()), G::lds_bytes(p.dil), stream, p);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -648,8 +657,8 @@ int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const flo
     TTS_REQUIRE(slope > 0.f && slope <= 1.f, "fused ResBlock pair: leaky-relu slope %g outside (0, 1]", (double)slope);
     // w2_wino (conv 2 as Winograd groups, pack_wino2_weight): phase B on F(2,3) -- 256-column blocks of C = 32 / 64 only
     // ... + w1_wino: phase A too (dilations 1 / 3 / 5: 256 / 252 / 250 intermediate columns per block)
-    const bool wb = w2_wino != nullptr && ntw == 2 && channels <= 64;
-    const bool wa = wb && w1_wino != nullptr && (dil == 1 || dil == 3 || dil == 5);
+    const bool wa = w2_wino != nullptr && w1_wino != nullptr && ntw == 2 && (dil == 1 || dil == 3 || dil == 5);   // C = 128: 8 waves
+    const bool wb = w2_wino != nullptr && ntw == 2 && (channels <= 64 || wa);
     conv_log(wa ? "fused_pair2ww" : wb ? "fused_pair2w" : (ntw == 2 ? "fused_pair2" : "fused_pair2n"), k, channels, channels, L, batch, 1, mode, len_mul, lens != nullptr, 1);
     FusedPair2Params p;
     std::memset(&p, 0, sizeof(p));
@@ -667,6 +676,11 @@ int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const flo
                         if (wb && k == KK && channels == CC) return launch_fused2_k<KK, CC, 2, 1>(p, stream);
     TTS_F2W(3, 32) TTS_F2W(7, 32) TTS_F2W(11, 32) TTS_F2W(3, 64) TTS_F2W(7, 64) TTS_F2W(11, 64)
 #undef TTS_F2W
+    if (wa && channels == 128) {
+        if (k == 3) return launch_fused2_k<3, 128, 2, 2>(p, stream);
+        if (k == 7) return launch_fused2_k<7, 128, 2, 2>(p, stream);
+        if (k == 11) return launch_fused2_k<11, 128, 2, 2>(p, stream);
+    }
 #define TTS_F2(KK, CC, NN) if (k == KK && channels == CC && ntw == NN) return launch_fused2_k<KK, CC, NN, 0>(p, stream);
     TTS_F2(3, 32, 2) TTS_F2(7, 32, 2) TTS_F2(11, 32, 2)
     TTS_F2(3, 64, 2) TTS_F2(7, 64, 2) TTS_F2(11, 64, 2)
