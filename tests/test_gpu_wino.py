@@ -73,6 +73,16 @@ def test_wino_is_deterministic_and_skips_small_problems(dev, monkeypatch):
     d = conv1d(xs.to(dev), w.to(dev))
     monkeypatch.setenv('TTSAMD_WINO', '1')
     assert torch.equal(conv1d(xs.to(dev), w.to(dev)), d)
+    # rows that are not float4-aligned (L % 4 != 0), a slope outside [0, 1] (the kernels activate with max(x, slope x)) and a kernel size
+    # without a decomposition keep the direct kernel too: same bits with the switch on and off
+    xo = torch.randn(8, 384, 1031, generator=g)
+    w5 = torch.randn(1536, 384, 5, generator=g) / 44.0
+    for args, kw in (((xo, w), {}), ((x, w), {'in_slope': 1.5}), ((x, w5), {})):
+        outs = []
+        for flag in ('0', '1'):
+            monkeypatch.setenv('TTSAMD_WINO', flag)
+            outs.append(conv1d(args[0].to(dev), args[1].to(dev), **kw))
+        assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize('cin,cout,L,B,mode', [(1536, 384, 496, 24, 0), (256, 256, 1032, 16, 1), (256, 256, 520, 40, 2)])
