@@ -90,6 +90,39 @@ def cpu_baseline(fp_sd, hg_sd, tokens, seconds_budget=25.0):
     return out
 
 
+def cpu_baseline_c1(fp_sd, hg_sd, threads, seconds_budget=10.0):
+    """BASELINE configs[0] on this host's cores: the reference's own CPU case (inference.py:45-58 -> FastPitch2Wave.tts on
+    data/infer_text.txt, batch_size=1; models/fastpitch/networks.py:402-411) restated by the oracle -- the first N committed lines
+    (token ids of the REAL reference's tokeniser, tests/golden/infer_text_ids.npz) one line at a time, PREDICTED durations, vocoder
+    per utterance, denoise off -- for as many lines as fit the budget.  Beside `configs[]` C1's GPU figure (same lines, batch_size=1)."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import tts_oracle as O
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    g = dict(np.load(os.path.join(REPO, 'tests', 'golden', 'infer_text_ids.npz'), allow_pickle=False))
+    fw, hw = O.to_torch(fp_sd), O.fold_weight_norm(hg_sd)
+    n_default = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        with torch.inference_mode():
+            n_lines = n_samples = n_tok = 0
+            t0 = time.perf_counter()
+            while n_lines < len(g['offsets']) - 1:
+                ids = np.asarray(g['flat'][g['offsets'][n_lines]:g['offsets'][n_lines + 1]], np.int64)[None]
+                _, _, waves = O.tts_batch(fw, NET_CONFIG, hw, HIFIGAN_CONFIG, ids)
+                n_samples += int(waves[0].numel())
+                n_tok += ids.shape[1]
+                n_lines += 1
+                el = time.perf_counter() - t0
+                if el > seconds_budget:
+                    break
+    finally:
+        torch.set_num_threads(n_default)
+    return {'value': n_samples / el, 'unit': 'audio samples/s', 'cores': threads, 'kind': 'port', 'ms_per_utterance': el * 1e3 / n_lines,
+            'rtf': el / (n_samples / SAMPLE_RATE), 'lines': n_lines, 'tokens': n_tok, 'samples': n_samples,
+            'sample': f'the first {n_lines} of the 100 infer_text.txt lines ({n_tok} tokens), batch_size 1, predicted durations, denoise 0, '
+                      f'{el:.1f} s of torch-CPU fp32 on {threads} threads (tokenisation not timed: ids of the reference tokeniser)'}
+
+
 def _cpu_worker(job):
     """One worker process of cpu_baseline_all_cores (spawned: never touches the GPU): its own copy of the synthetic weights,
     `threads` intra-op threads, distinct utterances (rows first, first + stride, ... of the synthetic batch), timed for
@@ -692,7 +725,7 @@ def main():
                                                           '(no per-launch events)'})
         return r
 
-    def small_config(b, prec=None, name=None, pipelined=False, inputs=None):
+    def small_config(b, prec=None, name=None, pipelined=False, inputs=None, predicted=False):
         """Batch-b sub-result (north star: batch 1 / 8 / 32): same step function, own warm-up, timed WITHOUT the
         per-launch events (they cost a B=1 call 17 %); its roofline figure is algorithmic work over the call's
         WALL time — launch gaps and the three-stream overlap included — so it can never exceed what ran."""
@@ -700,7 +733,7 @@ def main():
         set_precision(prec)
         try:
             ids_src, dur_src = inputs if inputs is not None else (ids, dur)
-            ids_b, dur_b = ids_src[:b].contiguous(), dur_src[:b].contiguous()
+            ids_b, dur_b = ids_src[:b].contiguous(), (None if predicted else dur_src[:b].contiguous())
             st = make_step(ids_b, dur_b, pipelined)
             for _ in range(5):
                 st()
@@ -717,6 +750,9 @@ def main():
                              else 'one call after the other on one stream')
         if name:
             out_c['config'] = name
+        if predicted:
+            out_c['durations'] = ('PREDICTED by the duration predictor (clamp(exp(log_dur) - 1, 0, 75), model.py:366-368) on the calibrated synthetic '
+                                  'weights of ttsamd.synth (~7 frames per token); every other entry forces dur_tgt so that the work is fixed')
         return out_c
 
     if rank == 0:
@@ -815,6 +851,13 @@ def main():
             if args.precision == 'f32' and args.pipeline and B == 32:
                 out['configs'].append(small_config(B, pipelined=False, name='C2 (this line\'s workload) on the ONE-stream schedule: every '
                                                                            'launch of a step on the caller\'s stream, same work and results'))
+            if args.precision == 'f32' and B == 32:
+                # SURVEY §8(d) primary synthetic run: the same workload on PREDICTED durations (no dur_tgt), both schedules
+                c2p = small_config(B, pipelined=bool(args.pipeline), predicted=True,
+                                   name='C2 on PREDICTED durations (dur_tgt=None: duration predictor -> regulate_len), calibrated synthetic weights')
+                c2p['ms_per_step_one_stream'] = small_config(B, pipelined=False, predicted=True)['ms_per_step']
+                out['configs'].append(c2p)
+                lap('C2 predicted durations')
             if not args.no_extra:
                 out['configs'] += extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline, sync, lap)
         if world == 1 and not args.no_extra:
@@ -822,6 +865,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(fp_sd, hg_sd, Lt)
             lap('cpu_baseline')
+            try:
+                out['cpu_baseline']['c1'] = cpu_baseline_c1(fp_sd, hg_sd, out['cpu_baseline']['cores'])
+            except Exception as e:                               # noqa: BLE001
+                out['cpu_baseline']['c1'] = {'error': str(e)[:300]}
+            lap('cpu_baseline.c1')
             try:
                 out['cpu_baseline']['all_cores'] = cpu_baseline_all_cores(Lt)
             except Exception as e:                               # noqa: BLE001

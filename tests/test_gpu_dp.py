@@ -189,19 +189,22 @@ def test_bench_two_ranks_one_device():
     assert 'ONE device' in out['config']['parallelism']
 
 
-def test_bench_config3_command_line_eight_ranks_one_device():
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_bench_config3_command_line_eight_ranks_one_device(precision):
     """BASELINE config 3 as the driver will type it on an 8-GPU node -- `bench.py --gpus 8 --scaling strong --batch 256 --precision
-    bf16` -- end to end on the one-device fallback (eight ranks share this GPU over gloo + host staging): 256 utterances dealt
+    bf16x3` (split bf16: config 3 INSIDE north_star's 1e-3 / 1e-4 tolerance) and `--precision bf16` (plain bf16 operands, own stated
+    tolerance) -- end to end on the one-device fallback (eight ranks share this GPU over gloo + host staging): 256 utterances dealt
     32 per rank, the two-channel exchange at world 8, ONE json line whose n_gpus / scaling / global batch are the configuration's.
     A functional check of the launch path, not a scaling number (the line says so)."""
     p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--scaling', 'strong', '--batch', '256',
-                        '--precision', 'bf16', '--steps', '1', '--warmup', '1', '--tokens', '16', '--no-cpu-baseline'],
+                        '--precision', precision, '--steps', '1', '--warmup', '1', '--tokens', '16', '--no-cpu-baseline'],
                        capture_output=True, timeout=1500)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 8 and out['value'] > 0 and out['scaling'] == 'strong' and out['dtype'] == 'bf16'
+    assert out['n_gpus'] == 8 and out['value'] > 0 and out['scaling'] == 'strong'
+    assert out['dtype'] == ('bf16' if precision == 'bf16' else 'f32 via split-bf16 (3x bf16 MFMA, fp32 accumulate)')
     assert out['config']['global_batch'] == 256 and out['config']['batch_per_gpu'] == 32
     assert 'ONE device' in out['config']['parallelism']
 
