@@ -39,6 +39,7 @@ def test_wino_conv_matches_float64_and_the_direct_kernel(dev, monkeypatch, cin, 
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2], lens[3] = L, L - 1 if L % 2 == 0 else L - 2, 129, 1
     lens_d = lens.to(dev)
+    monkeypatch.setenv('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
     monkeypatch.setenv('TTSAMD_WINO2', '6')           # k = 3 on conv_wino.hip (the decomposition kernel's k = 3 is tested below)
     monkeypatch.setenv('TTSAMD_WINO', '1')
     y_w = conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens_d, in_slope=slope, relu_out=relu).cpu()
@@ -63,6 +64,7 @@ def test_wino_is_deterministic_and_skips_small_problems(dev, monkeypatch):
     from ttsamd.engine import conv1d
     g = torch.Generator().manual_seed(1)
     x, w = torch.randn(8, 384, 496, generator=g), torch.randn(1536, 384, 3, generator=g) / 34.0
+    monkeypatch.setenv('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
     monkeypatch.setenv('TTSAMD_WINO2', '6')
     monkeypatch.setenv('TTSAMD_WINO', '1')
     a, b2 = conv1d(x.to(dev), w.to(dev)), conv1d(x.to(dev), w.to(dev))
@@ -101,6 +103,7 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2] = L, L - 1, 131
     outs = {}
+    monkeypatch.setenv('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
     monkeypatch.setenv('TTSAMD_WINO2', '6')
     for flag in ('1', '0'):
         monkeypatch.setenv('TTSAMD_WINO', flag)
@@ -130,8 +133,13 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
     (3, 1, 64, 64, 4100, 12, 1), (3, 3, 64, 64, 4100, 12, None), (7, 1, 64, 64, 4100, 12, 2), (7, 5, 64, 64, 4100, 12, None),
     (11, 1, 64, 64, 4100, 12, None), (11, 3, 64, 64, 4100, 12, 1), (11, 5, 64, 64, 4100, 12, 2), (11, 1, 128, 64, 4100, 12, 0),
 ])
-def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, mode):
-    """conv_wino2.hip: a k-tap filter as k // 3 three-tap F(2,3) sub-filters + k % 3 single taps accumulating into the same four planes
+@pytest.mark.parametrize('scheme', ['f23', 'f43'])
+def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, mode, scheme):
+    """scheme f43 = conv_wino4.hip: the same filters as F(4,3) sub-filters -- 6 / 16 / 23 products per output QUAD (q, q + d, q + 2 d, q + 3 d),
+    64 rows x 64 quads per block, k = 11 in two phases of 12 / 11 groups, the single tap of k = 7 through two extra planes; tiles of 256 /
+    252 / 240 outputs at dilation 1 / 3 / 5.  Same float64 checker, same ragged odd lengths and epilogues; F(2,3) and F(4,3) must differ
+    in bits (the routing took effect) and both stay within the bound.
+    scheme f23 = conv_wino2.hip: a k-tap filter as k // 3 three-tap F(2,3) sub-filters + k % 3 single taps accumulating into the same four planes
     (HiFi-GAN's ResBlock convs, vocoder/hifigan/models.py:30-44); at dilation d = 3 / 5 the output pair is (q, q + d) and a tile holds
     120 outputs.  Float64 checker, ragged odd lengths, with and without the residual / accumulate epilogues; the direct kernel beside it."""
     from ttsamd.engine import conv1d
@@ -145,6 +153,7 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, m
     lens[0], lens[1], lens[2], lens[3] = L, L - 1, 131, 1
     outs = {}
     monkeypatch.setenv('TTSAMD_WINO2', '31')
+    monkeypatch.setenv('TTSAMD_WINO4', '15' if scheme == 'f43' else '0')
     for flag in ('1', '0'):
         monkeypatch.setenv('TTSAMD_WINO', flag)
         y = y0.clone().to(dev)
@@ -161,6 +170,13 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, m
         for flag in ('1', '0'):
             worst[flag] = max(worst[flag], float((outs[flag][i, :, :n].double() - ref).abs().max()))
             assert torch.equal(outs[flag][i, :, n:], y0[i, :, n:]), 'positions past the utterance must stay untouched'
-    print(f'k={k} d={d} cin={cin} mode={mode}: decomposition max-abs {worst["1"]:.2e}, direct {worst["0"]:.2e}')
+    print(f'{scheme} k={k} d={d} cin={cin} mode={mode}: decomposition max-abs {worst["1"]:.2e}, direct {worst["0"]:.2e}')
     assert worst["1"] < 5e-5 and worst["0"] < 5e-5
     assert not torch.equal(outs['1'], outs['0'])
+    if scheme == 'f43':                                   # ... and it is not the F(2,3) kernel that ran
+        monkeypatch.setenv('TTSAMD_WINO4', '0')
+        monkeypatch.setenv('TTSAMD_WINO', '1')
+        y = y0.clone().to(dev)
+        conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), dilation=d, in_slope=0.1, res=None if res is None else res.to(dev),
+               mode=mode or 0, div=3.0, y=y)
+        assert not torch.equal(outs['1'], y.cpu())

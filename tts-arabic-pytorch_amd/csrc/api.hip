@@ -316,7 +316,36 @@ int32_t ttsamd_tagger_forward(void* handle, const int64_t* ids, int32_t batch, i
 
 int64_t ttsamd_conv1d_packed_floats(int32_t cout, int32_t cin, int32_t k) {
     // fp32 packed + bf16 hi/lo planes (+ k = 3 / 7 / 11: the Winograd group filters, conv_wino.hip / conv_wino2.hip)
-    return 2 * (int64_t)cin * k * cout_padded(cout) + ((k == 3 || k == 7 || k == 11) ? (int64_t)cin * wino2_groups(k) * cout_padded(cout) : 0);
+    return 2 * (int64_t)cin * k * cout_padded(cout) +
+           ((k == 3 || k == 7 || k == 11) ? (int64_t)cin * (wino2_groups(k) + wino4_groups(k)) * cout_padded(cout) : 0);
+}
+
+// [Cout][Cin][k] -> the F(4,3) group filters in the packed layout [cin/8][NGQ][2][cp][4] (same values as pack_wino4_weight, conv_wino4.hip)
+__global__ void pack_wino4_weight_kernel(const float* __restrict__ w, int cout, int cin, int k, int cp, float* __restrict__ out) {
+    const int ng = k == 3 ? 6 : (k == 7 ? 16 : 24), nsf = k == 3 ? 1 : (k == 7 ? 2 : 4);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)cin * ng * cp;
+    if (i >= n) return;
+    const int pq = (int)(i & 3);
+    const int64_t r = i >> 2;
+    const int co = (int)(r % cp);
+    const int64_t r2 = r / cp;
+    const int kk = (int)(r2 & 1);
+    const int64_t r3 = r2 >> 1;
+    const int t = (int)(r3 % ng), o = (int)(r3 / ng);
+    float v = 0.f;
+    if (co < cout) {
+        const float* g = w + ((int64_t)co * cin + (8 * o + 2 * pq + kk)) * k;
+        if (t < 6 * nsf) {
+            const int s = t / 6, j = t % 6;
+            const double g0 = g[3 * s], g1 = 3 * s + 1 < k ? g[3 * s + 1] : 0.0, g2 = 3 * s + 2 < k ? g[3 * s + 2] : 0.0;
+            v = j == 0 ? (float)(g0 / 4) : (j == 1 ? (float)(-(g0 + g1 + g2) / 6) : (j == 2 ? (float)(-(g0 - g1 + g2) / 6) :
+                (j == 3 ? (float)(g0 / 24 + g1 / 12 + g2 / 6) : (j == 4 ? (float)(g0 / 24 - g1 / 12 + g2 / 6) : (float)g2))));
+        } else {
+            v = g[6];                       // k = 7: the single tap, four copies (planes P0 / P6 / P7 / P5)
+        }
+    }
+    out[i] = v;
 }
 
 // [Cout][Cin][k] -> the Winograd group filters in the packed NG-tap layout [cin/8][NG][2][cp][4] (same values as pack_wino2_weight:
@@ -376,6 +405,11 @@ int32_t ttsamd_conv1d_ex(const float* x, const float* w, const float* bias, cons
         hipLaunchKernelGGL(pack_wino2_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, cout, cin, k, cp, wino);
         TTS_CHECK_HIP(hipGetLastError());
         p.w_wino = wino;
+        float* wino4 = wino + nw;
+        const int64_t nw4 = (int64_t)cin * wino4_groups(k) * cp;
+        hipLaunchKernelGGL(pack_wino4_weight_kernel, dim3((unsigned)((nw4 + 255) / 256)), dim3(256), 0, s, w, cout, cin, k, cp, wino4);
+        TTS_CHECK_HIP(hipGetLastError());
+        p.w_wino4 = wino4;
     }
     p.y = y; p.y_bs = (int64_t)cout * lin; p.y_cs = lin; p.y_ts = 1;
     p.lens_in = lens; p.lens_out = lens; p.len_in_mul = 1; p.len_out_mul = 1;

@@ -90,6 +90,7 @@ struct ConvParams {
     const float* w;      // packed fp32 weights [n_phase][Cin/8][K][2][CoutP][4]
     const void* w_bf16;  // same element order as bf16: plane hi then plane lo (nullptr if not packed)
     const float* w_wino; // k = 3 only: the Winograd F(2,3) filters as a 4-tap conv [Cin/8][4][2][CoutP][4] (conv_wino.hip; nullptr = none)
+    const float* w_wino4; // k = 3 / 7 / 11: the Winograd F(4,3) group filters [Cin/8][wino4_groups(k)][2][CoutP][4] (conv_wino4.hip; nullptr = none)
     int32_t precision;   // 0 fp32 MFMA, 1 bf16 MFMA, 2 split bf16 (3 MFMAs per product)
     const float* bias;   // [>=Cout] or nullptr
     float* y;            // (b,co,q) at y + b*y_bs + co*y_cs + q*y_ts + phase
@@ -158,7 +159,7 @@ int32_t launch_fused_pair2(int32_t channels, const float* x, float* y, const flo
 // (w2_wino: conv 2 as Winograd F(2,3) groups -- pack_wino2_weight; C = 32 / 64, ntw = 2: phase B of the pair runs on them; w1_wino:
 // conv 1 likewise -> phase A too)
 // Winograd F(2,3) path of the k = 3, dilation-1 convs (conv_wino.hip): routing test, launcher, host-side filter transform + packing
-int wino_route(const ConvParams& p);       // 0: direct kernel, 1: conv1d_wino_f32, 2: conv1d_wino2_f32 (conv_wino.hip)
+int wino_route(const ConvParams& p);       // 0: direct kernel, 1: conv1d_wino_f32, 2: conv1d_wino2_f32, 3: conv1d_wino4_f32 (conv_wino.hip)
 int32_t launch_wino(const ConvParams& p, hipStream_t stream);
 void pack_wino_weight(const float* w, int cout, int cin, float* out);   // out: cin * 4 * cout_padded(cout) floats
 // ... and its generalisation to k = 7 / 11 as sums of F(2,3) sub-filters + single taps (conv_wino2.hip): NG = wino2_groups(k) operand
@@ -167,6 +168,12 @@ int wino2_groups(int k);
 int wino2_block_outputs(int coutp, int dil);     // outputs per block of the kernel launch_wino2 picks
 int32_t launch_wino2(const ConvParams& p, hipStream_t stream);
 void pack_wino2_weight(const float* w, int cout, int cin, int k, float* out);   // out: cin * wino2_groups(k) * cout_padded(cout) floats
+// ... and the F(4,3) decomposition (conv_wino4.hip: 6 / 16 / 23 products per output QUAD at k = 3 / 7 / 11): 64 rows x 64 quads per block
+int wino4_groups(int k);                         // groups per octet in the packed weights: 6 / 16 / 24 (k = 11: 23 + one zero group)
+int wino4_block_outputs(int dil);
+int32_t launch_wino4(const ConvParams& p, hipStream_t stream);
+void wino4_filter_groups(const float* g, int k, float* o);                      // one (co, ci) filter -> its wino4_groups(k) group filters
+void pack_wino4_weight(const float* w, int cout, int cin, int k, float* out);   // out: cin * wino4_groups(k) * cout_padded(cout) floats
 // Host-side weight re-layout: torch Conv1d [Cout][Cin][K] -> [Cin][K][CoutP]
 void pack_conv_weight(const float* w, int cout, int cin, int k, float* out);
 // torch ConvTranspose1d [Cin][Cout][Kt] (Kt = 2u, stride u, padding p) -> [u][Cin][2][CoutP]

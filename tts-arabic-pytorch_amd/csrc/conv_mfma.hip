@@ -837,7 +837,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     TTS_REQUIRE(p.dil >= -DMAX && p.dil <= DMAX && p.dil != 0, "conv: dilation %d outside [-%d,%d]", p.dil, DMAX, DMAX);
     if (p.Nout <= 0) return 0;
     const int wino = wino_route(p);
-    conv_log(p.precision == 0 ? (wino ? "f32_wino" : "f32") : "bf16", p.K, p.Cin, p.Cout, p.Nout, p.batch, p.res != nullptr, p.mode, p.len_out_mul,
+    conv_log(p.precision == 0 ? (wino == 3 ? "f32_wino4" : (wino ? "f32_wino" : "f32")) : "bf16", p.K, p.Cin, p.Cout, p.Nout, p.batch, p.res != nullptr, p.mode, p.len_out_mul,
              p.lens_out != nullptr, p.n_phase);
     if (p.precision != 0) return launch_conv_bf16_any(p, stream);
     TTS_REQUIRE(!p.x_packed && !p.y_packed, "conv: packed bf16 activations exist only in the bf16 mode");
@@ -852,7 +852,7 @@ int32_t launch_conv(const ConvParams& p, hipStream_t stream) {
     set_error("conv: built with TTS_ONLY_K=%d", TTS_ONLY_K);
     return TTSAMD_EINVAL;
 #else
-    if (wino) return wino == 2 ? launch_wino2(p, stream) : launch_wino(p, stream);
+    if (wino) return wino == 3 ? launch_wino4(p, stream) : (wino == 2 ? launch_wino2(p, stream) : launch_wino(p, stream));
     switch (p.K) {
         case 1: return launch_k<1>(p, stream);
         case 2: return launch_k<2>(p, stream);

@@ -407,9 +407,28 @@ static int32_t launch_wino_epi(const ConvParams& q, dim3 grid, hipStream_t strea
 //                        = Cout = 64.  Default 31 (same-box A/B of the bench step, tools/ab_env.sh: 74.2 ms with none, 73.1 with k = 3,
 //                        68.5 with k = 7 + 11, 67.5 with the three, 65.6 with dilations, 64.6-65.1 with Cout = 64)
 int wino_route(const ConvParams& p) {
-    if (p.w_wino == nullptr || p.precision != 0 || (p.K != 3 && p.K != 7 && p.K != 11)) return 0;
+    if ((p.w_wino == nullptr && p.w_wino4 == nullptr) || p.precision != 0 || (p.K != 3 && p.K != 7 && p.K != 11)) return 0;
     const char* e = getenv("TTSAMD_WINO");
     if (e && e[0] == '0') return 0;
+    if (p.w_wino4 != nullptr) {
+        // F(4,3) decomposition (conv_wino4.hip): TTSAMD_WINO4=<mask>, bit 0 / 1 / 2 = k 3 / 7 / 11, bit 3 = their dilated convs; default 15.
+        // 64 rows x 64 quads per block, float4-aligned rows, at least 192 blocks (below: the F(2,3) / direct routing that follows)
+        const char* e4 = getenv("TTSAMD_WINO4");
+        const int mask4 = e4 ? atoi(e4) : 15;
+        const int kbit4 = p.K == 3 ? 1 : (p.K == 7 ? 2 : 4);
+        const bool ok4 = (mask4 & kbit4) && (p.dil == 1 || (mask4 & 8)) && (p.K != 3 || p.Cin % 16 == 0) &&
+                         (p.dil == 1 || p.dil == 3 || p.dil == 5) && p.pad == p.dil * (p.K - 1) / 2 && p.n_phase == 1 && p.y_ts == 1 &&
+                         p.CoutP % 64 == 0 && p.Cin % 8 == 0 && p.scale == nullptr && p.relu_out < 2 && p.in_slope >= 0.f && p.in_slope <= 1.f &&
+                         (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
+                         (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                         (int64_t)p.Cout * std::max(std::max(p.r_cs, p.y_cs), 1) * 4 < ((int64_t)1 << 31);
+        if (ok4) {
+            const int bo4 = wino4_block_outputs(p.dil);
+            const int64_t blocks4 = (int64_t)((p.Nout + bo4 - 1) / bo4) * (p.CoutP / 64) * p.batch;
+            if (blocks4 >= 192 && p.Nout >= 256) return 3;
+        }
+        if (p.w_wino == nullptr) return 0;
+    }
     const char* e2 = getenv("TTSAMD_WINO2");
     const int mask = e2 ? atoi(e2) : 31;
     const int kbit = p.K == 3 ? 1 : (p.K == 7 ? 2 : 4);

@@ -1,0 +1,488 @@
+// Winograd F(4,3) DECOMPOSITION kernel of the exact-fp32 engine (round 6): the k = 3 / 7 / 11 'same' Conv1d launches of
+// conv_wino2.hip with FOUR outputs per tuple instead of two --
+//     k = 3   one three-tap sub-filter, 6 products per output quad                                  (F(2,3):  8, direct 12)
+//     k = 7   two sub-filters + one single tap, 2 x 6 + 4 = 16                                      (F(2,3): 20, direct 28)
+//     k = 11  three sub-filters + taps (9, 10) as a sub-filter with a zero third tap whose U5 = g2 = 0 group is never issued
+//             (= F(4,2)), 3 x 6 + 5 = 23                                                            (F(2,3): 32, direct 44)
+// i.e. 0.75 / 0.80 / 0.72 of the F(2,3) kernel's MFMAs.  Transforms (Lavin & Gray, points 0, +-1, +-2, inf), sub-filter on the
+// positions x0..x5 of the tuple's d-decimated window:
+//     V0 = 4 x0 - 5 x2 + x4          V1 = (x4 - 4 x2) + (x3 - 4 x1)     V2 = (x4 - 4 x2) - (x3 - 4 x1)
+//     V3 = (x4 - x2) + 2 (x3 - x1)   V4 = (x4 - x2) - 2 (x3 - x1)       V5 = 4 x1 - 5 x3 + x5
+//     U0 = g0 / 4   U1 = -(g0 + g1 + g2) / 6   U2 = -(g0 - g1 + g2) / 6   U3 = g0 / 24 + g1 / 12 + g2 / 6
+//     U4 = g0 / 24 - g1 / 12 + g2 / 6   U5 = g2                                     (in double on the host, one rounding)
+//     y0 = P0 + (P1 + P2) + (P3 + P4)      y1 = (P1 - P2) + 2 (P3 - P4) [+ P6]
+//     y2 = (P1 + P2) + 4 (P3 + P4) [+ P7]  y3 = (P1 - P2) + 8 (P3 - P4) + P5
+// The output transform is linear and shared, so every sub-filter of a conv accumulates into the same six planes; the single tap
+// of k = 7 has no saving to offer (4 products per quad either way) and goes in untransformed: g x[t + j] -> P0 / P6 / P7 / P5 for
+// the outputs j = 0..3 (P0 and P5 reach y0 / y3 only, P6 / P7 are two extra accumulators added to y1 / y2).  Dilation d: the
+// output quad is (q, q + d, q + 2 d, q + 3 d), tuple slot pc of a tile at column (pc / d) 4 d + pc % d.
+// NUMERICS: tests/test_wino_f43_numerics_cpu.py runs the whole 75-conv vocoder and FastPitch with every routed conv emulated in
+// fp32 through these transforms: wave 3.2e-7 / mel 3.8e-6 max-abs against float64 (direct fp32: 2.6e-7 / 2.9e-6, F(2,3): 2.3e-7 /
+// 4.2e-6; tolerance 1e-4 / 1e-3).  tests/test_gpu_wino.py checks the kernel itself against float64.
+// Reference ops: vocoder/hifigan/models.py:30-53 (ResBlock1 convs), models/fastpitch/fastpitch/transformer.py:59-65 (conv-FF).
+//
+// Anatomy = conv_wino2.hip's (weights L2 -> register queue, LDS = the transformed planes only, range-checked row loads, one
+// activation per loaded value pair, single-instruction jobs in the gaps between MFMAs) with MT = 1: six or eight 32 x 32 planes per
+// wave are 96 / 128 accumulator registers, so a wave owns ONE 32-row tile x 32 tuples; block = 2 x 2 waves = 64 rows x 64 tuples
+// (256 outputs).  k = 11 runs its 23 groups in two PHASES (12 + 11) so that two stages fit 48 KB; its packed weights carry a 24th
+// all-zero group that is fetched (queue slots line up) and never multiplied.
+#include <cstdlib>
+#include <cstring>
+
+#include <algorithm>
+#include <vector>
+
+#include "conv_mfma_common.hpp"
+#include "bfo.hpp"
+
+namespace ttsamd {
+
+typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int K, int NOCT_, int NSTAGE_, int EPI_ = 0>
+struct Wino4Geo {
+    static constexpr int WM = 2, WN = 2;
+    static constexpr int NSF = K == 3 ? 1 : (K == 7 ? 2 : 4);        // sub-filters (k = 11: the fourth is taps 9, 10 + a zero tap)
+    static constexpr int NL = K == 7 ? 1 : 0;                        // single taps
+    static constexpr int NG = K == 3 ? 6 : (K == 7 ? 16 : 23);       // operand groups per octet that are multiplied
+    static constexpr int NGQ = (NG + 1) & ~1;                        // ... in the packed weights (k = 11: + one zero group)
+    static constexpr int NPL = (NL || EPI_ == 3) ? 8 : 6;            // accumulator planes (P6 / P7: the single tap of k = 7, the preloaded residual)
+    static constexpr int NPOS = K == 3 ? 6 : (K == 7 ? 10 : 14);     // input positions of a tuple's window
+    static constexpr int NOCT = NOCT_, NSTAGE = NSTAGE_;
+    static constexpr int NPH = K == 11 ? 2 : 1;
+    static constexpr int NGPM = NPH == 1 ? NG : 12;                  // group slots of a stage
+    static constexpr int CO_BLK = WM * 32;
+    static constexpr int NTUP = WN * 32;                             // output quads per block
+    static constexpr int NT_BLK = 4 * NTUP;                          // outputs per block (dilation 1)
+    static constexpr int BUF4 = NOCT * 2 * NGPM * NTUP;              // float4s per stage: [octet][kk][group slot][tuple]
+    static constexpr int PF = 4;                                     // weight groups in flight ahead of the one being multiplied (16 MFMAs ~ 1000 cycles;
+                                                                     // two groups -- 512 cycles, under the L2 latency -- measured 59-70 % matrix-pipe busy)
+    static constexpr int NM = 4;                                     // MFMAs per operand group (the four channel pairs of the octet)
+    static constexpr int DA = 16;                                    // a value is activated 16 MFMAs (~1000 cycles) after its load was issued
+    __host__ __device__ static constexpr int glo(int ph) { return NPH == 1 ? 0 : 12 * ph; }
+    __host__ __device__ static constexpr int ngp(int ph) { return NPH == 1 ? NG : (ph == 0 ? 12 : NG - 12); }     // multiplied
+    __host__ __device__ static constexpr int ngq(int ph) { return NPH == 1 ? NGQ : 12; }                          // fetched
+    // first / last input position (0 .. NPOS - 1) group g touches
+    __host__ __device__ static constexpr int gfirst(int g) { return g < 6 * NSF ? 3 * (g / 6) : 3 * NSF + (g - 6 * NSF); }
+    __host__ __device__ static constexpr int glast(int g) {
+        return g < 6 * NSF ? (3 * (g / 6) + 5 < NPOS ? 3 * (g / 6) + 5 : NPOS - 1) : 3 * NSF + (g - 6 * NSF);
+    }
+    __host__ __device__ static constexpr int plane(int g) {
+        return g < 6 * NSF ? g % 6 : ((g - 6 * NSF) == 0 ? 0 : ((g - 6 * NSF) == 1 ? 6 : ((g - 6 * NSF) == 2 ? 7 : 5)));
+    }
+    __host__ __device__ static constexpr int mlo(int ph) { return gfirst(glo(ph)); }
+    __host__ __device__ static constexpr int mhi(int ph) {
+        int m = 0;
+        for (int g = glo(ph); g < glo(ph) + ngp(ph); ++g) m = glast(g) > m ? glast(g) : m;
+        return m;
+    }
+    __host__ __device__ static constexpr int npos(int ph) { return mhi(ph) - mlo(ph) + 1; }
+    static constexpr int NPOSP = npos(0) > npos(NPH - 1) ? npos(0) : npos(NPH - 1);
+    __host__ __device__ static constexpr int ngap(int ph) { return NOCT * ngp(ph) * NM; }     // gaps (one per MFMA) of a step
+    __host__ __device__ static constexpr int nlj(int ph) { return NOCT * 2 * npos(ph); }      // load jobs (one value each)
+    __host__ __device__ static constexpr int nwj(int ph) { return NOCT * ngp(ph); }           // write jobs (one plane each)
+    static constexpr int LPG = 3 * (NOCT * 2 * NPOSP) > ngap(NPH - 1) ? 2 : 1;                // loads per gap
+    __host__ __device__ static constexpr int tw0(int ph) { return (nlj(ph) + LPG - 1) / LPG + DA; }    // first gap with every value activated
+    __host__ __device__ static constexpr int ws(int ph) { return (ngap(ph) - tw0(ph)) / nwj(ph); }     // one plane write every ws gaps after it
+    static_assert((NOCT * ngq(0)) % PF == 0 && (NOCT * ngq(NPH - 1)) % PF == 0, "queue slots line up across steps");
+    static_assert(ws(0) >= 1 && ws(NPH - 1) >= 1, "one write job per gap at most");
+    static_assert((size_t)NSTAGE * BUF4 * 16 <= 80 * 1024, "two blocks per CU");
+    static_assert(NPH == 1 || (NSTAGE == 2 && NOCT == 1), "phases alternate between two stages");
+    static_assert(NSTAGE < 3 || ((NOCT * ngp(0)) % 2 == 0 && (NOCT * ngp(NPH - 1)) % 2 == 0), "the B ping-pong restarts at slot 0");
+};
+
+// outputs per tile at dilation d: the largest multiple of 4 d in 4 * ntup
+__device__ __host__ constexpr int wino4_tile(int d, int ntup) { return (4 * ntup / (4 * d)) * (4 * d); }
+
+template <int K, int NOCT_, int NSTAGE_, int EPI>
+__global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    using G = Wino4Geo<K, NOCT_, NSTAGE_, EPI>;
+    constexpr int WN = G::WN, NSF = G::NSF, NOCT = G::NOCT, NSTAGE = G::NSTAGE, NPL = G::NPL, NGPM = G::NGPM;
+    constexpr int CO_BLK = G::CO_BLK, NTUP = G::NTUP, NT_BLK = G::NT_BLK, PF = G::PF;
+    constexpr int NPH = G::NPH, NPOSP = G::NPOSP, NM = G::NM, DA = G::DA, LPG = G::LPG;
+    const int dil = p.dil;
+    const int nt_eff = wino4_tile(dil, NTUP), ntup_eff = nt_eff / 4;
+    int b = blockIdx.z;
+    int q0 = blockIdx.x * nt_eff;
+    if (p.compact) {   // dead blocks last (live_tile, common.hpp)
+        int tile = 0;
+        if (!live_tile(p.lens_out, p.len_out_mul, p.Nout, nt_eff, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        b = __builtin_amdgcn_readfirstlane(b);
+        q0 = __builtin_amdgcn_readfirstlane(tile) * nt_eff;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int co_blk0 = blockIdx.y * CO_BLK;
+    int n_out = p.Nout;
+    if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
+    if (q0 >= n_out) return;
+    int in_len = p.Lin;
+    if (p.lens_in) in_len = min(in_len, (int)p.lens_in[b] * p.len_in_mul);
+
+    const int x_cs = p.x_cs, CoutP = p.CoutP;
+    const int n_chunks = p.Cin / (8 * NOCT);
+    const int n_groups = (p.Cin / 8) * G::NGQ;                // groups of the whole conv in the packed weights
+    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+    const float in_slope = p.in_slope;
+    const int pad = (K - 1) / 2;
+
+    float ep_bias = 0.f;
+    if (tid < CO_BLK && p.bias) ep_bias = p.bias[min(co_blk0 + tid, p.Cout - 1)];
+
+    const int kk = lane >> 5, l31 = lane & 31;
+    const int pe = wn * 32 + l31;                                           // the tuple this lane holds in the accumulators
+    const int col_e = dil == 1 ? 4 * pe : (pe / dil) * 4 * dil + pe % dil;  // ... its first column in the tile (then + dil, 2 dil, 3 dil)
+    f32x16 acc[NPL];
+#pragma unroll
+    for (int g = 0; g < NPL; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    // EPI 3 (dilation 1 only: the launcher's choice): residual [+ running ResBlock sum] of the lane's quad -- one 16-byte load per row --
+    // straight into the planes that reach exactly one output each: r0 -> P0 (y0), r1 -> P6 (y1), r2 -> P7 (y2), r3 -> P5 (y3).
+    // A quad cut by the utterance end loads values that are never stored; past the tensor the range check returns zeros.
+    constexpr bool preload = EPI == 3;
+    if constexpr (preload) {
+        const int wm_s = __builtin_amdgcn_readfirstlane(wm);
+        const int row0 = co_blk0 + wm_s * 32;
+        const int qv = q0 + col_e;
+        const int voff = (qv < n_out ? qv : 0) * 4;
+        {
+            const int r_cs = p.r_cs;
+            const bfo_i4 rs = bfo_rsrc(p.res + (int64_t)b * p.r_bs, (unsigned)p.Cout * (unsigned)r_cs * 4u);
+            const int vk = 4 * kk * r_cs * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const w4_f32x4 t = __builtin_bit_cast(w4_f32x4, bfo_ld16(rs, voff + vk, (row0 + (r & 3) + 8 * (r >> 2)) * r_cs * 4, 0));
+                acc[0][r] = t.x; acc[6][r] = t.y; acc[7][r] = t.z; acc[5][r] = t.w;
+            }
+        }
+        if (p.mode != 0) {
+            const int y_cs_ = p.y_cs;
+            const bfo_i4 ys = bfo_rsrc(p.y + (int64_t)b * p.y_bs, (unsigned)p.Cout * (unsigned)y_cs_ * 4u);
+            const int vk = 4 * kk * y_cs_ * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const w4_f32x4 t = __builtin_bit_cast(w4_f32x4, bfo_ld16(ys, voff + vk, (row0 + (r & 3) + 8 * (r >> 2)) * y_cs_ * 4, 0));
+                acc[0][r] += t.x; acc[6][r] += t.y; acc[7][r] += t.z; acc[5][r] += t.w;
+            }
+        }
+    }
+
+    // ---- weight queue: group gf = octet * NGQ + g sits at w_wino4 + gf * 2 CoutP float4 (the scalar offset of the buffer load, advanced by
+    // one group per refill and clamped at the conv's last group: an L1 hit, unused); this lane's fragment at + kk * CoutP + row
+    const bfo_i4 wrs = bfo_rsrc(p.w_wino4, (unsigned)n_groups * 2u * (unsigned)CoutP * 16u);
+    const int wv = (kk * CoutP + co_blk0 + wm * 32 + l31) * 16;
+    const int wstep = 2 * CoutP * 16, wlast = (n_groups - 1) * wstep;
+    int wso = 0;
+    w4_f32x4 aq[PF];
+#pragma unroll
+    for (int g = 0; g < PF; ++g) {
+        aq[g] = __builtin_bit_cast(w4_f32x4, bfo_ld16(wrs, wv, wso, 0));
+        wso = min(wso + wstep, wlast);
+    }
+
+    // ---- staging.  X item of thread (h, kks, pc) and octet ol: channels 8 (c NOCT + ol) + 2 (2 h + pp) + kks, pp = 0 / 1, at the positions
+    // q0 + col(pc) + (m - pad) d, m = the phase's window -> components 2 h, 2 h + 1 of the float4 of each plane of the phase at
+    // [ol][kks][g][pc].  (h, kks) = the wave index: a wave instruction reads ONE channel row, so the row is the base of a raw buffer
+    // descriptor of in_len * 4 bytes and the load's range check returns the zeros of the halo (conv_wino2.hip).
+    const int sh = __builtin_amdgcn_readfirstlane((tid >> 7) & 1), skk = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);
+    w4_f32x2 sx[NOCT][NPOSP];                                // [pp] = the two channels of the item, packed
+    const int spe = min(lane, ntup_eff - 1);                 // idle tuple slots (d > 1) repeat the last tuple: never stored
+    const int xv0 = (q0 + (dil == 1 ? 4 * spe : (spe / dil) * 4 * dil + spe % dil) - pad * dil) * 4;
+    const int xvd = 4 * dil;
+    const int ch_off = (4 * sh + skk) * x_cs;                 // channel 2 (2 h) + kks; pp adds 2 rows, the octet 8
+
+#define TTS_JOB_IDX(PH, J)                                                                           \
+        const int np_ = G::npos(PH);                                                                 \
+        const int ol_ = (J) / (2 * np_), mi_ = ((J) / 2) % np_, pp_ = (J) % 2;
+#define TTS_LOAD_JOB(PH, J, XSO)                                                                     \
+    {                                                                                                \
+        TTS_JOB_IDX(PH, J)                                                                           \
+        const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + (8 * ol_ + 2 * pp_) * x_cs), (unsigned)in_len * 4u);     \
+        sx[ol_][mi_][pp_] = bfo_ld4f(xrs_, xv0 + xvd * (G::mlo(PH) + mi_), 0, 0);                   \
+    }
+    // leaky-relu on load, once per value pair, after its second load (slopes in [0, 1]: max(x, slope x); slope 1 = the identity, exactly)
+#define TTS_ACT_JOB(PH, J)                                                                           \
+    if ((J) & 1) {                                                                                   \
+        TTS_JOB_IDX(PH, J)                                                                           \
+        (void)pp_;                                                                                   \
+        const w4_f32x2 w_ = sx[ol_][mi_] * in_slope;                                                 \
+        sx[ol_][mi_].x = fmaxf(sx[ol_][mi_].x, w_.x);                                                \
+        sx[ol_][mi_].y = fmaxf(sx[ol_][mi_].y, w_.y);                                                \
+    }
+    // plane g of octet ol from the staged values.  Job J -> (octet, group of the phase)
+#define TTS_SX(M) sx[ol_][(M) - G::mlo(PH_)]
+#define TTS_WRITE_JOB(PH, J, WR)                                                                     \
+    {                                                                                                \
+        const int PH_ = (PH);                                                                        \
+        const int ol_ = (J) / G::ngp(PH_), gl_ = (J) % G::ngp(PH_), g_ = G::glo(PH_) + gl_;         \
+        w4_f32x2 v2;                                                                                 \
+        if (g_ < 6 * NSF) {                                                                          \
+            const int s3 = 3 * (g_ / 6), i_ = g_ % 6;                                                \
+            if (i_ == 0) v2 = 4.f * TTS_SX(s3) + (TTS_SX(s3 + 4) - 5.f * TTS_SX(s3 + 2));           \
+            else if (i_ == 1) v2 = (TTS_SX(s3 + 4) - 4.f * TTS_SX(s3 + 2)) + (TTS_SX(s3 + 3) - 4.f * TTS_SX(s3 + 1));   \
+            else if (i_ == 2) v2 = (TTS_SX(s3 + 4) - 4.f * TTS_SX(s3 + 2)) - (TTS_SX(s3 + 3) - 4.f * TTS_SX(s3 + 1));   \
+            else if (i_ == 3) v2 = (TTS_SX(s3 + 4) - TTS_SX(s3 + 2)) + 2.f * (TTS_SX(s3 + 3) - TTS_SX(s3 + 1));         \
+            else if (i_ == 4) v2 = (TTS_SX(s3 + 4) - TTS_SX(s3 + 2)) - 2.f * (TTS_SX(s3 + 3) - TTS_SX(s3 + 1));         \
+            else v2 = 4.f * TTS_SX(s3 + 1) + (TTS_SX(s3 + 5 < G::NPOS ? s3 + 5 : s3) - 5.f * TTS_SX(s3 + 3));           \
+        } else {                                                                                     \
+            v2 = TTS_SX(3 * NSF + (g_ - 6 * NSF));                                                   \
+        }                                                                                            \
+        (WR)[2 * ((ol_ * 2 * NGPM + gl_) * NTUP)] = v2;                                              \
+    }
+
+    const float4* sB = smem4 + kk * NGPM * NTUP + wn * 32 + l31;      // + stage * BUF4 + (ol * 2 NGPM + g) * NTUP
+    w4_f32x2* sW = reinterpret_cast<w4_f32x2*>(smem4 + skk * NGPM * NTUP + lane) + sh;    // + 2 (stage * BUF4 + (ol * 2 NGPM + g) * NTUP)
+    float4 bq[2];
+
+    // prologue: fill NSTAGE - 1 stages (steps 0 .. NSTAGE - 2: phase st % NPH of chunk st / NPH), fetch the first B operand
+    {
+#pragma unroll
+        for (int st = 0; st < NSTAGE - 1; ++st) {
+            const int ph = st % NPH;
+            const int xso = min(st / NPH, n_chunks - 1) * 8 * NOCT * x_cs;
+#pragma unroll
+            for (int J = 0; J < G::nlj(ph); ++J) TTS_LOAD_JOB(ph, J, xso)
+#pragma unroll
+            for (int J = 0; J < G::nlj(ph); ++J) TTS_ACT_JOB(ph, J)
+            w4_f32x2* wr = sW + 2 * st * G::BUF4;
+#pragma unroll
+            for (int J = 0; J < G::nwj(ph); ++J) TTS_WRITE_JOB(ph, J, wr)
+        }
+    }
+    __syncthreads();
+    bq[0] = sB[0];
+
+    int stage = 0;  // step % NSTAGE
+    for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            // the step being staged: NSTAGE - 1 ahead (tail: the last chunk is re-staged into a dead stage -- branch-free body)
+            const int tph = (ph + NSTAGE - 1) % NPH;
+            const int xso = min(c + (ph + NSTAGE - 1) / NPH, n_chunks - 1) * 8 * NOCT * x_cs;
+            const int stage_next = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+            const int stage_fill = (stage == 0) ? NSTAGE - 1 : stage - 1;
+            w4_f32x2* wr = sW + 2 * stage_fill * G::BUF4;
+            const float4* rd = sB + stage * G::BUF4;
+            const int sn = (c + 1 < n_chunks || ph + 1 < NPH) ? stage_next : stage;
+#pragma unroll
+            for (int gs = 0; gs < NOCT * G::ngq(ph); ++gs) {
+                const int ol = gs / G::ngq(ph), gl = gs % G::ngq(ph);
+                const w4_f32x4 a4 = aq[gs % PF];
+                // refill the queue slot with the group PF ahead
+                aq[gs % PF] = __builtin_bit_cast(w4_f32x4, bfo_ld16(wrs, wv, wso, 0));
+                wso = min(wso + wstep, wlast);
+                if (gl >= G::ngp(ph)) continue;                    // the zero group of k = 11: fetched, never multiplied
+                const int r = ol * G::ngp(ph) + gl;                // multiplied groups of the step so far
+                const int cur = r & 1, nxt = cur ^ 1;
+                const int plane = G::plane(G::glo(ph) + gl);
+                // B operand of the next group: same stage, or (three stages) the first group of the next step's stage
+                if (r + 1 < NOCT * G::ngp(ph)) bq[nxt] = rd[(((r + 1) / G::ngp(ph)) * 2 * NGPM + (r + 1) % G::ngp(ph)) * NTUP];
+                else if (NSTAGE >= 3) bq[nxt] = sB[sn * G::BUF4];
+                __builtin_amdgcn_sched_barrier(0);
+                const float bv[4] = {bq[cur].x, bq[cur].y, bq[cur].z, bq[cur].w};
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    acc[plane] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m], bv[m], acc[plane], 0, 0, 0);
+                    // ---- gap work for the step NSTAGE - 1 ahead: LPG loads per gap first, each value activated DA gaps later, then
+                    // the plane writes into the stage the previous step has left
+                    const int t = r * NM + m;
+#pragma unroll
+                    for (int u = 0; u < LPG; ++u)
+                        if (t * LPG + u < G::nlj(tph)) TTS_LOAD_JOB(tph, t * LPG + u, xso)
+#pragma unroll
+                    for (int u = 0; u < LPG; ++u)
+                        if (t >= DA && (t - DA) * LPG + u < G::nlj(tph)) TTS_ACT_JOB(tph, (t - DA) * LPG + u)
+                    if (t >= G::tw0(tph) && (t - G::tw0(tph)) % G::ws(tph) == 0 && (t - G::tw0(tph)) / G::ws(tph) < G::nwj(tph))
+                        TTS_WRITE_JOB(tph, (t - G::tw0(tph)) / G::ws(tph), wr)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            if (NSTAGE < 3) bq[0] = sB[sn * G::BUF4];            // two stages: the next step's stage has only just been written
+            stage = stage_next;
+        }
+    }
+#undef TTS_LOAD_JOB
+#undef TTS_ACT_JOB
+#undef TTS_JOB_IDX
+#undef TTS_SX
+#undef TTS_WRITE_JOB
+
+    // ---- epilogue: output transform into the dead ring, then the row epilogue of conv_mfma.hip (bias, residual, ReLU, accumulate modes)
+    constexpr int LDS_F = CO_BLK * NT_BLK + CO_BLK;                     // floats of LDS this block owns (the launcher allocates max(ring, this))
+    constexpr int LPR = NT_BLK / 4;                                     // lanes per row (one float4 each) = 64
+    static_assert(LPR == 64, "one wave instruction per row");
+    float* ep = reinterpret_cast<float*>(smem4);
+    float* epb = ep + LDS_F - CO_BLK;                                   // [CO_BLK] bias
+    float* __restrict__ yb = p.y + (int64_t)b * p.y_bs;
+    const float* __restrict__ rb = (p.res && !preload) ? p.res + (int64_t)b * p.r_bs : nullptr;
+    const int mode = p.mode, relu_out = p.relu_out, Cout = p.Cout;
+    const float div = p.div;
+    __syncthreads();                                                    // ring stages are dead
+    if (tid < CO_BLK) epb[tid] = ep_bias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+        const float s34 = acc[3][r] + acc[4][r], d34 = acc[3][r] - acc[4][r];
+        float y0 = acc[0][r] + s12 + s34;
+        float y1 = d12 + 2.f * d34;
+        float y2 = s12 + 4.f * s34;
+        float y3 = d12 + 8.f * d34 + acc[5][r];
+        if constexpr (NPL == 8) {
+            y1 += acc[6][r];
+            y2 += acc[7][r];
+        }
+        if (pe < ntup_eff) {
+            if (dil == 1) {
+                *reinterpret_cast<float4*>(ep + row * NT_BLK + col_e) = make_float4(y0, y1, y2, y3);
+            } else {
+                ep[row * NT_BLK + col_e] = y0;
+                ep[row * NT_BLK + col_e + dil] = y1;
+                ep[row * NT_BLK + col_e + 2 * dil] = y2;
+                ep[row * NT_BLK + col_e + 3 * dil] = y3;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int NR = CO_BLK / 4;                                      // row iterations per wave
+    const int col = lane * 4, q = q0 + col;
+    if (q >= n_out || col >= nt_eff) return;
+    const bool full = q + 3 < n_out;
+    if (preload || (!rb && mode == 0)) {
+        // nothing to read from memory: a loop without a single vmcnt wait (conv_mfma.hip: why)
+        const float lo = relu_out == 1 ? 0.f : -__builtin_inff();
+        const bool do_div = preload && mode == 2;
+#pragma unroll 4
+        for (int it = 0; it < NR; ++it) {
+            const int rl = wid + it * 4;
+            const int co = co_blk0 + rl;
+            if (co >= Cout) continue;
+            const float bsv = epb[rl];
+            const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
+            float v[4] = {fmaxf(a4.x + bsv, lo), fmaxf(a4.y + bsv, lo), fmaxf(a4.z + bsv, lo), fmaxf(a4.w + bsv, lo)};
+            if (do_div) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / div;
+            }
+            float* yp = yb + (int64_t)co * p.y_cs + q;
+            if (full) {
+                *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q + e < n_out) yp[e] = v[e];
+            }
+        }
+        return;
+    }
+    if constexpr (preload) return;
+#pragma unroll 2
+    for (int it = 0; it < NR; ++it) {
+        const int rl = wid + it * 4;
+        const int co = co_blk0 + rl;
+        if (co >= Cout) continue;
+        const float bsv = epb[rl];
+        const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        float* yp = yb + (int64_t)co * p.y_cs + q;
+        const float* rp = rb ? rb + (int64_t)co * p.r_cs + q : nullptr;
+        float rr4[4] = {0.f, 0.f, 0.f, 0.f}, pp4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (full) {
+            if (rp) { const float4 t = *reinterpret_cast<const float4*>(rp); rr4[0] = t.x; rr4[1] = t.y; rr4[2] = t.z; rr4[3] = t.w; }
+            if (mode != 0) { const float4 t = *reinterpret_cast<const float4*>(yp); pp4[0] = t.x; pp4[1] = t.y; pp4[2] = t.z; pp4[3] = t.w; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (q + e < n_out) {
+                    if (rp) rr4[e] = rp[e];
+                    if (mode != 0) pp4[e] = yp[e];
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + bsv + rr4[e];
+            if (relu_out == 1) x = fmaxf(x, 0.f);
+            if (mode == 1) x = pp4[e] + x;
+            else if (mode == 2) x = (pp4[e] + x) / div;
+            v[e] = x;
+        }
+        if (full) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (q + e < n_out) yp[e] = v[e];
+        }
+    }
+}
+
+template <int K, int NOCT, int NSTAGE, int EPI>
+static int32_t launch_wino4_epi(const ConvParams& p, hipStream_t stream) {
+    using G = Wino4Geo<K, NOCT, NSTAGE, EPI>;
+    constexpr size_t ring = (size_t)G::NSTAGE * G::BUF4 * sizeof(float4);
+    constexpr size_t epi = ((size_t)G::CO_BLK * G::NT_BLK + G::CO_BLK) * sizeof(float);
+    constexpr size_t lds = ring > epi ? ring : epi;
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    static std::atomic<uint64_t> lds_done{0};
+    const auto kern = conv1d_wino4_f32<K, NOCT, NSTAGE, EPI>;
+    TTS_CHECK_HIP(lds_opt_in((const void*)kern, (int)lds, lds_done));
+    const int nt = wino4_tile(p.dil, G::NTUP);
+    dim3 grid((p.Nout + nt - 1) / nt, p.CoutP / G::CO_BLK, p.batch);
+    ConvParams q = p;
+    q.ksplit = 1;
+    q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int K, int NOCT, int NSTAGE>
+static int32_t launch_wino4_cfg(const ConvParams& p, hipStream_t stream) {
+    // residual preload (16-byte loads of the lane's quad): dilation 1 -- every c2 conv of a ResBlock, the second conv-FF conv
+    if (p.res != nullptr && p.dil == 1) return launch_wino4_epi<K, NOCT, NSTAGE, 3>(p, stream);
+    return launch_wino4_epi<K, NOCT, NSTAGE, 0>(p, stream);
+}
+
+int32_t launch_wino4(const ConvParams& p, hipStream_t stream) {
+    if (p.K == 3) return launch_wino4_cfg<3, 2, 3>(p, stream);       // 16-channel chunks: 48 MFMAs per wave between barriers, 72 KB ring
+    if (p.K == 7) return launch_wino4_cfg<7, 1, 2>(p, stream);       // 64 MFMAs, 64 KB ring
+    if (p.K == 11) return launch_wino4_cfg<11, 1, 2>(p, stream);     // two phases of 12 / 11 groups: 48 / 44 MFMAs, 48 KB ring
+    set_error("wino4: kernel size %d not built (3, 7, 11)", p.K);
+    return TTSAMD_EINVAL;
+}
+
+int wino4_block_outputs(int dil) { return wino4_tile(dil, 64); }
+
+// groups per octet in the packed weights (k = 11: 23 multiplied + one zero group)
+int wino4_groups(int k) { return k == 3 ? 6 : (k == 7 ? 16 : 24); }
+
+// the group filters of one (co, ci) filter g[0..k) in double: sub-filter s -> U0..U5 of (g[3s], g[3s+1], g[3s+2]) (taps past k are
+// zero; k = 11: the fourth sub-filter's U5 = 0 takes the zero group's slot), single tap of k = 7 -> four copies (P0 / P6 / P7 / P5)
+void wino4_filter_groups(const float* g, int k, float* o) {
+    const int nsf = k == 3 ? 1 : (k == 7 ? 2 : 4);
+    for (int s = 0; s < nsf; ++s) {
+        const double g0 = g[3 * s], g1 = 3 * s + 1 < k ? g[3 * s + 1] : 0.0, g2 = 3 * s + 2 < k ? g[3 * s + 2] : 0.0;
+        o[6 * s] = (float)(g0 / 4);
+        o[6 * s + 1] = (float)(-(g0 + g1 + g2) / 6);
+        o[6 * s + 2] = (float)(-(g0 - g1 + g2) / 6);
+        o[6 * s + 3] = (float)(g0 / 24 + g1 / 12 + g2 / 6);
+        o[6 * s + 4] = (float)(g0 / 24 - g1 / 12 + g2 / 6);
+        o[6 * s + 5] = (float)g2;
+    }
+    if (k == 7)
+        for (int j = 0; j < 4; ++j) o[12 + j] = g[6];
+}
+
+// host: torch Conv1d weight [Cout][Cin][K] -> the group filters as an NGQ-tap conv in the engine's packed layout [Cin/8][NGQ][2][CoutP][4]
+void pack_wino4_weight(const float* w, int cout, int cin, int k, float* out) {
+    const int ng = wino4_groups(k);
+    std::vector<float> u((size_t)cout * cin * ng);
+    for (int64_t i = 0; i < (int64_t)cout * cin; ++i) wino4_filter_groups(w + i * k, k, u.data() + i * ng);
+    pack_conv_weight(u.data(), cout, cin, ng, out);
+}
+
+}  // namespace ttsamd

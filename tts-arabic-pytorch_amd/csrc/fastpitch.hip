@@ -20,6 +20,7 @@ struct PConv {
     int64_t w_off = 0, b_off = -1, w16_off = 0;
     int64_t wo_off = -1;   // bf16 octet engine weights [Cin/16][K][2][CoutP][8] in the uint16 blob (the conv-FF convs; -1: not packed)
     int64_t wo3_off = -1;  // ... and their split-bf16 twin [Cin/16][K][2][CoutP][hi 8 | lo 8] (bfo3.hpp)
+    int64_t ww4_off = -1;  // ... and as Winograd F(4,3) groups (conv_wino4.hip)
     int64_t ww_off = -1;   // k = 3: Winograd F(2,3) filters as a 4-tap conv in the fp32 blob (conv_wino.hip; -1: none)
     int cin = 0, cout = 0, k = 0;
 };
@@ -106,6 +107,12 @@ struct Builder {
             c.ww_off = (int64_t)blob.size();
             blob.resize(blob.size() + (size_t)cin * 4 * cout_padded(cout));
             pack_wino_weight(w->data, cout, cin, blob.data() + c.ww_off);
+            if (cin % 16 == 0) {
+                blob.resize(align_up((int64_t)blob.size(), 64));
+                c.ww4_off = (int64_t)blob.size();
+                blob.resize(blob.size() + (size_t)cin * wino4_groups(3) * cout_padded(cout));
+                pack_wino4_weight(w->data, cout, cin, 3, blob.data() + c.ww4_off);
+            }
         }
         if (octet && cin % 8 == 0 && cout % 32 == 0 && cout >= 128 && (k == 1 || k == 3 || k == 7 || k == 11)) {
             // the conv-FF pair also runs on the bf16 octet engine (config 3): v_mfma_f32_32x32x16_bf16, bf16 intermediate
@@ -264,6 +271,7 @@ static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, floa
     p.w = h->dev + c.w_off; p.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
     p.w_bf16 = h->dev16 + c.w16_off; p.precision = default_precision();
     p.w_wino = c.ww_off >= 0 ? h->dev + c.ww_off : nullptr;
+    p.w_wino4 = c.ww4_off >= 0 ? h->dev + c.ww4_off : nullptr;
     p.y = y; p.y_bs = (int64_t)c.cout * S; p.y_cs = S; p.y_ts = 1;
     p.res = res; p.r_bs = (int64_t)c.cout * S; p.r_cs = S;
     p.lens_in = lens_in; p.lens_out = nullptr; p.len_in_mul = 1; p.len_out_mul = 1;

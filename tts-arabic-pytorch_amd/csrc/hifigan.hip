@@ -28,6 +28,7 @@ struct ConvW {
     int64_t w16_off = 0, w_n = 0;  // bf16 planes (hi, lo) in the uint16 blob; packed element count
     int64_t wo_off = -1;           // bf16 octet engine (bfo.hpp): [Cin/16][K][2][CoutP][8] in the same uint16 blob (-1: not packed)
     int64_t wo3_off = -1;          // its split-bf16 mode (bfo3.hpp): [Cin/16][K][2][CoutP][hi 8 | lo 8]
+    int64_t ww4_off = -1;          // ... and as Winograd F(4,3) groups (conv_wino4.hip; the un-fused convs: Cout >= 128)
     int64_t ww_off = -1;           // k = 3 / 7 / 11: Winograd F(2,3) (sub-)filters + single taps as an NG-tap conv in the fp32 blob (conv_wino2.hip; -1: none)
     int cin = 0, cout = 0, k = 0;
 };
@@ -216,6 +217,12 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
         cw.ww_off = (int64_t)blob.size();
         blob.resize(blob.size() + (size_t)cin * wino2_groups(k) * cout_padded(cout));
         pack_wino2_weight(w.data(), cout, cin, k, blob.data() + cw.ww_off);
+        if (cout >= 128) {            // the un-fused ResBlock convs (stages with 128 / 256 channels): F(4,3) decomposition
+            blob.resize(align_up((int64_t)blob.size(), 64));
+            cw.ww4_off = (int64_t)blob.size();
+            blob.resize(blob.size() + (size_t)cin * wino4_groups(k) * cout_padded(cout));
+            pack_wino4_weight(w.data(), cout, cin, k, blob.data() + cw.ww4_off);
+        }
     }
     if (cin % 8 == 0 && cout % 32 == 0) {
         blob16.resize(align_up((int64_t)blob16.size(), 64));
@@ -455,6 +462,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         p.w = h->dev + cw.w_off; p.bias = h->dev + cw.b_off;
         p.w_bf16 = h->dev16 + cw.w16_off; p.precision = default_precision();
         p.w_wino = cw.ww_off >= 0 ? h->dev + cw.ww_off : nullptr;
+        p.w_wino4 = cw.ww4_off >= 0 ? h->dev + cw.ww4_off : nullptr;
         p.y = y; p.y_bs = (int64_t)cw.cout * L; p.y_cs = L; p.y_ts = 1;
         p.res = res; p.r_bs = (int64_t)cw.cout * L; p.r_cs = L;
         p.len_in_mul = mul; p.len_out_mul = mul; p.Lin = L; p.Nout = L;
@@ -620,7 +628,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         // leaky_relu(0.1) + ConvTranspose1d as u polyphase 2-tap convs (models.py:114-115)
         p.x = cur; p.x_bs = (int64_t)uw.cin * L; p.x_cs = L;
         p.w = h->dev + uw.w_off; p.bias = h->dev + uw.b_off;
-        p.w_bf16 = h->dev16 + uw.w16_off; p.precision = default_precision(); p.w_wino = nullptr;
+        p.w_bf16 = h->dev16 + uw.w16_off; p.precision = default_precision(); p.w_wino = nullptr; p.w_wino4 = nullptr;
         p.y = ups_out; p.y_bs = (int64_t)uw.cout * L * u; p.y_cs = L * u; p.y_ts = u;
         p.res = nullptr;
         p.len_in_mul = mul; p.len_out_mul = mul; p.Lin = L; p.Nout = L;
