@@ -1,5 +1,5 @@
 """Kernel-level A/B of the fp32 conv kernels on HiFi-GAN's dilation-1 shapes: direct (TTSAMD_WINO=0), Winograd F(2,3) (k = 3) and the
-decomposition kernel (TTSAMD_WINO2 mask).  Run under rocprofv3 --kernel-trace --stats for per-kernel durations; prints wall-clock per call.
+decomposition kernels (F(2,3): TTSAMD_WINO2 mask, F(4,3): TTSAMD_WINO4 mask; WINO_BENCH_ONLY=wino2,wino4 picks the variants).  Run under rocprofv3 --kernel-trace --stats for per-kernel durations; prints wall-clock per call.
 gpurun -- 'python3 tools/wino_bench.py'"""
 import os
 import sys
@@ -26,9 +26,12 @@ for C, mul in ((256, 8), (128, 64), (64, 128)):
         b = torch.zeros(C, device=dev)
         y = torch.empty_like(x)
         packed = torch.empty(L.ttsamd_conv1d_packed_floats(C, C, k), dtype=torch.float32, device=dev)
-        for name, env in (('direct', {'TTSAMD_WINO': '0'}), ('wino', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '0'}),
-                          ('wino2', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '31'})):
+        for name, env in (('direct', {'TTSAMD_WINO': '0'}), ('wino', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '0', 'TTSAMD_WINO4': '0'}),
+                          ('wino2', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '31', 'TTSAMD_WINO4': '0'}),
+                          ('wino4', {'TTSAMD_WINO': '1', 'TTSAMD_WINO2': '31', 'TTSAMD_WINO4': '15'})):
             if name == 'wino' and (k != 3 or C == 64):
+                continue
+            if os.environ.get('WINO_BENCH_ONLY') and name not in os.environ['WINO_BENCH_ONLY'].split(','):
                 continue
             os.environ.update(env)
             def call():

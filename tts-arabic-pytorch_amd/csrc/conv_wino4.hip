@@ -35,6 +35,12 @@
 #include "conv_mfma_common.hpp"
 #include "bfo.hpp"
 
+// timing experiments only (tools/w4_exp.sh builds its own libraries; results are WRONG by design): bit 0 no x loads in the main loop,
+// 1 no activation, 2 no plane writes, 3 no weight refill, 4 no B reads
+#ifndef TTS_W4_EXP
+#define TTS_W4_EXP 0
+#endif
+
 namespace ttsamd {
 
 typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
@@ -85,24 +91,36 @@ struct Wino4Geo {
     static constexpr int LPG = 3 * (NOCT * 2 * NPOSP) > ngap(NPH - 1) ? 2 : 1;                // loads per gap
     __host__ __device__ static constexpr int tw0(int ph) { return (nlj(ph) + LPG - 1) / LPG + DA; }    // first gap with every value activated
     __host__ __device__ static constexpr int ws(int ph) { return (ngap(ph) - tw0(ph)) / nwj(ph); }     // one plane write every ws gaps after it
+    // dilation 1 (D1 kernels): the window is fetched as ALIGNED 16-byte vectors -- vector v of a lane = positions 4 (tuple + v) .. + 3 of the
+    // row (a vector is entirely left of position 0 -> zeros by the range check, which drops a WHOLE dwordx4 whose first dword is out of range
+    // and checks the right edge dword by dword: tools/buf_range_probe.hip) -- instead of one dword per position: a wave instruction then
+    // moves 1 KB of contiguous row instead of 64 dwords at a 16-byte stride (4x the lines through the L1 per value)
+    __host__ __device__ static constexpr int fdiv4(int e) { return e >= 0 ? e / 4 : -((3 - e) / 4); }
+    __host__ __device__ static constexpr int vlo(int ph) { return fdiv4(mlo(ph) - (K - 1) / 2); }
+    __host__ __device__ static constexpr int nvec(int ph) { return fdiv4(mhi(ph) - (K - 1) / 2) - vlo(ph) + 1; }
+    static constexpr int NVP = nvec(0) > nvec(NPH - 1) ? nvec(0) : nvec(NPH - 1);
+    __host__ __device__ static constexpr int nljv(int ph) { return NOCT * 2 * nvec(ph); }     // vector load jobs
+    static constexpr int DAV = K == 3 ? 8 : 16;
+    __host__ __device__ static constexpr int tw0v(int ph) { return DAV + 2 * nljv(ph); }       // two activation jobs per vector, one per gap
+    __host__ __device__ static constexpr int wsv(int ph) { return (ngap(ph) - tw0v(ph)) / nwj(ph); }
+    static_assert(wsv(0) >= 1 && wsv(NPH - 1) >= 1, "one write job per gap at most (vector loads)");
     static_assert((NOCT * ngq(0)) % PF == 0 && (NOCT * ngq(NPH - 1)) % PF == 0, "queue slots line up across steps");
     static_assert(ws(0) >= 1 && ws(NPH - 1) >= 1, "one write job per gap at most");
     static_assert((size_t)NSTAGE * BUF4 * 16 <= 80 * 1024, "two blocks per CU");
-    static_assert(NPH == 1 || (NSTAGE == 2 && NOCT == 1), "phases alternate between two stages");
-    static_assert(NSTAGE < 3 || ((NOCT * ngp(0)) % 2 == 0 && (NOCT * ngp(NPH - 1)) % 2 == 0), "the B ping-pong restarts at slot 0");
+    static_assert(NPH == 1 || NOCT == 1, "phases split an octet's groups");
 };
 
 // outputs per tile at dilation d: the largest multiple of 4 d in 4 * ntup
 __device__ __host__ constexpr int wino4_tile(int d, int ntup) { return (4 * ntup / (4 * d)) * (4 * d); }
 
-template <int K, int NOCT_, int NSTAGE_, int EPI>
+template <int K, int NOCT_, int NSTAGE_, int EPI, bool D1>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     using G = Wino4Geo<K, NOCT_, NSTAGE_, EPI>;
     constexpr int WN = G::WN, NSF = G::NSF, NOCT = G::NOCT, NSTAGE = G::NSTAGE, NPL = G::NPL, NGPM = G::NGPM;
     constexpr int CO_BLK = G::CO_BLK, NTUP = G::NTUP, NT_BLK = G::NT_BLK, PF = G::PF;
     constexpr int NPH = G::NPH, NPOSP = G::NPOSP, NM = G::NM, DA = G::DA, LPG = G::LPG;
-    const int dil = p.dil;
+    const int dil = D1 ? 1 : p.dil;
     const int nt_eff = wino4_tile(dil, NTUP), ntup_eff = nt_eff / 4;
     int b = blockIdx.z;
     int q0 = blockIdx.x * nt_eff;
@@ -188,10 +206,14 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     // [ol][kks][g][pc].  (h, kks) = the wave index: a wave instruction reads ONE channel row, so the row is the base of a raw buffer
     // descriptor of in_len * 4 bytes and the load's range check returns the zeros of the halo (conv_wino2.hip).
     const int sh = __builtin_amdgcn_readfirstlane((tid >> 7) & 1), skk = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);
-    w4_f32x2 sx[NOCT][NPOSP];                                // [pp] = the two channels of the item, packed
+    w4_f32x2 sx[D1 ? 1 : NOCT][D1 ? 1 : NPOSP];              // [pp] = the two channels of the item, packed (one dword per position)
+    w4_f32x4 sv[D1 ? NOCT : 1][2][D1 ? G::NVP : 1];          // D1: [octet][pp][vector]
+    w4_f32x2 ta[NOCT], tb[NOCT];                             // partial sums shared by two consecutive plane jobs
     const int spe = min(lane, ntup_eff - 1);                 // idle tuple slots (d > 1) repeat the last tuple: never stored
     const int xv0 = (q0 + (dil == 1 ? 4 * spe : (spe / dil) * 4 * dil + spe % dil) - pad * dil) * 4;
     const int xvd = 4 * dil;
+    const int xw0 = (q0 + 4 * lane) * 4;                      // D1: byte offset of the lane's vector 0 in its row
+    constexpr int pad_c = (K - 1) / 2;
     const int ch_off = (4 * sh + skk) * x_cs;                 // channel 2 (2 h) + kks; pp adds 2 rows, the octet 8
 
 #define TTS_JOB_IDX(PH, J)                                                                           \
@@ -203,17 +225,40 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + (8 * ol_ + 2 * pp_) * x_cs), (unsigned)in_len * 4u);     \
         sx[ol_][mi_][pp_] = bfo_ld4f(xrs_, xv0 + xvd * (G::mlo(PH) + mi_), 0, 0);                   \
     }
+    // D1: vector job J -> (octet, pp, vector)
+#define TTS_VJOB_IDX(PH, J)                                                                          \
+        const int nv_ = G::nvec(PH);                                                                 \
+        const int ol_ = (J) / (2 * nv_), pp_ = ((J) / nv_) % 2, vi_ = (J) % nv_;
+#define TTS_VLOAD_JOB(PH, J, XSO)                                                                    \
+    {                                                                                                \
+        TTS_VJOB_IDX(PH, J)                                                                          \
+        const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + (8 * ol_ + 2 * pp_) * x_cs), (unsigned)in_len * 4u);     \
+        sv[ol_][pp_][vi_] = __builtin_bit_cast(w4_f32x4, bfo_ld16(xrs_, xw0 + 16 * (G::vlo(PH) + vi_), 0, 0));      \
+    }
+    // ... its activation in two jobs (components 0, 1 / 2, 3)
+#define TTS_VACT_JOB(PH, A)                                                                          \
+    {                                                                                                \
+        TTS_VJOB_IDX(PH, (A) / 2)                                                                    \
+        if ((A) % 2 == 0) {                                                                          \
+            sv[ol_][pp_][vi_].x = bfo_lrelu(sv[ol_][pp_][vi_].x, in_slope);                          \
+            sv[ol_][pp_][vi_].y = bfo_lrelu(sv[ol_][pp_][vi_].y, in_slope);                          \
+        } else {                                                                                     \
+            sv[ol_][pp_][vi_].z = bfo_lrelu(sv[ol_][pp_][vi_].z, in_slope);                          \
+            sv[ol_][pp_][vi_].w = bfo_lrelu(sv[ol_][pp_][vi_].w, in_slope);                          \
+        }                                                                                            \
+    }
     // leaky-relu on load, once per value pair, after its second load (slopes in [0, 1]: max(x, slope x); slope 1 = the identity, exactly)
 #define TTS_ACT_JOB(PH, J)                                                                           \
     if ((J) & 1) {                                                                                   \
         TTS_JOB_IDX(PH, J)                                                                           \
         (void)pp_;                                                                                   \
-        const w4_f32x2 w_ = sx[ol_][mi_] * in_slope;                                                 \
-        sx[ol_][mi_].x = fmaxf(sx[ol_][mi_].x, w_.x);                                                \
-        sx[ol_][mi_].y = fmaxf(sx[ol_][mi_].y, w_.y);                                                \
+        sx[ol_][mi_].x = bfo_lrelu(sx[ol_][mi_].x, in_slope);                                       \
+        sx[ol_][mi_].y = bfo_lrelu(sx[ol_][mi_].y, in_slope);                                        \
     }
     // plane g of octet ol from the staged values.  Job J -> (octet, group of the phase)
-#define TTS_SX(M) sx[ol_][(M) - G::mlo(PH_)]
+#define TTS_SXV(M) (w4_f32x2{sv[ol_][0][G::fdiv4((M) - pad_c) - G::vlo(PH_)][((M) - pad_c) - 4 * G::fdiv4((M) - pad_c)],     \
+                             sv[ol_][1][G::fdiv4((M) - pad_c) - G::vlo(PH_)][((M) - pad_c) - 4 * G::fdiv4((M) - pad_c)]})
+#define TTS_SX(M) (D1 ? TTS_SXV(M) : sx[D1 ? 0 : ol_][D1 ? 0 : (M) - G::mlo(PH_)])
 #define TTS_WRITE_JOB(PH, J, WR)                                                                     \
     {                                                                                                \
         const int PH_ = (PH);                                                                        \
@@ -221,11 +266,18 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         w4_f32x2 v2;                                                                                 \
         if (g_ < 6 * NSF) {                                                                          \
             const int s3 = 3 * (g_ / 6), i_ = g_ % 6;                                                \
+            /* the pairs (V1, V2) and (V3, V4) share their two partial sums: kept in ta / tb from the odd job to the even one */ \
             if (i_ == 0) v2 = 4.f * TTS_SX(s3) + (TTS_SX(s3 + 4) - 5.f * TTS_SX(s3 + 2));           \
-            else if (i_ == 1) v2 = (TTS_SX(s3 + 4) - 4.f * TTS_SX(s3 + 2)) + (TTS_SX(s3 + 3) - 4.f * TTS_SX(s3 + 1));   \
-            else if (i_ == 2) v2 = (TTS_SX(s3 + 4) - 4.f * TTS_SX(s3 + 2)) - (TTS_SX(s3 + 3) - 4.f * TTS_SX(s3 + 1));   \
-            else if (i_ == 3) v2 = (TTS_SX(s3 + 4) - TTS_SX(s3 + 2)) + 2.f * (TTS_SX(s3 + 3) - TTS_SX(s3 + 1));         \
-            else if (i_ == 4) v2 = (TTS_SX(s3 + 4) - TTS_SX(s3 + 2)) - 2.f * (TTS_SX(s3 + 3) - TTS_SX(s3 + 1));         \
+            else if (i_ == 1) {                                                                      \
+                ta[ol_] = TTS_SX(s3 + 4) - 4.f * TTS_SX(s3 + 2);                                     \
+                tb[ol_] = TTS_SX(s3 + 3) - 4.f * TTS_SX(s3 + 1);                                     \
+                v2 = ta[ol_] + tb[ol_];                                                              \
+            } else if (i_ == 2) v2 = ta[ol_] - tb[ol_];                                              \
+            else if (i_ == 3) {                                                                      \
+                ta[ol_] = TTS_SX(s3 + 4) - TTS_SX(s3 + 2);                                           \
+                tb[ol_] = 2.f * (TTS_SX(s3 + 3) - TTS_SX(s3 + 1));                                   \
+                v2 = ta[ol_] + tb[ol_];                                                              \
+            } else if (i_ == 4) v2 = ta[ol_] - tb[ol_];                                              \
             else v2 = 4.f * TTS_SX(s3 + 1) + (TTS_SX(s3 + 5 < G::NPOS ? s3 + 5 : s3) - 5.f * TTS_SX(s3 + 3));           \
         } else {                                                                                     \
             v2 = TTS_SX(3 * NSF + (g_ - 6 * NSF));                                                   \
@@ -243,10 +295,17 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         for (int st = 0; st < NSTAGE - 1; ++st) {
             const int ph = st % NPH;
             const int xso = min(st / NPH, n_chunks - 1) * 8 * NOCT * x_cs;
+            if constexpr (D1) {
 #pragma unroll
-            for (int J = 0; J < G::nlj(ph); ++J) TTS_LOAD_JOB(ph, J, xso)
+                for (int J = 0; J < G::nljv(ph); ++J) TTS_VLOAD_JOB(ph, J, xso)
 #pragma unroll
-            for (int J = 0; J < G::nlj(ph); ++J) TTS_ACT_JOB(ph, J)
+                for (int J = 0; J < 2 * G::nljv(ph); ++J) TTS_VACT_JOB(ph, J)
+            } else {
+#pragma unroll
+                for (int J = 0; J < G::nlj(ph); ++J) TTS_LOAD_JOB(ph, J, xso)
+#pragma unroll
+                for (int J = 0; J < G::nlj(ph); ++J) TTS_ACT_JOB(ph, J)
+            }
             w4_f32x2* wr = sW + 2 * st * G::BUF4;
 #pragma unroll
             for (int J = 0; J < G::nwj(ph); ++J) TTS_WRITE_JOB(ph, J, wr)
@@ -272,15 +331,16 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
                 const int ol = gs / G::ngq(ph), gl = gs % G::ngq(ph);
                 const w4_f32x4 a4 = aq[gs % PF];
                 // refill the queue slot with the group PF ahead
-                aq[gs % PF] = __builtin_bit_cast(w4_f32x4, bfo_ld16(wrs, wv, wso, 0));
+                if (!(TTS_W4_EXP & 8)) aq[gs % PF] = __builtin_bit_cast(w4_f32x4, bfo_ld16(wrs, wv, wso, 0));
                 wso = min(wso + wstep, wlast);
                 if (gl >= G::ngp(ph)) continue;                    // the zero group of k = 11: fetched, never multiplied
                 const int r = ol * G::ngp(ph) + gl;                // multiplied groups of the step so far
                 const int cur = r & 1, nxt = cur ^ 1;
                 const int plane = G::plane(G::glo(ph) + gl);
                 // B operand of the next group: same stage, or (three stages) the first group of the next step's stage
-                if (r + 1 < NOCT * G::ngp(ph)) bq[nxt] = rd[(((r + 1) / G::ngp(ph)) * 2 * NGPM + (r + 1) % G::ngp(ph)) * NTUP];
-                else if (NSTAGE >= 3) bq[nxt] = sB[sn * G::BUF4];
+                if (TTS_W4_EXP & 16) bq[nxt] = bq[cur];
+                else if (r + 1 < NOCT * G::ngp(ph)) bq[nxt] = rd[(((r + 1) / G::ngp(ph)) * 2 * NGPM + (r + 1) % G::ngp(ph)) * NTUP];
+                else if (NSTAGE >= 3) bq[nxt] = sB[sn * G::BUF4];       // (an odd step leaves it in slot 1: moved to slot 0 behind the barrier)
                 __builtin_amdgcn_sched_barrier(0);
                 const float bv[4] = {bq[cur].x, bq[cur].y, bq[cur].z, bq[cur].w};
 #pragma unroll
@@ -289,22 +349,35 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
                     // ---- gap work for the step NSTAGE - 1 ahead: LPG loads per gap first, each value activated DA gaps later, then
                     // the plane writes into the stage the previous step has left
                     const int t = r * NM + m;
+                    if constexpr (D1) {
+                        if (!(TTS_W4_EXP & 1) && t < G::nljv(tph)) TTS_VLOAD_JOB(tph, t, xso)
+                        if (!(TTS_W4_EXP & 2) && t >= G::DAV && t - G::DAV < 2 * G::nljv(tph)) TTS_VACT_JOB(tph, t - G::DAV)
+                        if (!(TTS_W4_EXP & 4) && t >= G::tw0v(tph) && (t - G::tw0v(tph)) % G::wsv(tph) == 0 &&
+                            (t - G::tw0v(tph)) / G::wsv(tph) < G::nwj(tph))
+                            TTS_WRITE_JOB(tph, (t - G::tw0v(tph)) / G::wsv(tph), wr)
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < LPG; ++u)
-                        if (t * LPG + u < G::nlj(tph)) TTS_LOAD_JOB(tph, t * LPG + u, xso)
+                        for (int u = 0; u < LPG; ++u)
+                            if (!(TTS_W4_EXP & 1) && t * LPG + u < G::nlj(tph)) TTS_LOAD_JOB(tph, t * LPG + u, xso)
 #pragma unroll
-                    for (int u = 0; u < LPG; ++u)
-                        if (t >= DA && (t - DA) * LPG + u < G::nlj(tph)) TTS_ACT_JOB(tph, (t - DA) * LPG + u)
-                    if (t >= G::tw0(tph) && (t - G::tw0(tph)) % G::ws(tph) == 0 && (t - G::tw0(tph)) / G::ws(tph) < G::nwj(tph))
-                        TTS_WRITE_JOB(tph, (t - G::tw0(tph)) / G::ws(tph), wr)
+                        for (int u = 0; u < LPG; ++u)
+                            if (!(TTS_W4_EXP & 2) && t >= DA && (t - DA) * LPG + u < G::nlj(tph)) TTS_ACT_JOB(tph, (t - DA) * LPG + u)
+                        if (!(TTS_W4_EXP & 4) && t >= G::tw0(tph) && (t - G::tw0(tph)) % G::ws(tph) == 0 && (t - G::tw0(tph)) / G::ws(tph) < G::nwj(tph))
+                            TTS_WRITE_JOB(tph, (t - G::tw0(tph)) / G::ws(tph), wr)
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
             if (NSTAGE < 3) bq[0] = sB[sn * G::BUF4];            // two stages: the next step's stage has only just been written
+            else if ((NOCT * G::ngp(ph)) % 2 != 0) bq[0] = bq[1];
             stage = stage_next;
         }
     }
+#undef TTS_VLOAD_JOB
+#undef TTS_VACT_JOB
+#undef TTS_VJOB_IDX
+#undef TTS_SXV
 #undef TTS_LOAD_JOB
 #undef TTS_ACT_JOB
 #undef TTS_JOB_IDX
@@ -420,7 +493,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     }
 }
 
-template <int K, int NOCT, int NSTAGE, int EPI>
+template <int K, int NOCT, int NSTAGE, int EPI, bool D1>
 static int32_t launch_wino4_epi(const ConvParams& p, hipStream_t stream) {
     using G = Wino4Geo<K, NOCT, NSTAGE, EPI>;
     constexpr size_t ring = (size_t)G::NSTAGE * G::BUF4 * sizeof(float4);
@@ -428,7 +501,7 @@ static int32_t launch_wino4_epi(const ConvParams& p, hipStream_t stream) {
     constexpr size_t lds = ring > epi ? ring : epi;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static std::atomic<uint64_t> lds_done{0};
-    const auto kern = conv1d_wino4_f32<K, NOCT, NSTAGE, EPI>;
+    const auto kern = conv1d_wino4_f32<K, NOCT, NSTAGE, EPI, D1>;
     TTS_CHECK_HIP(lds_opt_in((const void*)kern, (int)lds, lds_done));
     const int nt = wino4_tile(p.dil, G::NTUP);
     dim3 grid((p.Nout + nt - 1) / nt, p.CoutP / G::CO_BLK, p.batch);
@@ -443,14 +516,18 @@ static int32_t launch_wino4_epi(const ConvParams& p, hipStream_t stream) {
 template <int K, int NOCT, int NSTAGE>
 static int32_t launch_wino4_cfg(const ConvParams& p, hipStream_t stream) {
     // residual preload (16-byte loads of the lane's quad): dilation 1 -- every c2 conv of a ResBlock, the second conv-FF conv
-    if (p.res != nullptr && p.dil == 1) return launch_wino4_epi<K, NOCT, NSTAGE, 3>(p, stream);
-    return launch_wino4_epi<K, NOCT, NSTAGE, 0>(p, stream);
+    // dilation 1: the window as aligned 16-byte vectors (D1)
+    if (p.dil == 1) {
+        if (p.res != nullptr) return launch_wino4_epi<K, NOCT, NSTAGE, 3, true>(p, stream);
+        return launch_wino4_epi<K, NOCT, NSTAGE, 0, true>(p, stream);
+    }
+    return launch_wino4_epi<K, NOCT, NSTAGE, 0, false>(p, stream);
 }
 
 int32_t launch_wino4(const ConvParams& p, hipStream_t stream) {
     if (p.K == 3) return launch_wino4_cfg<3, 2, 3>(p, stream);       // 16-channel chunks: 48 MFMAs per wave between barriers, 72 KB ring
     if (p.K == 7) return launch_wino4_cfg<7, 1, 2>(p, stream);       // 64 MFMAs, 64 KB ring
-    if (p.K == 11) return launch_wino4_cfg<11, 1, 2>(p, stream);     // two phases of 12 / 11 groups: 48 / 44 MFMAs, 48 KB ring
+    if (p.K == 11) return launch_wino4_cfg<11, 1, 3>(p, stream);     // two phases of 12 / 11 groups: 48 / 44 MFMAs, 72 KB ring
     set_error("wino4: kernel size %d not built (3, 7, 11)", p.K);
     return TTSAMD_EINVAL;
 }
