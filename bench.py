@@ -788,23 +788,24 @@ def main():
                 'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
-                    'kernel': ('MFMA conv engine: conv1d_wino2_f32 (Winograd F(2,3) decomposition, k = 3 / 7 / 11) + resblock_pair2 (fused C = 32 / 64 pairs, both phases on F(2,3)) + conv1d_mfma_f32 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
+                    'kernel': ('MFMA conv engine: conv1d_wino4_f32 (Winograd F(4,3) decomposition, k = 7 / 11, C >= 128) + conv1d_wino2_f32 (F(2,3), k = 3) + resblock_pair2 (fused C = 32 / 64 pairs, both phases on F(2,3)) + conv1d_mfma_f32 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
             if args.precision == 'f32':
                 # products the Winograd launches do NOT issue (conv_wino2.hip: k = 3 / 7 / 11 as F(2,3) sub-filters + single taps: 4/6,
                 # 10/14, 16/22 of the direct conv's): every ResBlock conv of HiFi-GAN's C >= 128 stages, FastPitch's decoder conv-FF
                 saved = args.steps * (hifigan_wino_saved_flops_per_frame(HC) * frames +
                                       NC['out_fft_n_layers'] * 2.0 * NC['symbols_embedding_dim'] * NC['out_fft_conv1d_filter_size'] *
-                                      NC['out_fft_conv1d_kernel_size'] * 2 / 3.0 * (frames + B)) if wino_on() else 0.0
+                                      NC['out_fft_conv1d_kernel_size'] * 2 * (1.0 - wino_product_ratio(NC['symbols_embedding_dim'], NC['out_fft_conv1d_kernel_size'], 1, fused=False)) * (frames + B)) if wino_on() else 0.0
                 issued = (flops - saved) / (max(conv_ms, 1e-9) * 1e-3) / 1e12
                 roof['issued'] = issued
                 roof['frac_issued'] = issued / peak
                 roof['flops_basis'] = ('`achieved` / `frac`: UN-REDUCED algorithmic FLOPs (2 Cout Cin K per valid output position) over kernel time.  '
-                                       '`issued` / `frac_issued`: the same minus the products the Winograd F(2,3) launches do not issue (k = 3 / 7 / 11 '
-                                       'convs as three-tap sub-filters + single taps: 4/6, 10/14, 16/22 of the direct products; every ResBlock conv of HiFi-GAN '
-                                       '(C >= 128 un-fused, C = 32 / 64 inside the fused pairs), FastPitch decoder conv-FF) = what the MFMA pipe '
-                                       'executed against its peak.  '
-                                       'TTSAMD_WINO=0 runs the direct kernels (profiles/r5/wino_off_bench_line.json)')
+                                       '`issued` / `frac_issued`: the same minus the products the Winograd launches do not issue, from the IDEAL product '
+                                       'counts of the routed kernels -- F(4,3) decomposition (conv_wino4.hip: 16/28, 23/44 of the direct products at k = 7 / 11; '
+                                       'HiFi-GAN C >= 128 un-fused), F(2,3) (4/6, 10/14, 16/22: k = 3 at C >= 128, both phases of the fused C = 32 / 64 pairs, '
+                                       'FastPitch decoder conv-FF).  Idle tuple slots at dilation 3 / 5, the fused pairs\' halo recompute and small launches '
+                                       'routed back to the direct kernel are NOT counted: a LOWER bound on what the MFMA pipe executed.  '
+                                       'TTSAMD_WINO=0 runs the direct kernels, TTSAMD_WINO4=0 the round-5 F(2,3) routing')
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
                      'traffic_algorithmic': traffic_alg, 'traffic_ratio': (traffic / traffic_alg) if (traffic and traffic_alg) else None,
                      'launches': int(n_launch), 'sections': int(n_sections),
@@ -1196,23 +1197,55 @@ def hifigan_flops_per_frame(h):
     return f
 
 
+def _env_int(name, default):
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+def wino_product_ratio(ch, kk, dil=1, fused=None):
+    """Products the routed kernel of a ResBlock / conv-FF conv issues, as a fraction of the direct conv's 2 k per output pair -- from the
+    routing masks the library reads (TTSAMD_WINO, TTSAMD_WINO4, TTSAMD_WINO2, TTSAMD_FUSED2_WB; csrc/conv_wino.hip: wino_route, csrc/hifigan.hip):
+      F(4,3) decomposition (conv_wino4.hip): 6 / 16 / 23 products per output quad at k = 3 / 7 / 11  -> 0.500 / 0.571 / 0.523
+      F(2,3) decomposition (conv_wino2.hip, both phases of the fused pairs): 4 / 10 / 16 per pair     -> 0.667 / 0.714 / 0.727
+    IDEAL counts of the routed kernels: idle tuple slots at dilation 3 / 5 (120 of 128 columns), the halo the fused pairs recompute and
+    launches that the >= 192-block rule sends back to the direct kernel (small batches) are not in it, so `issued` is a LOWER bound on what
+    the matrix pipe executed and `frac_issued` a lower bound on its utilisation."""
+    if kk not in (3, 7, 11) or os.environ.get('TTSAMD_WINO', '1') == '0':
+        return 1.0
+    kbit = {3: 1, 7: 2, 11: 4}[kk]
+    f23 = (4 * (kk // 3) + 2 * (kk % 3)) / (2.0 * kk)
+    f43 = {3: 6, 7: 16, 11: 23}[kk] / (4.0 * kk)
+    if fused is None:
+        fused = ch <= 32 or (ch <= 128 and kk == 3)            # hifigan.hip: kFused2Mask 04f
+    if fused:
+        return f23 if os.environ.get('TTSAMD_FUSED2_WB', '1') != '0' else 1.0
+    m4, m2 = _env_int('TTSAMD_WINO4', 14), _env_int('TTSAMD_WINO2', 31)
+    if (m4 & kbit) and (dil == 1 or (m4 & 8)):
+        return f43
+    if (m2 & kbit) and (dil == 1 or (m2 & 8)):
+        return f23
+    return 1.0
+
+
 def hifigan_wino_saved_flops_per_frame(h):
-    """Products per mel frame that the Winograd kernels do not issue (kernel sizes 3 / 7 / 11: 4/6, 10/14, 16/22 of the direct conv's
-    products): every ResBlock conv -- the stages with >= 128 channels on csrc/conv_wino2.hip, both phases of the fused C = 32 / 64 pairs
-    (csrc/resblock_fused2.hip).  Default routing (hifigan.hip: kFused2Mask)."""
+    """Products per mel frame that the Winograd kernels do not issue (wino_product_ratio per ResBlock conv): the stages with >= 128 channels on
+    csrc/conv_wino4.hip (k = 7 / 11; C >= 64) and conv_wino2.hip (k = 3), both phases of the fused pairs (C = 32 every k, C = 64 / 128 k = 3) on F(2,3)
+    (csrc/resblock_fused2.hip)."""
     ch, mul, f = h['upsample_initial_channel'], 1, 0.0
     for u in h['upsample_rates']:
         ch, mul = ch // 2, mul * u
         for kk, dil in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
-            if kk not in (3, 7, 11) or ch < 32:
+            if ch < 32:
                 continue
-            ng = 4 * (kk // 3) + 2 * (kk % 3)
-            f += len(dil) * 2 * (2.0 * ch * ch * kk) * mul * (1.0 - ng / (2.0 * kk))
+            for d in dil:
+                f += (2.0 * ch * ch * kk) * mul * ((1.0 - wino_product_ratio(ch, kk, d)) + (1.0 - wino_product_ratio(ch, kk, 1)))   # c1 (dilated) + c2
     return f
 
 
 def wino_on():
-    return os.environ.get('TTSAMD_WINO', '1') != '0' and os.environ.get('TTSAMD_WINO2', '31') == '31' and os.environ.get('TTSAMD_FUSED2_WB', '1') != '0'
+    return os.environ.get('TTSAMD_WINO', '1') != '0'
 
 
 def fastpitch_conv_flops_per_pos(c):

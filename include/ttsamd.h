@@ -107,10 +107,22 @@ typedef struct ttsamd_tagger_cfg {
 const char* ttsamd_last_error(void);
 /* ABI revision of this header.  Bumped whenever a struct gains a field or an argument changes meaning (2: ttsamd_tacotron2_cfg
  * gained decoder_early_stopping, ttsamd_profile_read's third value became the number of timed sections; 3: ttsamd_dp_* may be
- * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument; 5: the ttsamd_bfo3_* entries, ttsamd_conv1d_ex).  ttsamd_version() returns the value the library was BUILT with: a caller
+ * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument; 5: the ttsamd_bfo3_* entries, ttsamd_conv1d_ex; 6: ttsamd_set_option / ttsamd_get_option / ttsamd_option_name / ttsamd_options_check replace the per-call
+ * environment reads, ttsamd_resblock_pair takes the size of `packed`, ttsamd_resblock_pair_packed_floats).  ttsamd_version() returns the value the library was BUILT with: a caller
  * compiled against another revision must refuse to run (ttsamd/lib.py does). */
-#define TTSAMD_ABI_VERSION 5
+#define TTSAMD_ABI_VERSION 6
 int32_t ttsamd_version(void);
+/* Run-time routing options: every switch that routes between kernels / schedules that both ship (INTEGRATION.md lists them with their
+ * defaults).  An option's value is seeded ONCE from the environment variable of the same name (TTSAMD_<NAME>) when the library is first
+ * used and changed afterwards only here; `name` with or without the TTSAMD_ prefix, `value` as the variable would hold it (decimal, hex
+ * for the masks), NULL or "" = unset (the default applies).  An unknown name or a value outside the option's range returns TTSAMD_EINVAL
+ * and changes nothing.  ttsamd_get_option writes the current text ("" = unset); ttsamd_option_name(i) enumerates the names (NULL past the
+ * last); ttsamd_options_check reports a malformed TTSAMD_<NAME> found in the environment at load (ttsamd/lib.py raises on it).  No
+ * reference counterpart. */
+int32_t ttsamd_set_option(const char* name, const char* value);
+int32_t ttsamd_get_option(const char* name, char* value, int32_t capacity);
+const char* ttsamd_option_name(int32_t index);
+int32_t ttsamd_options_check(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
 int32_t ttsamd_device_ok(void);
 
@@ -255,6 +267,7 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
 /* the same with the rest of the conv engine's epilogue: y = act(conv + bias + res) | y + ... | (y + ...) / div  (mode 0 | 1 | 2); res
  * [B][Cout][lin] or NULL.  Drives the residual-preload epilogues of the direct and the Winograd F(2,3) kernel (csrc/conv_wino.hip:
  * k = 3, dilation 1 launches of at least one 128 x 128 tile per CU; TTSAMD_WINO=0 keeps the direct kernel) in the parity tests. */
+/* (relu_out != 0 is defined for mode 0 only: with an accumulate mode the call returns TTSAMD_EINVAL) */
 int32_t ttsamd_conv1d_ex(const float* x, const float* w, const float* bias, const float* res, const int64_t* lens, int32_t batch,
                          int32_t cin, int32_t cout, int32_t k, int32_t dilation, int32_t lin, float in_slope,
                          int32_t relu_out, int32_t mode, float div, float* y, float* packed, void* stream);
@@ -264,10 +277,15 @@ int32_t ttsamd_conv1d_ex(const float* x, const float* w, const float* bias, cons
  * x, y [B][C][L] (y != x), w1 / w2 [C][C][K] (torch layout, DEVICE), lens int64 [B] or NULL (valid length lens[b] * len_mul:
  * every conv pads at the true edge).  variant 1: first-generation kernel (weights through an LDS ring; C = 32, or C = 64 with
  * k = 3), 2 / 3: second generation (weights from L2 into a register queue, raw window; 256- / 128-column blocks; C = 32 / 64 /
- * 128, k = 3 / 7 / 11).  `packed` must hold 2 * C * C * K floats of scratch for the two re-laid-out weight tensors. */
+ * 128, k = 3 / 7 / 11), 4 / 5: 256-column blocks with conv 2 (4) or both convs (5) on Winograd F(2,3) (C = 32 / 64, k = 3 / 7 / 11;
+ * 5 also C = 128).  `packed` is scratch for the re-laid-out weights: ttsamd_resblock_pair_packed_floats(C, K, variant) floats (the two
+ * direct packings, + the Winograd group filters of variants 4 / 5); `packed_floats` = what the caller allocated, a smaller buffer is
+ * TTSAMD_EINVAL (nothing is written). */
+int64_t ttsamd_resblock_pair_packed_floats(int32_t channels, int32_t k, int32_t variant);
 int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
                              int32_t channels, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L,
-                             int32_t batch, int32_t mode, float div, float slope, int32_t variant, float* packed, void* stream);
+                             int32_t batch, int32_t mode, float div, float slope, int32_t variant, float* packed, int64_t packed_floats,
+                             void* stream);
 
 /* ---- bf16 octet engine (BASELINE config 3), kernel-level entries used by the parity tests and the roofline bench.
  *      Activations are [B][C/8][L][8] bf16 ("octet" layout: one 16-byte entry = 8 channels of one position = one lane's B

@@ -56,3 +56,23 @@ def synth_weights():
     assert digest(hg) == want['hifigan_seed0'], 'synthetic HiFi-GAN weights differ from the golden run'
     assert digest(fp4) == want['fastpitch_spk4_seed0']
     return {'fastpitch': fp, 'hifigan': hg, 'fastpitch_spk4': fp4}
+
+
+@pytest.fixture
+def ttsopt():
+    """Routing options of the library, set through its C ABI (ttsamd_set_option; include/ttsamd.h) and restored when the test ends:
+    ttsopt.set('TTSAMD_WINO', 0); ttsopt.set('TTSAMD_WINO', None) = back to the default."""
+    from ttsamd import lib
+
+    class _Opt:
+        def __init__(self):
+            self.old = {}
+
+        def set(self, name, value):
+            if name not in self.old:
+                self.old[name] = lib.get_option(name)
+            lib.set_option(name, value)
+    o = _Opt()
+    yield o
+    for k, v in o.old.items():
+        lib.set_option(k, v)

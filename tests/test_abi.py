@@ -50,3 +50,56 @@ def test_package_import_asks_for_one_hardware_queue_per_stream():
     assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == '8'
     env['GPU_MAX_HW_QUEUES'] = '2'
     assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == '2'
+
+
+def test_routing_options_set_get_validate():
+    """include/ttsamd.h: ttsamd_set_option / ttsamd_get_option / ttsamd_option_name -- the validated options table that replaced the per-call
+    environment reads.  Unknown names and values outside an option's range are errors and change nothing; None restores the default."""
+    import pytest
+    from ttsamd import lib
+    names = lib.option_names()
+    assert 'TTSAMD_WINO' in names and 'TTSAMD_FUSED2_MASK' in names and 'TTSAMD_WINO4' in names and len(names) == len(set(names))
+    assert lib.get_option('TTSAMD_WINO4') is None                       # unset: the documented default applies
+    lib.set_option('WINO4', 6)                                          # with or without the prefix
+    assert lib.get_option('TTSAMD_WINO4') == '6'
+    for bad in ('99', '-1', 'x', '6 '):
+        with pytest.raises(lib.TtsAmdError):
+            lib.set_option('TTSAMD_WINO4', bad)
+        assert lib.get_option('TTSAMD_WINO4') == '6'
+    lib.set_option('TTSAMD_FUSED2_MASK', '1ff')                         # hex mask
+    with pytest.raises(lib.TtsAmdError):
+        lib.set_option('TTSAMD_FUSED2_MASK', '200')
+    with pytest.raises(lib.TtsAmdError):
+        lib.set_option('TTSAMD_NO_SUCH_SWITCH', '1')
+    with lib.options(TTSAMD_WINO4=15, TTSAMD_WINO=0):
+        assert lib.get_option('WINO4') == '15' and lib.get_option('WINO') == '0'
+    assert lib.get_option('WINO4') == '6' and lib.get_option('WINO') is None
+    lib.set_option('TTSAMD_WINO4', None)
+    lib.set_option('TTSAMD_FUSED2_MASK', None)
+    assert lib.get_option('TTSAMD_WINO4') is None
+
+
+def test_options_are_seeded_from_the_environment_once_and_a_bad_value_is_loud():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from ttsamd import lib; lib.load(); print(lib.get_option('TTSAMD_WINO2'))"
+            % os.path.join(REPO, 'tts-arabic-pytorch_amd'))
+    ok = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TTSAMD_WINO2='6'), capture_output=True, text=True)
+    assert ok.returncode == 0 and ok.stdout.strip() == '6', ok.stderr[-800:]
+    bad = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TTSAMD_WINO2='banana'), capture_output=True, text=True)
+    assert bad.returncode != 0 and 'TTSAMD_WINO2' in bad.stderr
+
+
+def test_no_per_call_getenv_in_the_product_sources():
+    """Routing switches are read through the options table (api.hip: one getenv per option and process); what may still call getenv:
+    the table itself, the closed-experiment hook exp_env (common.hpp, -DTTS_EXPERIMENT builds) and the conv-log path (read once)."""
+    root = os.path.join(REPO, 'tts-arabic-pytorch_amd', 'csrc')
+    for fn in sorted(os.listdir(root)):
+        if not fn.endswith(('.hip', '.hpp')):
+            continue
+        with open(os.path.join(root, fn), encoding='utf-8') as f:
+            for ln, line in enumerate(f, 1):
+                code = line.split('//')[0]
+                if 'getenv(' in code:
+                    assert (fn, 'TTSAMD_CONV_LOG' in code or 'kOpts[i].name' in code or fn == 'common.hpp') in (
+                        ('conv_mfma.hip', True), ('api.hip', True), ('common.hpp', True)), f'{fn}:{ln}: {line.strip()}'

@@ -71,7 +71,7 @@ def _pair_ref(a, w1, b1, w2, b2, k, dil, n, sum_raw, mode, div, in_slope, out_sl
     (32, 3, 3, 2100, 1, 1.0), (32, 7, 5, 1030, 2, 0.01), (32, 11, 1, 2500, 0, 0.1),
 ])
 @pytest.mark.parametrize('small_tiles', ['0', '1'])
-def test_resblock_pair(dev, monkeypatch, C, k, dil, L, mode, out_slope, small_tiles):
+def test_resblock_pair(dev, monkeypatch, C, k, dil, L, mode, out_slope, small_tiles, ttsopt):
     """Fused c1 -> c2 pair vs the reference ops; ragged batch incl. an utterance ending inside a tile halo, one ending
     before the first tile boundary, and the untouched tail past each length."""
     from ttsamd import bfo
@@ -83,7 +83,7 @@ def test_resblock_pair(dev, monkeypatch, C, k, dil, L, mode, out_slope, small_ti
     b1, b2 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
     s_raw = torch.randn(B, C, L, generator=g)
     # both tile widths of the kernel: 256 columns per wave, or 128 (always for k = 3 at C <= 64; for small grids otherwise)
-    monkeypatch.setenv('TTSAMD_BFO_SMALL_TILES', small_tiles)
+    ttsopt.set('TTSAMD_BFO_SMALL_TILES', small_tiles)
     half = small_tiles == '1' or (k == 3 and C <= 64)
     ts = {128: 256, 64: 512, 32: 1024}[C] // (2 if half else 1) - (k - 1)                     # outputs per block (BfoPairGeo::TS)
     lens = torch.tensor([L, min(L, ts + 2), max(1, min(L, ts) - 5)], dtype=torch.int64)     # ends 2 columns into tile 1 / inside tile 0
@@ -238,7 +238,7 @@ def test_conv_post(dev):
 
 
 @pytest.mark.parametrize('T', [1, 7, 40])
-def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T):
+def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T, ttsopt):
     """The whole generator on the octet engine vs the real reference's fp32 golden (stated bf16 tolerance), and
     that the round-2 bf16 engine (TTSAMD_BFO=0) and the octet engine agree to the same tolerance."""
     import os
@@ -249,10 +249,10 @@ def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T):
     try:
         hg = HifiGanEngine(synth_weights['hifigan'], device=dev)
         wave = hg.forward(mel[None] if mel.dim() == 2 else mel).cpu().reshape(-1)
-        os.environ['TTSAMD_BFO'] = '0'
+        ttsopt.set('TTSAMD_BFO', '0')
         wave_old = hg.forward(mel[None] if mel.dim() == 2 else mel).cpu().reshape(-1)
     finally:
-        os.environ.pop('TTSAMD_BFO', None)
+        ttsopt.set('TTSAMD_BFO', None)
         set_precision('f32')
     ref = torch.from_numpy(gd['wave']).reshape(-1)
     err, err_old = float((wave - ref).abs().max()), float((wave_old - ref).abs().max())
@@ -260,7 +260,7 @@ def test_hifigan_bf16_octet_engine_golden(dev, golden, synth_weights, T):
     assert err < BF16_WAVE_TOL and err_old < BF16_WAVE_TOL
 
 
-def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch):
+def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch, ttsopt):
     """FastPitch under config 3 with the whole FFT block on the bf16 matrix cores (octet-engine qkv / o_net / conv-FF convs, LayerNorm
     that writes the octet copies, bf16 MFMA attention: 32-query tiles, the four waves of a block split the keys) against the same run
     on the round-2 bf16 conv engine with the fp32 attention kernel, and against the exact-fp32 engine: ragged batch, sequence lengths that are not
@@ -276,11 +276,11 @@ def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch
     mel32, lens32, *_ = fp.infer(ids, dur_tgt=dur)
     set_precision('bf16')
     try:
-        monkeypatch.setenv('TTSAMD_BF16_ATTN', '1')                       # the whole FFT block on the bf16 matrix cores (the default)
-        monkeypatch.setenv('TTSAMD_BFO_FF', '1')
+        ttsopt.set('TTSAMD_BF16_ATTN', '1')                       # the whole FFT block on the bf16 matrix cores (the default)
+        ttsopt.set('TTSAMD_BFO_FF', '1')
         mel_a, lens_a, *_ = fp.infer(ids, dur_tgt=dur)
-        monkeypatch.setenv('TTSAMD_BF16_ATTN', '0')                       # round-2 bf16 conv engine + the fp32 attention kernel
-        monkeypatch.setenv('TTSAMD_BFO_FF', '0')
+        ttsopt.set('TTSAMD_BF16_ATTN', '0')                       # round-2 bf16 conv engine + the fp32 attention kernel
+        ttsopt.set('TTSAMD_BFO_FF', '0')
         mel_b, lens_b, *_ = fp.infer(ids, dur_tgt=dur)
     finally:
         set_precision('f32')
@@ -296,7 +296,7 @@ def test_bf16_fft_block_matches_the_fp32_kernels(dev, synth_weights, monkeypatch
     assert worst_a < BF16_MEL_TOL and worst_ab < 4e-2
 
 
-def test_hifigan_bf16_chained_resblocks_change_no_bit(dev, synth_weights, monkeypatch):
+def test_hifigan_bf16_chained_resblocks_change_no_bit(dev, synth_weights, monkeypatch, ttsopt):
     """The generator's launch schedule is a routing choice, not a numeric one: three pair launches per ResBlock, the k = 3 ResBlocks
     chained, the k = 7 ResBlocks of the C = 32 / 64 stages chained as well (the default below 1.5 M columns) -- the same waveform bits on
     a ragged batch."""
@@ -309,11 +309,11 @@ def test_hifigan_bf16_chained_resblocks_change_no_bit(dev, synth_weights, monkey
         hg = HifiGanEngine(synth_weights['hifigan'], device=dev)
         waves = []
         for chain, chain7 in (('0', '0'), ('1', '0'), ('1', '1')):
-            monkeypatch.setenv('TTSAMD_BFO_CHAIN', chain)
-            monkeypatch.setenv('TTSAMD_BFO_CHAIN7', chain7)
+            ttsopt.set('TTSAMD_BFO_CHAIN', chain)
+            ttsopt.set('TTSAMD_BFO_CHAIN7', chain7)
             waves.append(hg.forward(mel, lens.to(dev)).cpu())
-        monkeypatch.delenv('TTSAMD_BFO_CHAIN')
-        monkeypatch.delenv('TTSAMD_BFO_CHAIN7')
+        ttsopt.set('TTSAMD_BFO_CHAIN', None)
+        ttsopt.set('TTSAMD_BFO_CHAIN7', None)
         waves.append(hg.forward(mel, lens.to(dev)).cpu())
     finally:
         set_precision('f32')
@@ -322,7 +322,7 @@ def test_hifigan_bf16_chained_resblocks_change_no_bit(dev, synth_weights, monkey
         assert torch.equal(w, waves[0])
 
 
-def test_split_k_small_batch(dev, synth_weights, monkeypatch):
+def test_split_k_small_batch(dev, synth_weights, monkeypatch, ttsopt):
     """Batch 1: the octet engine's convs split K over their C-in slabs (partial sums in fp32, summed in slice order by
     bfo_splitk_reduce: deterministic) because a batch-1 launch is a handful of blocks.  Same results as the un-split launches up to
     the fp32 summation order, run-to-run bit-identical, and inside the bf16 tolerances against the exact-fp32 engines."""
@@ -335,12 +335,12 @@ def test_split_k_small_batch(dev, synth_weights, monkeypatch):
     wave32 = hg.forward(mel32, lens32)
     set_precision('bf16')
     try:
-        monkeypatch.setenv('TTSAMD_BFO_SPLITK', '1')
+        ttsopt.set('TTSAMD_BFO_SPLITK', '1')
         mel_a, _, *_ = fp.infer(ids, dur_tgt=dur)
         wave_a = hg.forward(mel32, lens32)
         mel_a2, _, *_ = fp.infer(ids, dur_tgt=dur)
         wave_a2 = hg.forward(mel32, lens32)
-        monkeypatch.setenv('TTSAMD_BFO_SPLITK', '0')
+        ttsopt.set('TTSAMD_BFO_SPLITK', '0')
         mel_b, _, *_ = fp.infer(ids, dur_tgt=dur)
         wave_b = hg.forward(mel32, lens32)
     finally:

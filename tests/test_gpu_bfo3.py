@@ -262,7 +262,7 @@ def test_resblock_chain3_equals_three_pairs_bit_for_bit(dev, C, L, mode, out_slo
     assert torch.equal(y, ref)
 
 
-def test_hifigan_x3_chained_resblocks_change_no_bit(dev, synth_weights, monkeypatch):
+def test_hifigan_x3_chained_resblocks_change_no_bit(dev, synth_weights, monkeypatch, ttsopt):
     """The generator's launch schedule in this mode is a routing choice, not a numeric one: k = 3 ResBlocks as one launch (default)
     or as three pair launches (TTSAMD_BFO_CHAIN=0) give the same wave bit for bit on a ragged batch."""
     from ttsamd.engine import HifiGanEngine, set_precision
@@ -273,7 +273,7 @@ def test_hifigan_x3_chained_resblocks_change_no_bit(dev, synth_weights, monkeypa
     try:
         hg = HifiGanEngine(synth_weights['hifigan'], device=dev)
         wave = hg.forward(mel, lens).clone()
-        monkeypatch.setenv('TTSAMD_BFO_CHAIN', '0')
+        ttsopt.set('TTSAMD_BFO_CHAIN', '0')
         wave_p = hg.forward(mel, lens).clone()
     finally:
         set_precision('f32')

@@ -116,7 +116,7 @@ def test_config5_full_batch_every_utterance(synth_weights):
     assert worst_mel < MEL_TOL and worst_wave < WAVE_TOL
 
 
-def test_config4_full_size_tacotron2_448_steps():
+def test_config4_full_size_tacotron2_448_steps(ttsopt):
     """BASELINE config 4 at the bench's size: batch 8 x 64 tokens, 448 decoder steps (gate biased shut so every run decodes
     exactly 448 frames, prenet dropout ON with the shared hash masks), persistent decoder (the default) AND the graph path,
     against oracle/taco_oracle.py on the host.  PARITY UNPINNED (torchaudio's Tacotron2 is not in the reference tree, SURVEY
@@ -141,14 +141,14 @@ def test_config4_full_size_tacotron2_448_steps():
     # persistent dataflow decoder in ONE segment (the default: 512 steps per launch), in five segments of 96 steps (launch after launch,
     # region 0 and the per-thread state handed over: what a decoder_max_step = 3000 call does), then the hipGraph path
     for mode, seg in (('2', None), ('2', '96'), ('0', None)):
-        os.environ['TTSAMD_TACO_PERSISTENT'] = mode
+        ttsopt.set('TTSAMD_TACO_PERSISTENT', mode)
         if seg:
-            os.environ['TTSAMD_TACO_SEG'] = seg
+            ttsopt.set('TTSAMD_TACO_SEG', seg)
         try:
             mel, mel_lens, al = eng.infer(tok.to(dev), sids.to(dev), lens.to(dev), max_step=frames, dropout_seed=7)
         finally:
-            os.environ.pop('TTSAMD_TACO_PERSISTENT', None)
-            os.environ.pop('TTSAMD_TACO_SEG', None)
+            ttsopt.set('TTSAMD_TACO_PERSISTENT', None)
+            ttsopt.set('TTSAMD_TACO_SEG', None)
         assert mel.shape == (bt, 80, frames) and mel_lens.cpu().tolist() == np.asarray(lens_ref).tolist() == [frames] * bt
         em = float((mel.cpu() - mel_ref).abs().max())
         ea = float((al.cpu() - al_ref).abs().max())

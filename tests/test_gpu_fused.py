@@ -100,7 +100,7 @@ def test_resblock_pair_len_mul_and_full_batch():
 
 
 @pytest.mark.parametrize('mask,mask_n1', [('1ff', '000'), ('1ff', '1ff')])
-def test_hifigan_every_pair_on_the_second_generation_kernel_vs_oracle(synth_weights, monkeypatch, mask, mask_n1):
+def test_hifigan_every_pair_on_the_second_generation_kernel_vs_oracle(synth_weights, monkeypatch, mask, mask_n1, ttsopt):
     """The whole generator with EVERY ResBlock pair of the C = 128 / 64 / 32 stages forced onto resblock_pair2 (256-column blocks, then
     128-column blocks) against the oracle on a ragged batch whose utterances end inside a block's halo: 1-, 2- and 4-frame utterances are
     64 ... 1024 positions in those stages, 4 ... 12 columns around a block edge (blocks hold 252 / 248 / 244 resp. 124 / 120 / 116 outputs)."""
@@ -108,10 +108,10 @@ def test_hifigan_every_pair_on_the_second_generation_kernel_vs_oracle(synth_weig
     from ttsamd.config import HIFIGAN_CONFIG
     from ttsamd.engine import HifiGanEngine
     dev = torch.device('cuda:0')
-    monkeypatch.setenv('TTSAMD_FUSED_PAIR', '1')
-    monkeypatch.setenv('TTSAMD_FUSED2', '1')
-    monkeypatch.setenv('TTSAMD_FUSED2_MASK', mask)
-    monkeypatch.setenv('TTSAMD_FUSED2_MASK_N1', mask_n1)
+    ttsopt.set('TTSAMD_FUSED_PAIR', '1')
+    ttsopt.set('TTSAMD_FUSED2', '1')
+    ttsopt.set('TTSAMD_FUSED2_MASK', mask)
+    ttsopt.set('TTSAMD_FUSED2_MASK_N1', mask_n1)
     w = O.fold_weight_norm(synth_weights['hifigan'])
     rng = np.random.default_rng(11)
     lens = [19, 1, 2, 4, 8]

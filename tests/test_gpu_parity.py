@@ -159,7 +159,7 @@ def test_hifigan_ragged_batch_matches_unbatched(dev, synth_weights, hifigan_engi
 
 
 @pytest.mark.parametrize('mode,tol', [('f32', WAVE_TOL), ('bf16', 8e-3)])
-def test_hifigan_ragged_fused_kernels_vs_oracle(dev, synth_weights, monkeypatch, mode, tol):
+def test_hifigan_ragged_fused_kernels_vs_oracle(dev, synth_weights, monkeypatch, mode, tol, ttsopt):
     """The fused c1 -> c2 pair and the all-phase transposed-conv kernels, FORCED ON, against the oracle on a ragged batch
     whose utterances end inside a fused tile's halo: fp32 resblock_pair tiles hold 252 / 248 / 244 outputs at C = 32 (252 at
     C = 64, k = 3) and the stage-4 / stage-3 lengths of 1- and 2-frame utterances (256, 512 / 128, 256) fall 4..12 columns
@@ -168,9 +168,9 @@ def test_hifigan_ragged_fused_kernels_vs_oracle(dev, synth_weights, monkeypatch,
     import tts_oracle as O
     from ttsamd.config import HIFIGAN_CONFIG
     from ttsamd.engine import HifiGanEngine, set_precision
-    monkeypatch.setenv('TTSAMD_FUSED_PAIR', '1')
-    monkeypatch.setenv('TTSAMD_CONVT', '1')
-    monkeypatch.setenv('TTSAMD_BFO', '1')
+    ttsopt.set('TTSAMD_FUSED_PAIR', '1')
+    ttsopt.set('TTSAMD_CONVT', '1')
+    ttsopt.set('TTSAMD_BFO', '1')
     w = O.fold_weight_norm(synth_weights['hifigan'])
     rng = np.random.default_rng(11)
     lens = [19, 1, 2, 4, 8]
@@ -568,19 +568,19 @@ def test_full_size_bench_workload_properties(dev, synth_weights, fastpitch_engin
         assert maxabs(w[b, :256 * n], waves_ref[r]) < WAVE_TOL
 
 
-def test_hifigan_branch_streams_bit_identical(dev, hifigan_engine, monkeypatch):
+def test_hifigan_branch_streams_bit_identical(dev, hifigan_engine, monkeypatch, ttsopt):
     """Small batches run the three ResBlocks of a stage on three streams (csrc/hifigan.hip); the accumulation
     into the stage output is event-chained in the reference's order, so the waves must equal the one-stream
     result bit for bit, call after call (a missing dependency would show up as run-to-run differences)."""
     rng = np.random.default_rng(11)
     lens = torch.tensor([37, 12, 30]).to(dev)
     mel = torch.from_numpy((rng.standard_normal((3, 80, 37)) * 1.5 - 4.0).astype(np.float32)).to(dev)
-    monkeypatch.setenv('TTSAMD_HIFIGAN_STREAMS', '0')
+    ttsopt.set('TTSAMD_HIFIGAN_STREAMS', '0')
     ref = hifigan_engine.forward(mel, lens).clone()
-    monkeypatch.setenv('TTSAMD_HIFIGAN_STREAMS', '1')
+    ttsopt.set('TTSAMD_HIFIGAN_STREAMS', '1')
     for _ in range(20):
         assert torch.equal(hifigan_engine.forward(mel, lens), ref)
-    monkeypatch.delenv('TTSAMD_HIFIGAN_STREAMS')
+    ttsopt.set('TTSAMD_HIFIGAN_STREAMS', None)
     assert torch.equal(hifigan_engine.forward(mel, lens), ref)
 
 
@@ -615,7 +615,7 @@ def test_dropin_app_utils_request_flow(dev, golden, checkpoints):
     assert maxabs(peak_normalise(wave_den.cpu().reshape(-1)), outs[0].reshape(-1)) < 1e-6
 
 
-def test_bf16_packed_intermediate_bit_identical(dev, precision, hifigan_engine, monkeypatch):
+def test_bf16_packed_intermediate_bit_identical(dev, precision, hifigan_engine, monkeypatch, ttsopt):
     """bf16 mode: the c1 -> c2 intermediate of every ResBlock crosses HBM as packed bf16 (leaky-relu and RNE
     rounding done by the producer instead of the consumer's staging): same rounding point, same bits.
     Covers the small tiles (B=3) and the large ones (B=24 x 200 frames)."""
@@ -625,9 +625,9 @@ def test_bf16_packed_intermediate_bit_identical(dev, precision, hifigan_engine, 
         lens = torch.from_numpy(rng.integers(T // 2, T + 1, size=B)).to(dev)
         lens[0] = T
         mel = torch.from_numpy((rng.standard_normal((B, 80, T)) * 1.5 - 4.0).astype(np.float32)).to(dev)
-        monkeypatch.setenv('TTSAMD_BF16_PACKED_T', '0')
+        ttsopt.set('TTSAMD_BF16_PACKED_T', '0')
         ref = hifigan_engine.forward(mel, lens).clone()
-        monkeypatch.setenv('TTSAMD_BF16_PACKED_T', '1')
+        ttsopt.set('TTSAMD_BF16_PACKED_T', '1')
         out = hifigan_engine.forward(mel, lens)
         assert torch.equal(out, ref), (B, T, float((out - ref).abs().max()))
 
@@ -681,7 +681,7 @@ def test_denoiser_rejects_utterances_of_at_most_512_samples(dev, hifigan_engine)
         Denoiser.forward_batch(den, wave.clone(), ns, 0.1)
 
 
-def test_fused_pair_and_all_phase_convt_match_the_generic_engine(dev, synth_weights, hifigan_engine, monkeypatch):
+def test_fused_pair_and_all_phase_convt_match_the_generic_engine(dev, synth_weights, hifigan_engine, monkeypatch, ttsopt):
     """Round-2 kernels against the generic MFMA conv engine they replace, same weights, ragged batch with a 1-frame and a
     2-tile utterance: `resblock_pair<K, C>` (c1 -> c2 of the C = 32 stage, and of the C = 64 stage at k = 3, in one launch, intermediate in LDS, halo recompute)
     and `convt_mfma_f32` (all output phases of a transposed conv per wave).  Only the summation order differs (bias first,
@@ -689,20 +689,20 @@ def test_fused_pair_and_all_phase_convt_match_the_generic_engine(dev, synth_weig
     rng = np.random.default_rng(21)
     lens = torch.tensor([41, 1, 17, 2]).to(dev)
     mel = torch.from_numpy((rng.standard_normal((4, 80, 41)) * 1.5 - 4.0).astype(np.float32)).to(dev)
-    monkeypatch.setenv('TTSAMD_FUSED_PAIR', '0')
-    monkeypatch.setenv('TTSAMD_CONVT', '0')
+    ttsopt.set('TTSAMD_FUSED_PAIR', '0')
+    ttsopt.set('TTSAMD_CONVT', '0')
     ref = hifigan_engine.forward(mel, lens).clone()
     for fused, convt in (('1', '0'), ('0', '1'), ('1', '1')):
-        monkeypatch.setenv('TTSAMD_FUSED_PAIR', fused)
-        monkeypatch.setenv('TTSAMD_CONVT', convt)
+        ttsopt.set('TTSAMD_FUSED_PAIR', fused)
+        ttsopt.set('TTSAMD_CONVT', convt)
         out = hifigan_engine.forward(mel, lens).clone()
         assert maxabs(out, ref) < 5e-6, (fused, convt)
         assert torch.equal(hifigan_engine.forward(mel, lens), out)
         for b in range(4):
             n = 256 * int(lens[b])
             assert float(out[b, n:].abs().max()) == 0.0 if n < out.shape[1] else True
-    monkeypatch.delenv('TTSAMD_FUSED_PAIR')
-    monkeypatch.delenv('TTSAMD_CONVT')
+    ttsopt.set('TTSAMD_FUSED_PAIR', None)
+    ttsopt.set('TTSAMD_CONVT', None)
     assert torch.equal(hifigan_engine.forward(mel, lens), out)          # both are the default
 
 
@@ -751,22 +751,22 @@ def test_dropin_tts_list_pipeline_matches_the_one_stream_loop(dev, golden, check
             print(f'\n[tts list, {len(lines)} lines, batch_size {bs}] one stream {res["0"][1] * 1e3:.1f} ms, pipelined {res["1"][1] * 1e3:.1f} ms')
 
 
-def test_fastpitch_deep_splitk_tiles(dev, fastpitch_engine, monkeypatch):
+def test_fastpitch_deep_splitk_tiles(dev, fastpitch_engine, monkeypatch, ttsopt):
     """Batch 8 x 64 tokens (~450 frames each): the second conv-FF conv of the decoder (1536 -> 384) runs as 128 x 64 tiles with K
     split into slices + a reduce launch; same mel as the un-split 64 x 64 tiles up to the summation order."""
     from ttsamd import synth
     ids = torch.from_numpy(synth.synth_ids(8, 64)).to(dev)
     dur = torch.from_numpy(synth.synth_durations(8, 64)).to(dev)
-    monkeypatch.setenv('TTSAMD_DEEP_SPLITK', '0')
+    ttsopt.set('TTSAMD_DEEP_SPLITK', '0')
     mel0, dl0, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
-    monkeypatch.setenv('TTSAMD_DEEP_SPLITK', '1')
+    ttsopt.set('TTSAMD_DEEP_SPLITK', '1')
     mel1, dl1, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
     assert torch.equal(dl0, dl1) and bool(torch.isfinite(mel1).all())
     assert maxabs(mel0, mel1) < 2e-5
     assert not torch.equal(mel0, mel1)          # the other schedule did run
 
 
-def test_attention_schedules_bit_identical(dev, fastpitch_engine, monkeypatch):
+def test_attention_schedules_bit_identical(dev, fastpitch_engine, monkeypatch, ttsopt):
     """FastPitch's self-attention (transformer.py:131-141) merges one tile-local softmax per 64-key tile in tile order; which block
     does it is a schedule: 64 or 16 queries per block walking the tiles (TTSAMD_ATT_RA), or one block per (16 queries, key tile)
     plus a merge launch (the batch-1 default).  Same mel bits on a ragged batch whose decoder sequences span 1 ... 8 key tiles."""
@@ -778,8 +778,8 @@ def test_attention_schedules_bit_identical(dev, fastpitch_engine, monkeypatch):
     ids_d, dur_d = torch.from_numpy(ids).to(dev), torch.from_numpy(dur).to(dev)
     mels = []
     for ra, split in (('4', '0'), ('1', '0'), ('2', '0'), ('1', '1')):
-        monkeypatch.setenv('TTSAMD_ATT_RA', ra)
-        monkeypatch.setenv('TTSAMD_ATT_SPLIT', split)
+        ttsopt.set('TTSAMD_ATT_RA', ra)
+        ttsopt.set('TTSAMD_ATT_SPLIT', split)
         mel, lens, *_ = fastpitch_engine.infer(ids_d, dur_tgt=dur_d)
         mels.append(mel.cpu())
     assert int(lens.max()) > 128 and int(lens.min()) < 64 and bool(torch.isfinite(mels[0]).all())
@@ -788,7 +788,7 @@ def test_attention_schedules_bit_identical(dev, fastpitch_engine, monkeypatch):
 
 
 @pytest.mark.parametrize('cin,cout,k,dil,lin,B', [(256, 256, 7, 3, 3584, 16), (128, 128, 11, 5, 7168, 16), (384, 1536, 3, 1, 448, 32), (1536, 384, 3, 1, 512, 16)])
-def test_conv1d_block_order_maps_bit_identical(dev, monkeypatch, cin, cout, k, dil, lin, B):
+def test_conv1d_block_order_maps_bit_identical(dev, monkeypatch, cin, cout, k, dil, lin, B, ttsopt):
     """Which XCD runs which (time tile, co-tile) is a schedule: the tile-owning map (an XCD keeps the co-tiles of its time tiles: default), one
     co-tile class per XCD (TTSAMD_XCD_WMAX_KB=0), every co-tile on one XCD and the plain grid order (TTSAMD_XCD_W=0) give the same bits on a
     ragged batch with an empty utterance, and the float64 result within the conv tolerance."""
@@ -803,8 +803,8 @@ def test_conv1d_block_order_maps_bit_identical(dev, monkeypatch, cin, cout, k, d
     xd, wd, bd, ld = x.to(dev), w.to(dev), b.to(dev), lens.to(dev)
     ys = []
     for wmax, xw in (('3000', '1'), ('0', '1'), ('100000', '1'), ('3000', '0')):
-        monkeypatch.setenv('TTSAMD_XCD_WMAX_KB', wmax)
-        monkeypatch.setenv('TTSAMD_XCD_W', xw)
+        ttsopt.set('TTSAMD_XCD_WMAX_KB', wmax)
+        ttsopt.set('TTSAMD_XCD_W', xw)
         ys.append(conv1d(xd, wd, bd, ld, dilation=dil, in_slope=0.1).cpu())
     assert all(torch.equal(ys[0], y) for y in ys[1:])
     for i in (0, 1, 2, B - 1):

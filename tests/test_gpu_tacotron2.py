@@ -267,7 +267,7 @@ def test_inference_cli_both_models(dev, taco_ckpt, tmp_path, synth_weights):
 
 @pytest.mark.parametrize('mode', ['1', '2'])
 @pytest.mark.parametrize('num_speakers,B,L,steps,seed', [(40, 3, 23, 20, -1), (1, 8, 64, 24, 7), (40, 1, 7, 9, 0)])
-def test_tacotron2_persistent_decoder_matches_oracle(dev, monkeypatch, num_speakers, B, L, steps, seed, mode):
+def test_tacotron2_persistent_decoder_matches_oracle(dev, monkeypatch, num_speakers, B, L, steps, seed, mode, ttsopt):
     """TTSAMD_TACO_PERSISTENT=1 / 2: the whole decoder loop as one cooperative kernel (weights resident in LDS / registers,
     stop test on the device) — 1: six fence-free grid barriers per step, 2: no barriers, consumers poll the words they need
     (sentinel-filled arena) and the cells' big operands are folded in ahead — against the oracle at the same tolerances as
@@ -279,19 +279,19 @@ def test_tacotron2_persistent_decoder_matches_oracle(dev, monkeypatch, num_speak
     sids = torch.arange(B) % num_speakers if num_speakers > 1 else None
     mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=steps, seed=seed)
     eng = Tacotron2Engine(sd, cfg, device=dev)
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', mode)
     monkeypatch.setenv('TTSAMD_TACO_DEBUG', '1')
     mel, mel_lens, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)
     assert mel_lens.cpu().tolist() == np.asarray(lens_ref).tolist() == [steps] * B
     assert maxabs(al, al_ref) < ALIGN_TOL
     assert maxabs(mel, mel_ref) < MEL_TOL
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '0')
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', '0')
     mel_g, _, al_g = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)       # and against the graph path
     assert maxabs(mel, mel_g) < MEL_TOL and maxabs(al, al_g) < ALIGN_TOL
 
 
 @pytest.mark.parametrize('mode', ['1', '2'])
-def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch, mode):
+def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch, mode, ttsopt):
     """the persistent decoder's device-side stop test: utterances finish at different steps, the loop ends with the last"""
     import taco_oracle as T
     from ttsamd.engine import Tacotron2Engine
@@ -301,14 +301,14 @@ def test_tacotron2_persistent_decoder_stop_token(dev, monkeypatch, mode):
     stops = [12, 27, 5, 21]
     sd = _gate_for_stops(cfg, sd, tok, sids, lens, stops, max_step=40, seed=4)
     mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=40, seed=4)
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', mode)
     mel, mel_lens, al = Tacotron2Engine(sd, cfg, device=dev).infer(tok, sids, lens, max_step=40, dropout_seed=4)
     assert mel_lens.cpu().tolist() == stops and mel.shape == mel_ref.shape
     assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL
 
 
 @pytest.mark.parametrize('mode', ['1', '2'])
-def test_tacotron2_persistent_decoder_segments(dev, monkeypatch, mode):
+def test_tacotron2_persistent_decoder_segments(dev, monkeypatch, mode, ttsopt):
     """The persistent decoder as SEGMENTS of 8 steps, one cooperative launch each (the arena holds one segment; region 0 of a segment is
     the previous segment's last region, the per-thread cell states / cumulative attention / stop flags travel through the state buffer):
     utterances stop at steps 12 / 27 / 5 / 21 of 40, i.e. in segments 1 / 3 / 0 / 2, the loop ends inside segment 3 and the fifth
@@ -322,21 +322,21 @@ def test_tacotron2_persistent_decoder_segments(dev, monkeypatch, mode):
     sd = _gate_for_stops(cfg, sd, tok, sids, lens, stops, max_step=40, seed=4)
     mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=40, seed=4)
     eng = Tacotron2Engine(sd, cfg, device=dev)
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', mode)
     mel_one, lens_one, al_one = eng.infer(tok, sids, lens, max_step=40, dropout_seed=4)
-    monkeypatch.setenv('TTSAMD_TACO_SEG', '8')
+    ttsopt.set('TTSAMD_TACO_SEG', '8')
     mel, mel_lens, al = eng.infer(tok, sids, lens, max_step=40, dropout_seed=4)
     mel2, _, _ = eng.infer(tok, sids, lens, max_step=40, dropout_seed=4)
     assert mel_lens.cpu().tolist() == stops == lens_one.cpu().tolist() and mel.shape == mel_ref.shape
     assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL
     assert torch.equal(mel, mel_one) and torch.equal(al, al_one) and torch.equal(mel, mel2)
     # workspace: one segment of regions, not max_step + 1 (the wrapper's decoder_max_step = 3000 was 0.5-0.9 GB)
-    monkeypatch.delenv('TTSAMD_TACO_SEG')
+    ttsopt.set('TTSAMD_TACO_SEG', None)
     nb = eng.lib.ttsamd_tacotron2_workspace_bytes(eng.handle, 8, 256, 3000)
     assert nb < 150 * (1 << 20) + 8 * 512 * 3000 * 4 * 2 + 64 * (1 << 20), nb     # arena + the two postnet buffers [8][512][3000] + the rest
 
 
-def test_tacotron2_persistent_decoder_geometries(dev, monkeypatch):
+def test_tacotron2_persistent_decoder_geometries(dev, monkeypatch, ttsopt):
     """The default (persistent, dataflow) decoder against the graph path over the corners of its residency plan: the largest
     token count (256: LDS 155-159 KB per block), both memory dims, odd batch sizes, one step, and back-to-back calls of
     different shapes on one engine (the exchange arena is re-filled with the sentinel per call)."""
@@ -347,16 +347,16 @@ def test_tacotron2_persistent_decoder_geometries(dev, monkeypatch):
         for B, L, steps, seed in ((8, 256, 3, 3), (5, 100, 6, -1), (2, 33, 5, 1), (8, 256, 1, -1), (1, 1, 4, 2)):
             tok, lens = _tokens(B, L, 7 * B + L)
             sids = torch.arange(B) % num_speakers if num_speakers > 1 else None
-            monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '2')          # explicit: a geometry that did not fit or a time-out would raise
+            ttsopt.set('TTSAMD_TACO_PERSISTENT', '2')          # explicit: a geometry that did not fit or a time-out would raise
             mel, mel_lens, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)
-            monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '0')
+            ttsopt.set('TTSAMD_TACO_PERSISTENT', '0')
             mel_g, lens_g, al_g = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)
             assert mel_lens.cpu().tolist() == lens_g.cpu().tolist() == [steps] * B
             assert bool(torch.isfinite(mel).all())
             assert maxabs(mel, mel_g) < MEL_TOL and maxabs(al, al_g) < ALIGN_TOL, (num_speakers, B, L, steps)
 
 
-def test_tacotron2_persistent_explicit_request_raises_when_it_does_not_fit(dev, monkeypatch):
+def test_tacotron2_persistent_explicit_request_raises_when_it_does_not_fit(dev, monkeypatch, ttsopt):
     """TTSAMD_TACO_PERSISTENT=1 / 2 is a demand, not a hint: a geometry outside the residency plan (batch 9 > 8) must raise instead
     of silently taking the graph path (so the geometry test above really proves the persistent kernel ran); unset, the same call
     runs on the graph path and matches it."""
@@ -366,18 +366,18 @@ def test_tacotron2_persistent_explicit_request_raises_when_it_does_not_fit(dev, 
     eng = Tacotron2Engine(sd, cfg, device=dev)
     tok, lens = _tokens(9, 12, 3)
     sids = torch.arange(9) % cfg['num_speakers']
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '2')
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', '2')
     with pytest.raises(TtsAmdError, match='does not fit'):
         eng.infer(tok, sids, lens, max_step=4, dropout_seed=-1)
-    monkeypatch.delenv('TTSAMD_TACO_PERSISTENT')
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', None)
     mel, mel_lens, _ = eng.infer(tok, sids, lens, max_step=4, dropout_seed=-1)
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', '0')
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', '0')
     mel_g, _, _ = eng.infer(tok, sids, lens, max_step=4, dropout_seed=-1)
     assert mel_lens.cpu().tolist() == [4] * 9 and maxabs(mel, mel_g) == 0.0
 
 
 @pytest.mark.parametrize('mode', ['0', '2'])
-def test_tacotron2_without_early_stopping(dev, monkeypatch, mode):
+def test_tacotron2_without_early_stopping(dev, monkeypatch, mode, ttsopt):
     """decoder_early_stopping=False (tacotron2_ms.py:139,169,197): the loop runs to max_step although every utterance's gate fired;
     the output has max_step frames, the per-utterance lengths are still the stop steps.  Graph path and persistent decoder vs the oracle."""
     import taco_oracle as T
@@ -390,7 +390,7 @@ def test_tacotron2_without_early_stopping(dev, monkeypatch, mode):
     cfg = dict(cfg, decoder_early_stopping=False)
     mel_ref, lens_ref, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=20, seed=3)
     assert mel_ref.shape[2] == 20 and np.asarray(lens_ref).tolist() == stops
-    monkeypatch.setenv('TTSAMD_TACO_PERSISTENT', mode)
+    ttsopt.set('TTSAMD_TACO_PERSISTENT', mode)
     mel, mel_lens, al = Tacotron2Engine(sd, cfg, device=dev).infer(tok, sids, lens, max_step=20, dropout_seed=3)
     assert mel.shape == (3, 80, 20) and mel_lens.cpu().tolist() == stops
     assert maxabs(mel, mel_ref) < MEL_TOL and maxabs(al, al_ref) < ALIGN_TOL

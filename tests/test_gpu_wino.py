@@ -29,7 +29,7 @@ def dev():
     (128, 128, 700, 48, 0.1, False),
     (16, 128, 300, 100, 1.0, False),         # two chunks: prologue = whole ring
 ])
-def test_wino_conv_matches_float64_and_the_direct_kernel(dev, monkeypatch, cin, cout, L, B, slope, relu):
+def test_wino_conv_matches_float64_and_the_direct_kernel(dev, monkeypatch, cin, cout, L, B, slope, relu, ttsopt):
     from ttsamd.engine import conv1d
     g = torch.Generator().manual_seed(cin + cout + L)
     x = torch.randn(B, cin, L, generator=g)
@@ -39,11 +39,11 @@ def test_wino_conv_matches_float64_and_the_direct_kernel(dev, monkeypatch, cin, 
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2], lens[3] = L, L - 1 if L % 2 == 0 else L - 2, 129, 1
     lens_d = lens.to(dev)
-    monkeypatch.setenv('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
-    monkeypatch.setenv('TTSAMD_WINO2', '6')           # k = 3 on conv_wino.hip (the decomposition kernel's k = 3 is tested below)
-    monkeypatch.setenv('TTSAMD_WINO', '1')
+    ttsopt.set('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
+    ttsopt.set('TTSAMD_WINO2', '6')           # k = 3 on conv_wino.hip (the decomposition kernel's k = 3 is tested below)
+    ttsopt.set('TTSAMD_WINO', '1')
     y_w = conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens_d, in_slope=slope, relu_out=relu).cpu()
-    monkeypatch.setenv('TTSAMD_WINO', '0')
+    ttsopt.set('TTSAMD_WINO', '0')
     y_d = conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens_d, in_slope=slope, relu_out=relu).cpu()
     worst_w = worst_d = 0.0
     for i in range(B):
@@ -60,20 +60,20 @@ def test_wino_conv_matches_float64_and_the_direct_kernel(dev, monkeypatch, cin, 
     assert not torch.equal(y_w, y_d), 'TTSAMD_WINO=1 must route these shapes to the Winograd kernel'
 
 
-def test_wino_is_deterministic_and_skips_small_problems(dev, monkeypatch):
+def test_wino_is_deterministic_and_skips_small_problems(dev, monkeypatch, ttsopt):
     from ttsamd.engine import conv1d
     g = torch.Generator().manual_seed(1)
     x, w = torch.randn(8, 384, 496, generator=g), torch.randn(1536, 384, 3, generator=g) / 34.0
-    monkeypatch.setenv('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
-    monkeypatch.setenv('TTSAMD_WINO2', '6')
-    monkeypatch.setenv('TTSAMD_WINO', '1')
+    ttsopt.set('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
+    ttsopt.set('TTSAMD_WINO2', '6')
+    ttsopt.set('TTSAMD_WINO', '1')
     a, b2 = conv1d(x.to(dev), w.to(dev)), conv1d(x.to(dev), w.to(dev))
     assert torch.equal(a, b2)
     # short sequences (the 64-token encoder) and grids under one block per CU keep the direct kernel: same bits either way
     xs = torch.randn(4, 384, 64, generator=g)
-    monkeypatch.setenv('TTSAMD_WINO', '0')
+    ttsopt.set('TTSAMD_WINO', '0')
     d = conv1d(xs.to(dev), w.to(dev))
-    monkeypatch.setenv('TTSAMD_WINO', '1')
+    ttsopt.set('TTSAMD_WINO', '1')
     assert torch.equal(conv1d(xs.to(dev), w.to(dev)), d)
     # rows that are not float4-aligned (L % 4 != 0), a slope outside [0, 1] (the kernels activate with max(x, slope x)) and a kernel size
     # without a decomposition keep the direct kernel too: same bits with the switch on and off
@@ -82,13 +82,13 @@ def test_wino_is_deterministic_and_skips_small_problems(dev, monkeypatch):
     for args, kw in (((xo, w), {}), ((x, w), {'in_slope': 1.5}), ((x, w5), {})):
         outs = []
         for flag in ('0', '1'):
-            monkeypatch.setenv('TTSAMD_WINO', flag)
+            ttsopt.set('TTSAMD_WINO', flag)
             outs.append(conv1d(args[0].to(dev), args[1].to(dev), **kw))
         assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize('cin,cout,L,B,mode', [(1536, 384, 496, 24, 0), (256, 256, 1032, 16, 1), (256, 256, 520, 40, 2)])
-def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout, L, B, mode):
+def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout, L, B, mode, ttsopt):
     """The epilogue that FastPitch's second conv-FF conv (conv + residual, transformer.py:83-86) and the c2 convs of HiFi-GAN's
     ResBlocks (x + conv, summed over the three branches and divided, vocoder/hifigan/models.py:46-53,116-122) use: the residual -- and
     in the accumulate modes the previous y -- enters through the accumulators (res[2j] -> M0, -res[2j + 1] -> M3).  Ragged, odd
@@ -103,10 +103,10 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2] = L, L - 1, 131
     outs = {}
-    monkeypatch.setenv('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
-    monkeypatch.setenv('TTSAMD_WINO2', '6')
+    ttsopt.set('TTSAMD_WINO4', '0')           # these cases pin the F(2,3) kernels
+    ttsopt.set('TTSAMD_WINO2', '6')
     for flag in ('1', '0'):
-        monkeypatch.setenv('TTSAMD_WINO', flag)
+        ttsopt.set('TTSAMD_WINO', flag)
         y = y0.clone().to(dev)
         conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), in_slope=0.1, res=res.to(dev), mode=mode, div=3.0, y=y)
         outs[flag] = y.cpu()
@@ -134,7 +134,7 @@ def test_wino_residual_preload_and_accumulate_modes(dev, monkeypatch, cin, cout,
     (11, 1, 64, 64, 4100, 12, None), (11, 3, 64, 64, 4100, 12, 1), (11, 5, 64, 64, 4100, 12, 2), (11, 1, 128, 64, 4100, 12, 0),
 ])
 @pytest.mark.parametrize('scheme', ['f23', 'f43'])
-def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, mode, scheme):
+def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, mode, scheme, ttsopt):
     """scheme f43 = conv_wino4.hip: the same filters as F(4,3) sub-filters -- 6 / 16 / 23 products per output QUAD (q, q + d, q + 2 d, q + 3 d),
     64 rows x 64 quads per block, k = 11 in two phases of 12 / 11 groups, the single tap of k = 7 through two extra planes; tiles of 256 /
     252 / 240 outputs at dilation 1 / 3 / 5.  Same float64 checker, same ragged odd lengths and epilogues; F(2,3) and F(4,3) must differ
@@ -152,10 +152,10 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, m
     lens = torch.randint(1, L + 1, (B,), generator=g)
     lens[0], lens[1], lens[2], lens[3] = L, L - 1, 131, 1
     outs = {}
-    monkeypatch.setenv('TTSAMD_WINO2', '31')
-    monkeypatch.setenv('TTSAMD_WINO4', '15' if scheme == 'f43' else '0')
+    ttsopt.set('TTSAMD_WINO2', '31')
+    ttsopt.set('TTSAMD_WINO4', '15' if scheme == 'f43' else '0')
     for flag in ('1', '0'):
-        monkeypatch.setenv('TTSAMD_WINO', flag)
+        ttsopt.set('TTSAMD_WINO', flag)
         y = y0.clone().to(dev)
         conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), dilation=d, in_slope=0.1, res=None if res is None else res.to(dev),
                mode=mode or 0, div=3.0, y=y)
@@ -174,8 +174,8 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, m
     assert worst["1"] < 5e-5 and worst["0"] < 5e-5
     assert not torch.equal(outs['1'], outs['0'])
     if scheme == 'f43':                                   # ... and it is not the F(2,3) kernel that ran
-        monkeypatch.setenv('TTSAMD_WINO4', '0')
-        monkeypatch.setenv('TTSAMD_WINO', '1')
+        ttsopt.set('TTSAMD_WINO4', '0')
+        ttsopt.set('TTSAMD_WINO', '1')
         y = y0.clone().to(dev)
         conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), dilation=d, in_slope=0.1, res=None if res is None else res.to(dev),
                mode=mode or 0, div=3.0, y=y)

@@ -53,14 +53,15 @@ def main():
         w2 = (torch.randn(c, c, k, generator=g) / np.sqrt(c * k)).to(dev)
         b1, b2 = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
         lens = torch.from_numpy(frames).to(dev)
-        packed = torch.empty(2 * c * c * k, dtype=torch.float32, device=dev)
+        n_packed = max(int(lib.ttsamd_resblock_pair_packed_floats(c, k, v)) for v in variants + [2])
+        packed = torch.empty(n_packed, dtype=torch.float32, device=dev)
         flops = 2 * 2.0 * c * c * k * float(frames.sum()) * mul
         row = f'C={c:3d} k={k:2d} d={d}:'
         pack_us = 0.0
         for v in [-1] + variants:
             def run():
                 return lib.ttsamd_resblock_pair(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), c, k, d, _ptr(lens), mul, Lx,
-                                                args.batch, 0, C.c_float(1.0), C.c_float(0.1), v, _ptr(packed), _stream())
+                                                args.batch, 0, C.c_float(1.0), C.c_float(0.1), v, _ptr(packed), n_packed, _stream())
             if run() != 0:
                 row += f'   v{v}: n/a'
                 continue

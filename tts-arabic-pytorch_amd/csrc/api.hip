@@ -1,8 +1,13 @@
 // extern "C" surface of libttsamd.so (include/ttsamd.h): argument checks, error strings,
 // the launch-timing hooks used by bench.py, and thin forwards into the model code.
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "kernels.hpp"
@@ -141,6 +146,56 @@ __global__ void split_bf16_kernel(const float* __restrict__ packed, int64_t n, u
     out[n + i] = (unsigned short)(v >> 16);
 }
 
+// ---- run-time routing options (common.hpp: TTS_OPTIONS) --------------------------------------------------------------------------------
+namespace {
+struct OptDesc { const char* name; int kind; long long lo, hi; };
+const OptDesc kOpts[OPT_COUNT] = {
+#define TTS_OPT_DESC(name, kind, lo, hi) {"TTSAMD_" #name, kind, lo, hi},
+    TTS_OPTIONS(TTS_OPT_DESC)
+#undef TTS_OPT_DESC
+};
+std::atomic<const char*> g_opt[OPT_COUNT];       // interned strings, never freed (a few bytes per ttsamd_set_option call)
+std::once_flag g_opt_once;
+std::string g_opt_env_error;                     // first malformed TTSAMD_<NAME> of the environment (ttsamd_options_check)
+
+bool opt_valid(const OptDesc& d, const char* v) {
+    if (!v || !*v) return false;
+    char* end = nullptr;
+    errno = 0;
+    const long long x = std::strtoll(v, &end, d.kind == 1 ? 16 : 10);
+    return errno == 0 && end != v && *end == '\0' && x >= d.lo && x <= d.hi;
+}
+void opt_init() {
+    std::call_once(g_opt_once, [] {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            const char* e = std::getenv(kOpts[i].name);        // the ONE getenv per option and process
+            if (!e || !*e) continue;
+            if (!opt_valid(kOpts[i], e)) {
+                if (g_opt_env_error.empty()) {
+                    char buf[256];
+                    std::snprintf(buf, sizeof buf, "%s='%s' in the environment is not a valid value (%s in [%llx, %llx])", kOpts[i].name, e,
+                                  kOpts[i].kind == 1 ? "hex mask" : "integer", kOpts[i].lo, kOpts[i].hi);
+                    g_opt_env_error = buf;
+                }
+                continue;
+            }
+            g_opt[i].store(strdup(e), std::memory_order_release);
+        }
+    });
+}
+int opt_find(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (std::strcmp(name, kOpts[i].name) == 0 || std::strcmp(name, kOpts[i].name + 7) == 0) return i;
+    return -1;
+}
+}  // namespace
+
+const char* opt_str(Opt o) {
+    opt_init();
+    return g_opt[o].load(std::memory_order_acquire);
+}
+
 }  // namespace ttsamd
 
 using namespace ttsamd;
@@ -149,6 +204,34 @@ extern "C" {
 
 const char* ttsamd_last_error(void) { return g_err.c_str(); }
 int32_t ttsamd_version(void) { return TTSAMD_ABI_VERSION; }
+
+int32_t ttsamd_set_option(const char* name, const char* value) {
+    opt_init();
+    const int i = opt_find(name);
+    TTS_REQUIRE(i >= 0, "set_option: unknown option '%s' (ttsamd_option_name lists them)", name ? name : "(null)");
+    if (!value || !*value) {
+        g_opt[i].store(nullptr, std::memory_order_release);
+        return 0;
+    }
+    TTS_REQUIRE(opt_valid(kOpts[i], value), "set_option: %s='%s' is not a valid value (%s in [%llx, %llx])", kOpts[i].name, value,
+                kOpts[i].kind == 1 ? "hex mask" : "integer", kOpts[i].lo, kOpts[i].hi);
+    g_opt[i].store(strdup(value), std::memory_order_release);
+    return 0;
+}
+int32_t ttsamd_get_option(const char* name, char* value, int32_t capacity) {
+    opt_init();
+    const int i = opt_find(name);
+    TTS_REQUIRE(i >= 0 && value && capacity > 0, "get_option: unknown option '%s' or no buffer", name ? name : "(null)");
+    const char* v = g_opt[i].load(std::memory_order_acquire);
+    std::snprintf(value, (size_t)capacity, "%s", v ? v : "");
+    return 0;
+}
+const char* ttsamd_option_name(int32_t index) { return (index >= 0 && index < OPT_COUNT) ? kOpts[index].name : nullptr; }
+int32_t ttsamd_options_check(void) {
+    opt_init();
+    TTS_REQUIRE(g_opt_env_error.empty(), "%s", g_opt_env_error.c_str());
+    return 0;
+}
 
 int32_t ttsamd_device_ok(void) {
     int n = 0;
@@ -382,6 +465,8 @@ int32_t ttsamd_conv1d_ex(const float* x, const float* w, const float* bias, cons
                          int32_t relu_out, int32_t mode, float div, float* y, float* packed, void* stream) {
     TTS_REQUIRE(x && w && y && packed, "conv1d: null argument");
     TTS_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || div != 0.f), "conv1d: bad mode / div");
+    // the residual-preload epilogues apply the activation to y_prev + res + conv + b: only mode 0 has the documented meaning with relu_out
+    TTS_REQUIRE(relu_out == 0 || mode == 0, "conv1d: relu_out with an accumulate mode (mode %d) is not defined", mode);
     hipStream_t s = (hipStream_t)stream;
     const int cp = cout_padded(cout);
     const int64_t n = (int64_t)cin * k * cp;
@@ -429,11 +514,23 @@ int32_t ttsamd_conv1d(const float* x, const float* w, const float* bias, const i
     return ttsamd_conv1d_ex(x, w, bias, nullptr, lens, batch, cin, cout, k, dilation, lin, in_slope, relu_out, 0, 1.f, y, packed, stream);
 }
 
+int64_t ttsamd_resblock_pair_packed_floats(int32_t channels, int32_t k, int32_t variant) {
+    // the two direct packings + (variant 4: conv 2, variant 5: both convs) as Winograd F(2,3) groups
+    if (channels < 1 || k < 1) return 0;
+    const int64_t n = 2 * (int64_t)channels * k * channels;
+    const int nwino = (variant == 4 ? 1 : (variant == 5 ? 2 : 0));
+    return n + ((k == 3 || k == 7 || k == 11) ? nwino * (int64_t)channels * wino2_groups(k) * channels : 0);
+}
+
 int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
                              int32_t channels, int32_t k, int32_t dil, const int64_t* lens, int32_t len_mul, int32_t L,
-                             int32_t batch, int32_t mode, float div, float slope, int32_t variant, float* packed, void* stream) {
+                             int32_t batch, int32_t mode, float div, float slope, int32_t variant, float* packed, int64_t packed_floats,
+                             void* stream) {
     TTS_REQUIRE(x && y && w1 && b1 && w2 && b2 && packed && channels % 32 == 0 && k >= 1 && batch >= 1 && L >= 1 && len_mul >= 1 &&
                 mode >= 0 && mode <= 2, "resblock_pair: bad argument");
+    TTS_REQUIRE(packed_floats >= ttsamd_resblock_pair_packed_floats(channels, k, variant),
+                "resblock_pair: `packed` holds %lld floats, variant %d at C = %d, k = %d needs %lld (ttsamd_resblock_pair_packed_floats)",
+                (long long)packed_floats, variant, channels, k, (long long)ttsamd_resblock_pair_packed_floats(channels, k, variant));
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)channels * k * channels;
     for (int i = 0; i < 2; ++i) {
@@ -465,7 +562,7 @@ int32_t ttsamd_resblock_pair(const float* x, float* y, const float* w1, const fl
     } else if (variant == -1) {
         rc = 0;                                    // the two weight re-layout launches only (tools/fused_pair_bench.py subtracts them)
     } else {
-        set_error("resblock_pair: variant %d (1: first generation, 2 / 3: second generation with 256- / 128-column blocks, 4 / 5: 256 columns + Winograd phase B / both phases; `packed` then holds 2 C C k + 2 C NG C floats)", variant);
+        set_error("resblock_pair: variant %d (1: first generation, 2 / 3: second generation with 256- / 128-column blocks, 4 / 5: 256 columns + Winograd phase B / both phases)", variant);
         rc = TTSAMD_EINVAL;
     }
     prof_end(s);

@@ -244,10 +244,10 @@ bool bfo_chain_supported(int32_t channels, int32_t k, const int32_t* dil, int32_
 
 // ... and what the generator routes to it (the switches are read per call, like the other schedule switches: tests and A/B runs flip them)
 bool bfo_chain_wanted(int32_t channels, int32_t k, const int32_t* dil, int32_t n_pairs, int32_t L, int32_t batch) {
-    const char* ce = getenv("TTSAMD_BFO_CHAIN");
+    const char* ce = opt_str(OPT_BFO_CHAIN);
     if (ce && ce[0] == '0') return false;
     if (k == 7) {
-        const char* c7 = getenv("TTSAMD_BFO_CHAIN7");           // 0 / 1 force it; default: small batches only
+        const char* c7 = opt_str(OPT_BFO_CHAIN7);           // 0 / 1 force it; default: small batches only
         const bool on7 = c7 ? c7[0] != '0' : (int64_t)batch * L <= kBfoChain7MaxColumns;
         if (!on7) return false;
     }

@@ -247,7 +247,7 @@ static int32_t bfo_launch_conv_cfg(const BfoConvParams& p_in, hipStream_t stream
     const int64_t blocks = (int64_t)grid.x * grid.y * grid.z;
     const int n_slabs = ((p.Cin + 15) / 16 + G::SH - 1) / G::SH;
     const int64_t per = (int64_t)p.batch * p.Cout * p.Lin;
-    const char* ske = getenv("TTSAMD_BFO_SPLITK");              // 0 disables (A/B and parity runs)
+    const char* ske = opt_str(OPT_BFO_SPLITK);              // 0 disables (A/B and parity runs)
     const char* mse = exp_env("TTSAMD_BFO_SPLITK_MIN_SLABS");
     const int min_slabs = mse ? atoi(mse) : 4;
     const char* mbe = exp_env("TTSAMD_BFO_SPLITK_BLOCKS");

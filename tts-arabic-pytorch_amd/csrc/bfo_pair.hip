@@ -239,7 +239,7 @@ static int32_t bfo_launch_pair_k(const BfoPairParams& p, hipStream_t stream) {
         // fewer than 1.5 blocks per CU with 256-column tiles: halve them (TTSAMD_BFO_SMALL_TILES=0/1 forces either)
         using G8 = BfoPairGeo<K, C, 8>;
         const int64_t blocks8 = (int64_t)((p.L + G8::TS - 1) / G8::TS) * p.batch;
-        const char* e = getenv("TTSAMD_BFO_SMALL_TILES");
+        const char* e = opt_str(OPT_BFO_SMALL_TILES);
         const bool small = e ? e[0] == '1' : blocks8 < 384;
         if (small) return bfo_launch_pair_nt<K, C, 4>(p, stream);
     }

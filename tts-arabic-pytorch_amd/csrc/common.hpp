@@ -65,6 +65,47 @@ inline hipError_t lds_opt_in(const void* fn, int bytes, std::atomic<uint64_t>& d
     return e;
 }
 
+// ---- run-time routing options (include/ttsamd.h: ttsamd_set_option / ttsamd_get_option) -----------------------------------------------
+// Every switch that routes between kernels / schedules that BOTH ship.  One table (api.hip): the value is seeded ONCE from the
+// environment variable TTSAMD_<NAME> when the library is first used, validated (a malformed value is an error of ttsamd_options_check and
+// of every ttsamd_set_option call, never silently ignored), and changed afterwards only through ttsamd_set_option -- product code never calls
+// getenv on a hot path (a forward used to make several hundred getenv calls, each racing with a concurrent setenv of the host).
+// X(name, kind, lo, hi): kind 0 = decimal integer in [lo, hi], 1 = hex mask <= hi.
+#define TTS_OPTIONS(X)                                                                                     \
+    X(HIFIGAN_STREAMS, 0, 0, 1)   /* ResBlock branches of a HiFi-GAN stage on one / three streams (default: by size) */ \
+    X(WINO, 0, 0, 1)              /* fp32 engine: 0 = direct kernels only */                                \
+    X(WINO2, 0, 0, 31)            /* F(2,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated, 4 = Cout 64 */ \
+    X(WINO4, 0, 0, 15)            /* F(4,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated (default 14) */ \
+    X(FUSED_PAIR, 0, 0, 1)        /* fp32 fused c1 -> c2 pairs: 0 = every pair as two launches */           \
+    X(FUSED2, 0, 0, 1)            /* second-generation fused pair off / on */                               \
+    X(FUSED2_MASK, 1, 0, 0x1ff)   /* which (C, k) pairs it takes: bit 3 ci + ki (default 04f) */            \
+    X(FUSED2_MASK_N1, 1, 0, 0x1ff) /* ... with 128-column direct-arithmetic blocks (default 000) */         \
+    X(FUSED2_WB, 0, 0, 2)         /* its Winograd phases: 0 none, 1 phase B, 2 both (default) */            \
+    X(CONVT, 0, 0, 1)             /* all-phase transposed conv (convt_mfma.hip) off / on */                 \
+    X(BFO, 0, 0, 1)               /* bf16 modes: 0 = the round-2 bf16 conv engine instead of the octet engine */ \
+    X(BFO_CHAIN, 0, 0, 1)         /* whole k = 3 ResBlock in one launch (octet engines) */                  \
+    X(BFO_CHAIN7, 0, 0, 1)        /* ... and k = 7 (default: small batches only) */                         \
+    X(BFO_FF, 0, 0, 1)            /* FastPitch conv-FF / predictors on the octet engine */                  \
+    X(BFO_SPLITK, 0, 0, 1)        /* split-K of the octet slab conv */                                      \
+    X(BFO_SMALL_TILES, 0, 0, 1)   /* 128-column tiles of the bf16 pair (default: by block count) */         \
+    X(BF16_ATTN, 0, 0, 1)         /* bf16 MFMA attention in the bf16 mode */                                \
+    X(BF16_PACKED_T, 0, 0, 1)     /* round-2 bf16 engine: packed bf16 c1 -> c2 intermediate */              \
+    X(ATT_RA, 0, 1, 4)            /* fp32 attention: 16 * RA queries per block (1, 2, 4) */                 \
+    X(ATT_SPLIT, 0, 0, 1)         /* ... one block per (16 queries, key tile) + merge launch */             \
+    X(XCD_W, 0, 0, 1)             /* XCD-aware block -> tile map of the direct conv kernel */               \
+    X(XCD_WMAX_KB, 0, 0, 1 << 20) /* ... weight footprint per XCD that keeps co-tile classes together */    \
+    X(DEEP_SPLITK, 0, 0, 1)       /* 128 x 64 tiles with split K for the deep conv-FF conv at batch 7..13 */ \
+    X(TACO_PERSISTENT, 0, 0, 2)   /* Tacotron2 decoder: 0 graph replay, 1 grid-barrier kernel, 2 dataflow kernel */ \
+    X(TACO_SEG, 0, 8, 1 << 20)    /* ... decoder steps per persistent launch (default 512) */
+enum Opt : int {
+#define TTS_OPT_ENUM(name, kind, lo, hi) OPT_##name,
+    TTS_OPTIONS(TTS_OPT_ENUM)
+#undef TTS_OPT_ENUM
+    OPT_COUNT
+};
+// current value as text (what the environment variable would hold), nullptr = unset (the documented default applies)
+const char* opt_str(Opt o);
+
 // Bump allocator over the caller-provided workspace (no hidden hipMalloc on hot calls).
 struct Arena {
     char* base;

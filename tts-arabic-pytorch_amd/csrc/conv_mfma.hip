@@ -702,7 +702,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     if (q.tile_major) std::swap(grid.x, grid.z);
     q.compact = (!q.tile_major && compact_order(p.lens_out, p.batch)) ? 1 : 0;
     {
-        const char* xe = getenv("TTSAMD_XCD_W");                    // read per call, like the other schedule switches
+        const char* xe = opt_str(OPT_XCD_W);                    // read per call, like the other schedule switches
         const bool xw = !(xe && xe[0] == '0');
         const unsigned nct = grid.y;
         const unsigned g = (nct % 8 == 0) ? 8 : (nct % 4 == 0 ? 4 : (nct % 2 == 0 ? 2 : 1));
@@ -711,7 +711,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         // an XCD owns whole time tiles: the co-tiles of its class are consecutive slots and share the input window through its L2.  As few
         // classes (g2 <= g) as keep a class's weights under TTSAMD_XCD_WMAX_KB (0 = the plain map above); with more co-tiles than classes
         // (FastPitch's 384 -> 1536 conv: 12 co-tiles in 4 classes; 1536 -> 384: 3 in 1) the same g already saves the re-reads
-        const char* we = getenv("TTSAMD_XCD_WMAX_KB");
+        const char* we = opt_str(OPT_XCD_WMAX_KB);
         const int64_t wmax = (we ? (int64_t)atoi(we) : (int64_t)kXcdWeightKB) * 1024;
         if (can && wmax > 0 && nct > 1) {
             const int64_t wbytes = (int64_t)p.CoutP * p.Cin * K * 4;
@@ -807,7 +807,7 @@ static int32_t launch_k(const ConvParams& p, hipStream_t stream) {
         // (launch_cfg: < 320 tiles -> 2..4 slices) instead of twice as many 64 x 64 tiles that each walk all 96 chunks
         if (p.splitk_ws && p.Cin >= 1024 && !tiny && blocks(128, 64) >= 160 && blocks(128, 64) < 320 &&
             (int64_t)2 * p.batch * p.Cout * p.Nout <= p.splitk_floats) {
-            const char* e = getenv("TTSAMD_DEEP_SPLITK");                    // read per launch of this (rare) shape: the tests flip it
+            const char* e = opt_str(OPT_DEEP_SPLITK);                    // read per launch of this (rare) shape: the tests flip it
             if (!(e && e[0] == '0')) return launch_cfg<K, 1, 2, 4, 1>(p, stream);
         }
         if (blocks(128, 64) >= want || (tiny && blocks(64, 64) < 2 * want)) return launch_cfg<K, 1, 2, 4, 1>(p, stream);   // 128 co x 64 t

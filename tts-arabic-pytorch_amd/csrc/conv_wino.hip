@@ -408,14 +408,14 @@ static int32_t launch_wino_epi(const ConvParams& q, dim3 grid, hipStream_t strea
 //                        68.5 with k = 7 + 11, 67.5 with the three, 65.6 with dilations, 64.6-65.1 with Cout = 64)
 int wino_route(const ConvParams& p) {
     if ((p.w_wino == nullptr && p.w_wino4 == nullptr) || p.precision != 0 || (p.K != 3 && p.K != 7 && p.K != 11)) return 0;
-    const char* e = getenv("TTSAMD_WINO");
+    const char* e = opt_str(OPT_WINO);
     if (e && e[0] == '0') return 0;
     if (p.w_wino4 != nullptr) {
         // F(4,3) decomposition (conv_wino4.hip): TTSAMD_WINO4=<mask>, bit 0 / 1 / 2 = k 3 / 7 / 11, bit 3 = their dilated convs; default 14
         // (k = 3 stays on F(2,3): 6 instead of 8 products per quad do not pay for the 32-row wave tiles -- 414 / 330 vs 392 / 315 us on
         // FastPitch's conv-FF pair, 319 vs 308 us at C = 256).
         // 64 rows x 64 quads per block, float4-aligned rows, at least 192 blocks (below: the F(2,3) / direct routing that follows)
-        const char* e4 = getenv("TTSAMD_WINO4");
+        const char* e4 = opt_str(OPT_WINO4);
         const int mask4 = e4 ? atoi(e4) : 14;
         const int kbit4 = p.K == 3 ? 1 : (p.K == 7 ? 2 : 4);
         const bool ok4 = (mask4 & kbit4) && (p.dil == 1 || (mask4 & 8)) && (p.K != 3 || p.Cin % 16 == 0) &&
@@ -431,7 +431,7 @@ int wino_route(const ConvParams& p) {
         }
         if (p.w_wino == nullptr) return 0;
     }
-    const char* e2 = getenv("TTSAMD_WINO2");
+    const char* e2 = opt_str(OPT_WINO2);
     const int mask = e2 ? atoi(e2) : 31;
     const int kbit = p.K == 3 ? 1 : (p.K == 7 ? 2 : 4);
     const bool rows64 = p.CoutP % 128 != 0;

@@ -503,17 +503,17 @@ int32_t launch_attention(const float* qkv, const int64_t* lens, int32_t B, int32
     TTS_REQUIRE(D == ATT_D, "attention: d_head=%d, only %d is built", D, ATT_D);
     if (S <= 0 || B <= 0) return 0;
     if (default_precision() == 1) {                              // config 3: bf16 MFMA attention (TTSAMD_BF16_ATTN=0: the fp32 kernel)
-        const char* e = getenv("TTSAMD_BF16_ATTN");
+        const char* e = opt_str(OPT_BF16_ATTN);
         if (!(e && e[0] == '0')) return launch_attention_bf16(qkv, lens, B, D, S, scale, out, s);
     }
     // 64 queries per block once that gives every CU a block (batch 32 x 450 frames: 78.14 -> 77.95 ms per step), 16 otherwise
     // (batch 1 / 8: 4.60 / 21.94 ms against 4.80 / 22.14); TTSAMD_ATT_RA=1/2/4 forces the tile
-    const char* rae = getenv("TTSAMD_ATT_RA");
+    const char* rae = opt_str(OPT_ATT_RA);
     const int ra = rae ? atoi(rae) : ((int64_t)((S + 63) / 64) * B >= 256 ? 4 : 1);
     // fewer than half a block per CU and several key tiles: one block per (16 queries, key tile) + the merge launch (same bits);
     // TTSAMD_ATT_SPLIT=0/1 forces either
     const int qb = (S + 15) / 16, nt = (S + 63) / 64;
-    const char* spe = getenv("TTSAMD_ATT_SPLIT");
+    const char* spe = opt_str(OPT_ATT_SPLIT);
     const bool fits = ws != nullptr && (int64_t)B * qb * nt * 16 * ATT_PS <= ws_floats;
     const bool split = fits && nt >= 2 && (spe ? spe[0] == '1' : (ra == 1 && (int64_t)qb * B < 128));
     if (split) {

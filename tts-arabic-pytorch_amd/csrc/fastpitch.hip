@@ -291,7 +291,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
                        const int64_t* lens, int B, int S, const FftWs& w, hipStream_t s) {
     const int d = h->cfg.d_model;
     const float scale = 1.0f / std::sqrt((float)d_head);
-    const char* ffe = std::getenv("TTSAMD_BFO_FF");              // read per call: the tests and A/B runs flip it
+    const char* ffe = opt_str(OPT_BFO_FF);              // read per call: the tests and A/B runs flip it
     bool octet = default_precision() == 1 && !(ffe && ffe[0] == '0') && d % 64 == 0 && d <= 512 && d_head == 64;
     for (const FftLayer& l : layers)
         octet = octet && l.ff0.wo_off >= 0 && l.ff2.wo_off >= 0 && l.qkv.wo_off >= 0 && l.o_net.wo_off >= 0 && l.qkv.cout == 3 * d_head;
@@ -396,7 +396,7 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
     {
         // config 3: Conv1d + ReLU -> LayerNorm chain on the bf16 octet engine (input packed once, masked on load; LayerNorm writes the
         // next conv's octet copy).  The octet tensors sit behind the fp32 buffers' used part: t0 / t1 are sized for the widest filter.
-        const char* ffe = std::getenv("TTSAMD_BFO_FF");
+        const char* ffe = opt_str(OPT_BFO_FF);
         bool octet = default_precision() == 1 && !(ffe && ffe[0] == '0') && pr.convs.size() == 2 && pr.filter % 64 == 0 && pr.filter <= 512 &&
                      pr.convs[0].cin % 8 == 0 && pr.convs[0].cin <= pr.filter * 2;
         for (const PConv& c : pr.convs) octet = octet && c.wo_off >= 0;
@@ -430,7 +430,7 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
     {
         // split bf16: the same chain on the x3 kernels.  The x3 tensors are as large as the fp32 ones: the packed input ([B][cin][S] x 4
         // bytes, cin <= 2 filter would not fit) and the copy of the first LayerNorm's output both go to `px3`
-        const char* ffe = std::getenv("TTSAMD_BFO_FF");
+        const char* ffe = opt_str(OPT_BFO_FF);
         bool x3 = default_precision() == 2 && !(ffe && ffe[0] == '0') && pr.convs.size() == 2 && (pr.filter == 256 || pr.filter == 384 || pr.filter == 512) &&
                   pr.convs[0].cin % 8 == 0 && pr.convs[0].cin <= pr.filter * 2 && px3 != nullptr;
         for (const PConv& c : pr.convs) x3 = x3 && c.wo3_off >= 0;

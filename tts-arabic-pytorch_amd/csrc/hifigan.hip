@@ -16,10 +16,11 @@
 namespace ttsamd {
 
 // default routing of the second-generation fused pair (fused2_choice below), set from same-box A/B runs of the bench workload
-constexpr unsigned kFused2Mask = 0x07F;       // C = 32 and C = 64: k = 3 / 7 / 11; C = 128: k = 3.  Both convs of these pairs run on Winograd F(2,3) inside the
-                                              // launch (resblock_pair2<..., WM = 2>; C = 128: the 8-wave block).  Same-box A/B (tools/ab_env.sh): C = 64
-                                              // k = 11 fused 61.93 vs 62.45 ms per step; C = 128 k = 3 fused 63.90 vs 64.06 (its un-fused k = 3 launches sit
-                                              // at both roofs), + k = 7 64.23, + k = 11 65.36 (MFMA-bound either way: the halo recompute costs more)
+constexpr unsigned kFused2Mask = 0x04F;       // C = 32: k = 3 / 7 / 11; C = 64 and C = 128: k = 3.  Both convs of these pairs run on Winograd F(2,3) inside the
+                                              // launch (resblock_pair2<..., WM = 2>; C = 128: the 8-wave block).  Round 6: the k = 7 / 11 pairs of C = 64 run
+                                              // un-fused on the F(4,3) kernel (conv_wino4.hip, 64-row blocks = its native tile): same-box A/B 56.72 (07f) /
+                                              // 56.15 (06f: k = 7 un-fused) / 55.00 (05f: k = 11) / 54.81 ms (04f).  Round 5 on F(2,3): C = 64 k = 11 fused
+                                              // 61.93 vs 62.45; C = 128 k = 3 fused 63.90 vs 64.06, + k = 7 64.23, + k = 11 65.36
 constexpr unsigned kFused2MaskN1 = 0x000;     // 128-column blocks (the direct-arithmetic kernels only): none by default
 constexpr int64_t kFused2SmallColumns = 2 * 256 * 252;   // batch x positions under which a stage counts as a small problem
 
@@ -60,13 +61,13 @@ struct HifiGan {
 // TTSAMD_HIFIGAN_STREAMS=0/1 forces either schedule.
 static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
     if (h->cfg.n_kernels != 3) return false;
-    const char* env = std::getenv("TTSAMD_HIFIGAN_STREAMS");   // read per call: the tests flip it
+    const char* env = opt_str(OPT_HIFIGAN_STREAMS);   // read per call: the tests flip it
     if (env) return env[0] == '1';
     // bf16 octet engine: the launches are power-bound at batch 32 and latency-bound below; the fork / join events cost more than the
     // overlap returns under ~8 k frames (batch 1: 2.09 -> 1.92 ms, batch 8: 4.35 -> 4.26 on one stream; batch 32: 10.02 -> 9.88 ms with
     // three under the two-stream pipeline)
     if ((default_precision() == 1 || default_precision() == 2) && h->bfo_ok) {
-        const char* bfo_env = std::getenv("TTSAMD_BFO");
+        const char* bfo_env = opt_str(OPT_BFO);
         if (!(bfo_env && bfo_env[0] == '0')) return (int64_t)B * T >= 8192;
     }
     return true;
@@ -92,15 +93,15 @@ static bool parse_hex_mask(const char* txt, unsigned& out) {
     return true;
 }
 static int32_t read_fused2_switches(Fused2Switches& sw) {
-    const char* e = std::getenv("TTSAMD_FUSED2");
+    const char* e = opt_str(OPT_FUSED2);
     sw.on = !(e && e[0] == '0');
-    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK")) {
+    if (const char* m = opt_str(OPT_FUSED2_MASK)) {
         TTS_REQUIRE(parse_hex_mask(m, sw.mask), "TTSAMD_FUSED2_MASK='%s' is not a hex mask of 9 bits (bit 3 * ci + ki; 1ff = every pair)", m);
         sw.mask_forced = true;
     }
-    if (const char* m = std::getenv("TTSAMD_FUSED2_MASK_N1"))
+    if (const char* m = opt_str(OPT_FUSED2_MASK_N1))
         TTS_REQUIRE(parse_hex_mask(m, sw.mask_n1), "TTSAMD_FUSED2_MASK_N1='%s' is not a hex mask of 9 bits", m);
-    const char* wb = std::getenv("TTSAMD_FUSED2_WB");
+    const char* wb = opt_str(OPT_FUSED2_WB);
     sw.wino_b = !(wb && wb[0] == '0');
     sw.wino_a = sw.wino_b && !(wb && wb[0] == '1');
     const char* se = exp_env("TTSAMD_FUSED2_SMALL");
@@ -217,7 +218,7 @@ static int32_t add_conv(const TensorMap& tm, const std::string& base, int cin, i
         cw.ww_off = (int64_t)blob.size();
         blob.resize(blob.size() + (size_t)cin * wino2_groups(k) * cout_padded(cout));
         pack_wino2_weight(w.data(), cout, cin, k, blob.data() + cw.ww_off);
-        if (cout >= 128) {            // the un-fused ResBlock convs (stages with 128 / 256 channels): F(4,3) decomposition
+        if (cout >= 64) {             // the un-fused ResBlock convs (stages with 64 / 128 / 256 channels): F(4,3) decomposition
             blob.resize(align_up((int64_t)blob.size(), 64));
             cw.ww4_off = (int64_t)blob.size();
             blob.resize(blob.size() + (size_t)cin * wino4_groups(k) * cout_padded(cout));
@@ -446,13 +447,13 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     p.splitk_ws = splitks[0]; p.splitk_floats = kSplitKFloats;     // batch 1: stage-1 launches have < 256 tiles
     // plain bf16 mode: the c1 -> c2 intermediate of a ResBlock only feeds c2, so it crosses HBM as packed bf16
     // (ConvParams::y_packed / x_packed; same rounding point as the fp32 buffer + round-on-load, bit-identical)
-    const char* pk_env = std::getenv("TTSAMD_BF16_PACKED_T");
+    const char* pk_env = opt_str(OPT_BF16_PACKED_T);
     const bool pack_t = default_precision() == 1 && !(pk_env && pk_env[0] == '0');
     Fused2Switches f2sw;
     TTS_TRY(read_fused2_switches(f2sw));
-    const char* fz_env = std::getenv("TTSAMD_FUSED_PAIR");
+    const char* fz_env = opt_str(OPT_FUSED_PAIR);
     const bool fused_ok = default_precision() == 0 && !(fz_env && fz_env[0] == '0');
-    const char* ct_env = std::getenv("TTSAMD_CONVT");
+    const char* ct_env = opt_str(OPT_CONVT);
     const bool convt_ok = !(ct_env && ct_env[0] == '0');   // all-phases-per-wave transposed conv (convt_mfma.hip)
     bool in_section = false;   // inside a multi-stream fork..join section (profiling brackets the section)
     int pack_io = 0;   // bit 0: x is packed, bit 1: write y packed (set around the c1 / c2 launches below)
@@ -484,7 +485,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
     // ---- config 3: plain bf16 (precision 1) and split bf16 (precision 2) run on the octet engine (bfo.hpp / bfo3.hpp):
     // v_mfma_f32_32x32x16_bf16, activations in HBM as octet entries (bf16, or hi + lo) stored pre-activated for their consumer,
     // fused c1 -> c2 pairs for C <= 128.  TTSAMD_BFO=0 keeps the round-2 bf16 engine (fp32 activations in HBM).
-    const char* bfo_env = std::getenv("TTSAMD_BFO");
+    const char* bfo_env = opt_str(OPT_BFO);
     const int prec = default_precision();
     if ((prec == 1 || prec == 2) && h->bfo_ok && !(bfo_env && bfo_env[0] == '0')) {
         const bool x3 = prec == 2;
@@ -494,7 +495,7 @@ int32_t hifigan_forward(const HifiGan* h, const float* mel, const int64_t* lens,
         const auto l_convt = x3 ? bfo3_launch_convt : bfo_launch_convt;
         const auto l_pair = x3 ? bfo3_launch_pair : bfo_launch_pair;
         const auto pair_ok = x3 ? bfo3_pair_supported : bfo_pair_supported;
-        const char* c3e = std::getenv("TTSAMD_BFO_CHAIN");      // 0: three pair launches per k = 3 ResBlock (bit-identical; A/B and parity runs)
+        const char* c3e = opt_str(OPT_BFO_CHAIN);      // 0: three pair launches per k = 3 ResBlock (bit-identical; A/B and parity runs)
         const bool chain3_on = !(c3e && c3e[0] == '0');
         void *curo = cur, *upso = ups_out;                 // the fp32-sized buffers hold bf16 / x3 tensors of the same element count
         HG_TRY((x3 ? bfo3_launch_pack : bfo_launch_pack)(mel, B, cfg.num_mels, T, 1.f, mel_o, s));

@@ -1831,7 +1831,7 @@ __global__ __launch_bounds__(256) void taco_decoder_persistent(const TacoPersist
 
 // TTSAMD_TACO_PERSISTENT (read per call): see taco_persistent_mode()
 static int taco_persistent_mode() {          // 0 graph path (8-step hipGraph replay), 1 persistent kernel with grid barriers, 2 persistent kernel with
-    const char* e = getenv("TTSAMD_TACO_PERSISTENT");   // dataflow hand-offs and MFMA cells (default where it fits: 47.5 vs 57.5 us per step)
+    const char* e = opt_str(OPT_TACO_PERSISTENT);   // dataflow hand-offs and MFMA cells (default where it fits: 47.5 vs 57.5 us per step)
     if (!e || !e[0]) return 2;
     return (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
 }
@@ -1852,7 +1852,7 @@ struct TWs {
 // Read by workspace_bytes and by infer alike; a value that grows between the two calls is caught by infer's own carve of the arena it was
 // given ("workspace of N bytes needed"), never written past.
 static int taco_segment_steps() {
-    const char* e = getenv("TTSAMD_TACO_SEG");
+    const char* e = opt_str(OPT_TACO_SEG);
     const int v = e ? atoi(e) : 512;
     return std::max(8, v);
 }
@@ -2000,7 +2000,7 @@ int32_t tacotron2_infer(const Taco2* h, const int64_t* tokens, const int64_t* le
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev_id);
         (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_id);
-        const char* pe = getenv("TTSAMD_TACO_PERSISTENT");
+        const char* pe = opt_str(OPT_TACO_PERSISTENT);
         const bool explicit_req = pe && (pe[0] == '1' || pe[0] == '2');          // an explicit request must run the persistent kernel or fail
         bool fits = want && B <= 8 && L <= 256 && (M == 512 || M == 640) && A == 1024 && D == 1024 && P == 256 && KS % 2 == 1 &&
                     (B * L + 15) / 16 + KS - 1 <= 256 &&      /* the alignment window of an energy tile: one word per thread */

@@ -443,12 +443,12 @@ def resblock_pair(x, w1, b1, w2, b2, dil, lens=None, len_mul=1, y=None, mode=0, 
         y = torch.zeros_like(x)
     if lens is not None:
         lens = lens.to(device=x.device, dtype=torch.int64).contiguous()
-    ng = 4 * (k // 3) + 2 * (k % 3)                             # variants 4 / 5: the convs' Winograd groups behind the two direct packings
-    packed = torch.empty(2 * Cc * Cc * k + 2 * Cc * ng * Cc, dtype=torch.float32, device=x.device)
+    n_packed = int(lib.ttsamd_resblock_pair_packed_floats(Cc, k, int(variant)))      # variants 4 / 5: + the convs' Winograd groups
+    packed = torch.empty(max(n_packed, 1), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         L.check(lib.ttsamd_resblock_pair(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), Cc, k, int(dil), _ptr(lens),
                                          int(len_mul), Lx, B, int(mode), float(div), float(slope), int(variant), _ptr(packed),
-                                         _stream()), 'resblock_pair')
+                                         n_packed, _stream()), 'resblock_pair')
     return y
 
 

@@ -54,6 +54,10 @@ _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     'ttsamd_last_error': (C.c_char_p, []),
     'ttsamd_version': (_I32, []),
+    'ttsamd_set_option': (_I32, [C.c_char_p, C.c_char_p]),
+    'ttsamd_get_option': (_I32, [C.c_char_p, C.c_char_p, _I32]),
+    'ttsamd_option_name': (C.c_char_p, [_I32]),
+    'ttsamd_options_check': (_I32, []),
     'ttsamd_device_ok': (_I32, []),
     'ttsamd_hifigan_create': (_I32, [C.POINTER(Tensor), _I32, C.POINTER(HifiGanCfg), C.POINTER(_P)]),
     'ttsamd_hifigan_destroy': (_I32, [_P]),
@@ -89,7 +93,8 @@ SYMBOLS = {
     'ttsamd_conv1d_packed_floats': (_I64, [_I32, _I32, _I32]),
     'ttsamd_conv1d': (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     'ttsamd_conv1d_ex': (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _I32, _F, _P, _P, _P]),
-    'ttsamd_resblock_pair': (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P]),
+    'ttsamd_resblock_pair_packed_floats': (_I64, [_I32, _I32, _I32]),
+    'ttsamd_resblock_pair': (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _I64, _P]),
     'ttsamd_bfo_pack': (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),
     'ttsamd_bfo_unpack': (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),
     'ttsamd_bfo_weight_elems': (_I64, [_I32, _I32, _I32, _I32]),
@@ -123,7 +128,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 5            # == TTSAMD_ABI_VERSION of include/ttsamd.h (struct layouts and argument meanings of this binding)
+ABI_VERSION = 6            # == TTSAMD_ABI_VERSION of include/ttsamd.h (struct layouts and argument meanings of this binding)
 
 
 def load():
@@ -147,8 +152,52 @@ def load():
     if got != ABI_VERSION:
         raise TtsAmdError(f'{LIB_PATH} was built from another revision of include/ttsamd.h (library ABI {got}, this binding '
                           f'{ABI_VERSION}): rebuild it with `make -C tts-arabic-pytorch_amd/csrc`')
+    if lib.ttsamd_options_check() != 0:             # a malformed TTSAMD_<NAME> in the environment: loud, not ignored
+        msg = lib.ttsamd_last_error()
+        raise TtsAmdError(f'bad routing option in the environment: {msg.decode() if msg else "?"}')
     _lib = lib
     return lib
+
+
+def set_option(name, value):
+    """Routing option of the library (include/ttsamd.h: ttsamd_set_option): `name` with or without the TTSAMD_ prefix, `value` an int / str
+    as the environment variable would hold it, None = back to the default.  Raises on an unknown name or a value out of range."""
+    v = None if value is None else str(value).encode()
+    check(load().ttsamd_set_option(name.encode(), v), f'set_option({name}={value})')
+
+
+def get_option(name):
+    """Current text of a routing option, None when unset (the default applies)."""
+    buf = C.create_string_buffer(64)
+    check(load().ttsamd_get_option(name.encode(), buf, 64), f'get_option({name})')
+    return buf.value.decode() or None
+
+
+def option_names():
+    lib, out, i = load(), [], 0
+    while True:
+        n = lib.ttsamd_option_name(i)
+        if not n:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+class options:
+    """Context manager: set routing options for a block and restore what was there before.  `with options(TTSAMD_WINO=0): ...`"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            set_option(k, v)
 
 
 def check(rc, what):
