@@ -212,6 +212,8 @@ void pack_wino2_weight(const float* w, int cout, int cin, int k, float* out);   
 // ... and the F(4,3) decomposition (conv_wino4.hip: 6 / 16 / 23 products per output QUAD at k = 3 / 7 / 11): 64 rows x 64 quads per block
 int wino4_groups(int k);                         // groups per octet in the packed weights: 6 / 16 / 24 (k = 11: 23 + one zero group)
 int wino4_block_outputs(int dil);
+int wino4_ksplit(const ConvParams& p);           // C-in slices the launcher will use for this launch (1 = none)
+int32_t launch_splitk_reduce(const ConvParams& q, hipStream_t stream);   // conv_mfma.hip: y = epilogue(sum of the ksplit partial tensors)
 int32_t launch_wino4(const ConvParams& p, hipStream_t stream);
 void wino4_filter_groups(const float* g, int k, float* o);                      // one (co, ci) filter -> its wino4_groups(k) group filters
 void pack_wino4_weight(const float* w, int cout, int cin, int k, float* out);   // out: cin * wino4_groups(k) * cout_padded(cout) floats

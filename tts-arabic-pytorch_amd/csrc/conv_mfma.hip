@@ -653,6 +653,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
     *yp = v;
 }
 
+int32_t launch_splitk_reduce(const ConvParams& q, hipStream_t stream) {
+    dim3 rg((q.Nout + 255) / 256, q.Cout, q.batch);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, stream, q);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int K, int MT, int NTL, int WM, int WN, int EPI>
 static int32_t launch_epi(const ConvParams& q, dim3 grid, size_t lds, hipStream_t stream) {
     static std::atomic<uint64_t> lds_done{0};          // per instantiation: devices already opted in (common.hpp: lds_opt_in)
@@ -759,11 +766,7 @@ static int32_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     else if (epi == 1) rc = launch_epi<K, MT, NTL, WM, WN, (K == 1 || K == 5) ? 1 : 2>(q, grid, lds, stream);
     else rc = launch_epi<K, MT, NTL, WM, WN, 2>(q, grid, lds, stream);
     if (rc != 0) return rc;
-    if (q.ksplit > 1) {
-        dim3 rg((p.Nout + 255) / 256, p.Cout, p.batch);
-        hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, stream, q);
-        TTS_CHECK_HIP(hipGetLastError());
-    }
+    if (q.ksplit > 1) return launch_splitk_reduce(q, stream);
     return 0;
 }
 

@@ -426,7 +426,7 @@ int wino_route(const ConvParams& p) {
                          (int64_t)p.Cout * std::max(std::max(p.r_cs, p.y_cs), 1) * 4 < ((int64_t)1 << 31);
         if (ok4) {
             const int bo4 = wino4_block_outputs(p.dil);
-            const int64_t blocks4 = (int64_t)((p.Nout + bo4 - 1) / bo4) * (p.CoutP / 64) * p.batch;
+            const int64_t blocks4 = (int64_t)((p.Nout + bo4 - 1) / bo4) * (p.CoutP / 64) * p.batch * wino4_ksplit(p);
             if (blocks4 >= 192 && p.Nout >= 256) return 3;
         }
         if (p.w_wino == nullptr) return 0;

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int co_blk0 = blockIdx.y * CO_BLK;
+    // split K (small problems: launch_wino4_cfg): slice ks of the C-in chunks, raw partial sums to splitk_ws, epilogue in splitk_reduce_kernel
+    const int tiles_y = p.CoutP / CO_BLK;
+    const int ks = blockIdx.y / tiles_y;
+    const int co_blk0 = (blockIdx.y - ks * tiles_y) * CO_BLK;
     int n_out = p.Nout;
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
     if (q0 >= n_out) return;
@@ -140,7 +143,8 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     if (p.lens_in) in_len = min(in_len, (int)p.lens_in[b] * p.len_in_mul);
 
     const int x_cs = p.x_cs, CoutP = p.CoutP;
-    const int n_chunks = p.Cin / (8 * NOCT);
+    const int chunks_all = p.Cin / (8 * NOCT);
+    const int c_beg = (int)((int64_t)ks * chunks_all / p.ksplit), n_chunks = (int)((int64_t)(ks + 1) * chunks_all / p.ksplit);   // [c_beg, n_chunks)
     const int n_groups = (p.Cin / 8) * G::NGQ;                // groups of the whole conv in the packed weights
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
     const float in_slope = p.in_slope;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     const bfo_i4 wrs = bfo_rsrc(p.w_wino4, (unsigned)n_groups * 2u * (unsigned)CoutP * 16u);
     const int wv = (kk * CoutP + co_blk0 + wm * 32 + l31) * 16;
     const int wstep = 2 * CoutP * 16, wlast = (n_groups - 1) * wstep;
-    int wso = 0;
+    int wso = c_beg * NOCT * G::NGQ * wstep;
     w4_f32x4 aq[PF];
 #pragma unroll
     for (int g = 0; g < PF; ++g) {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
 #pragma unroll
         for (int st = 0; st < NSTAGE - 1; ++st) {
             const int ph = st % NPH;
-            const int xso = min(st / NPH, n_chunks - 1) * 8 * NOCT * x_cs;
+            const int xso = min(c_beg + st / NPH, n_chunks - 1) * 8 * NOCT * x_cs;
             if constexpr (D1) {
 #pragma unroll
                 for (int J = 0; J < G::nljv(ph); ++J) TTS_VLOAD_JOB(ph, J, xso)
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     bq[0] = sB[0];
 
     int stage = 0;  // step % NSTAGE
-    for (int c = 0; c < n_chunks; ++c) {
+    for (int c = c_beg; c < n_chunks; ++c) {
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             // the step being staged: NSTAGE - 1 ahead (tail: the last chunk is re-staged into a dead stage -- branch-free body)
@@ -425,6 +429,26 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     const int col = lane * 4, q = q0 + col;
     if (q >= n_out || col >= nt_eff) return;
     const bool full = q + 3 < n_out;
+    if (p.ksplit > 1) {                                                 // raw partial sums of this C-in slice
+        float* __restrict__ pb = p.splitk_ws + ((int64_t)ks * p.batch + b) * Cout * p.Nout;
+#pragma unroll 4
+        for (int it = 0; it < NR; ++it) {
+            const int rl = wid + it * 4;
+            const int co = co_blk0 + rl;
+            if (co >= Cout) continue;
+            const float4 a4 = *reinterpret_cast<const float4*>(ep + rl * NT_BLK + col);
+            float* yp = pb + (int64_t)co * p.Nout + q;
+            if (full && (p.Nout & 3) == 0) {
+                *reinterpret_cast<float4*>(yp) = a4;
+            } else {
+                const float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q + e < n_out) yp[e] = v[e];
+            }
+        }
+        return;
+    }
     if (preload || (!rb && mode == 0)) {
         // nothing to read from memory: a loop without a single vmcnt wait (conv_mfma.hip: why)
         const float lo = relu_out == 1 ? 0.f : -__builtin_inff();
@@ -506,10 +530,12 @@ static int32_t launch_wino4_epi(const ConvParams& p, hipStream_t stream) {
     const int nt = wino4_tile(p.dil, G::NTUP);
     dim3 grid((p.Nout + nt - 1) / nt, p.CoutP / G::CO_BLK, p.batch);
     ConvParams q = p;
-    q.ksplit = 1;
+    q.ksplit = EPI == 0 ? wino4_ksplit(p) : 1;
+    grid.y *= q.ksplit;
     q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
+    if (q.ksplit > 1) return launch_splitk_reduce(q, stream);
     return 0;
 }
 
@@ -518,7 +544,7 @@ static int32_t launch_wino4_cfg(const ConvParams& p, hipStream_t stream) {
     // residual preload (16-byte loads of the lane's quad): dilation 1 -- every c2 conv of a ResBlock, the second conv-FF conv
     // dilation 1: the window as aligned 16-byte vectors (D1)
     if (p.dil == 1) {
-        if (p.res != nullptr) return launch_wino4_epi<K, NOCT, NSTAGE, 3, true>(p, stream);
+        if (p.res != nullptr && wino4_ksplit(p) == 1) return launch_wino4_epi<K, NOCT, NSTAGE, 3, true>(p, stream);
         return launch_wino4_epi<K, NOCT, NSTAGE, 0, true>(p, stream);
     }
     return launch_wino4_epi<K, NOCT, NSTAGE, 0, false>(p, stream);
@@ -533,6 +559,19 @@ int32_t launch_wino4(const ConvParams& p, hipStream_t stream) {
 }
 
 int wino4_block_outputs(int dil) { return wino4_tile(dil, 64); }
+
+// C-in slices of a launch that cannot fill the chip by its tiles alone (batch 1: HiFi-GAN's C = 256 stage is 56 blocks): enough for
+// ~224 blocks, at least four chunks per slice, partial sums within the caller's split-K workspace.  1 = no split.
+int wino4_ksplit(const ConvParams& p) {
+    const int bo = wino4_block_outputs(p.dil);
+    const int64_t blocks = (int64_t)((p.Nout + bo - 1) / bo) * (p.CoutP / 64) * p.batch;
+    if (blocks >= 192 || p.splitk_ws == nullptr) return 1;
+    const int n_chunks = p.Cin / (p.K == 3 ? 16 : 8);
+    const int64_t per = (int64_t)p.batch * p.Cout * p.Nout;
+    int64_t ks = std::min<int64_t>((224 + blocks - 1) / blocks, n_chunks / 4);
+    ks = std::min<int64_t>(ks, p.splitk_floats / std::max<int64_t>(per, 1));
+    return ks >= 2 ? (int)ks : 1;
+}
 
 // groups per octet in the packed weights (k = 11: 23 multiplied + one zero group)
 int wino4_groups(int k) { return k == 3 ? 6 : (k == 7 ? 16 : 24); }
