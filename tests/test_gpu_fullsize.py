@@ -80,6 +80,47 @@ def test_full_batch_every_utterance(workload, synth_weights, mode, mel_tol, wave
         set_precision('f32')
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+def test_batch1_full_size_utterance(workload, synth_weights, mode, ttsopt):
+    """north_star's batch-1 case at full size: ONE 64-token utterance (the longest of the bench workload) alone through FastPitch + HiFi-GAN --
+    the small-problem routing of every engine (split K in the direct, the F(2,3) and the F(4,3) kernels: conv_wino4.hip slices the C-in
+    chunks of HiFi-GAN's C = 256 stage at this size; attention tile + merge; one- / three-stream vocoder) -- against the oracle of that
+    utterance (the vocoder is batch-independent; FastPitch alone on an unpadded batch of one = the reference's batch_size = 1 call).
+    fp32 additionally with the F(4,3) kernel off (TTSAMD_WINO4=0): both inside the tolerance, different bits = the routing took effect."""
+    import tts_oracle as O
+    from ttsamd.config import NET_CONFIG, HIFIGAN_CONFIG
+    from ttsamd.engine import FastPitchEngine, HifiGanEngine, set_precision
+    dev = workload['dev']
+    b = int(np.argmax(workload['lens']))
+    ids, dur = workload['ids'][b:b + 1], workload['dur'][b:b + 1]
+    fw = {k: v.to(dev) for k, v in O.to_torch(synth_weights['fastpitch']).items()}
+    hw = {k: v.to(dev) for k, v in O.fold_weight_norm(synth_weights['hifigan']).items()}
+    with torch.backends.cudnn.flags(enabled=False), torch.inference_mode(), torch.device(dev):
+        mel_ref, lens_ref, *_ = O.fastpitch_infer(fw, NET_CONFIG, ids.cpu().numpy(), dur_tgt=dur)
+        wave_ref = O.hifigan_forward(hw, mel_ref[0], HIFIGAN_CONFIG).reshape(-1).cpu()
+    mel_ref = mel_ref.cpu()
+    set_precision(mode)
+    try:
+        fp, hg = FastPitchEngine(synth_weights['fastpitch'], device=dev), HifiGanEngine(synth_weights['hifigan'], device=dev)
+        outs = {}
+        for w4 in ((None, '0') if mode == 'f32' else (None,)):
+            ttsopt.set('TTSAMD_WINO4', w4)
+            mel, dec_lens, *_ = fp.infer(ids, dur_tgt=dur)
+            wave = hg.forward(mel, dec_lens)
+            torch.cuda.synchronize()
+            n = int(dec_lens[0])
+            assert n == int(lens_ref[0]) == int(workload['lens'][b])
+            em = float((mel[0, :, :n].cpu() - mel_ref[0, :, :n]).abs().max())
+            ew = float((wave[0, :256 * n].cpu() - wave_ref).abs().max())
+            print(f'batch 1 full-size {mode} (TTSAMD_WINO4={w4}): {n} frames, mel max-abs {em:.2e} (tol {MEL_TOL}), wave max-abs {ew:.2e} (tol {WAVE_TOL})')
+            assert em < MEL_TOL and ew < WAVE_TOL
+            outs[w4] = wave.cpu()
+        if mode == 'f32':
+            assert not torch.equal(outs[None], outs['0']), 'the F(4,3) kernels must take part in the batch-1 call'
+    finally:
+        set_precision('f32')
+
+
 def test_config5_full_batch_every_utterance(synth_weights):
     """BASELINE config 5 at full size: 4-speaker FastPitch (32 x 64 tokens, forced durations, one speaker id per call as the
     reference API has it: models/fastpitch/fastpitch/model.py:358-359) -> MelVocos('22k') on the ragged batch, every utterance

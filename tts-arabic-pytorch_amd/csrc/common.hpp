@@ -172,7 +172,7 @@ struct ConvParams {
                               // utterance-major list of LIVE tiles (live_tile below), so every dead block sits at the end of the grid
     unsigned long long* timing;   // tools/conv_bench -DTTS_TIMING only: [blocks][8] clock samples (nullptr otherwise)
 };
-constexpr int64_t kSplitKFloats = 2 << 20;   // 8 MB covers every case the launcher picks (< 192 blocks x <= 512/blocks)
+constexpr int64_t kSplitKFloats = 4 << 20;   // 16 MB covers every case the launchers pick (direct kernel: < 320 blocks, ~640 blocks wanted; conv_wino4.hip: four C-in slices of a 1 x 256 x 3584 launch = 3.7 M floats)
 constexpr int64_t kSplitKFloatsFp = 8 << 20; // FastPitch: 32 MB, the deep conv-FF conv (1536 -> 384) splits K at batch 4..13 too
 
 void conv_log(const char* kind, int K, int cin, int cout, int nout, int batch, int has_res, int mode, int len_mul, int ragged,

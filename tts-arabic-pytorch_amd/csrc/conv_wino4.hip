@@ -565,10 +565,17 @@ int wino4_block_outputs(int dil) { return wino4_tile(dil, 64); }
 int wino4_ksplit(const ConvParams& p) {
     const int bo = wino4_block_outputs(p.dil);
     const int64_t blocks = (int64_t)((p.Nout + bo - 1) / bo) * (p.CoutP / 64) * p.batch;
-    if (blocks >= 192 || p.splitk_ws == nullptr) return 1;
+#ifdef TTS_EXPERIMENT      /* (std::getenv directly: exp_env is an inline function, one definition per library) */
+    static const int sk_blocks = [] { const char* e = std::getenv("TTSAMD_W4_SPLITK_BLOCKS"); return e ? atoi(e) : 192; }();
+    static const int sk_target = [] { const char* e = std::getenv("TTSAMD_W4_SPLITK_TARGET"); return e ? atoi(e) : 224; }();
+    if (std::getenv("TTSAMD_W4_SPLITK_LOG")) fprintf(stderr, "wino4 K=%d Cin=%d Nout=%d blocks=%lld\n", p.K, p.Cin, p.Nout, (long long)blocks);
+#else
+    constexpr int sk_blocks = 192, sk_target = 224;
+#endif
+    if (blocks >= sk_blocks || p.splitk_ws == nullptr) return 1;
     const int n_chunks = p.Cin / (p.K == 3 ? 16 : 8);
     const int64_t per = (int64_t)p.batch * p.Cout * p.Nout;
-    int64_t ks = std::min<int64_t>((224 + blocks - 1) / blocks, n_chunks / 4);
+    int64_t ks = std::min<int64_t>((sk_target + blocks - 1) / blocks, n_chunks / 4);
     ks = std::min<int64_t>(ks, p.splitk_floats / std::max<int64_t>(per, 1));
     return ks >= 2 ? (int)ks : 1;
 }
