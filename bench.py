@@ -1070,17 +1070,37 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
             mel, dl, *_ = fp.infer(ids, dur_tgt=dur)
             wave = hg.forward(mel, dl)
             return den.forward_batch(wave, dl * hop, 0.005, nsamples_min=513), dl
-        for _ in range(3):
-            c2d()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            _, dl = c2d()
-        sync()
-        el = (time.perf_counter() - t0) / n
+        from ttsamd.pipeline import FastPitchHifiGan
+        pipe_d = FastPitchHifiGan(fp, hg, dev)
+
+        def c2dp():                                              # the headline's two-stream schedule with the denoiser behind the vocoder
+            _, dl, wave = pipe_d.submit(ids, vocode=lambda mel, dl_: den.forward_batch(hg.forward(mel, dl_), dl_ * hop, 0.005, nsamples_min=513),
+                                        dur_tgt=dur)
+            return wave, dl
+
+        def c2p():                                               # ... and without it, timed right beside (same box, same minute)
+            _, dl, wave = pipe_d.submit(ids, dur_tgt=dur)
+            return wave, dl
+
+        def timed_d(f):
+            for _ in range(3):
+                f()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                _, dl_ = f()
+            sync()
+            return (time.perf_counter() - t0) / n, dl_
+        el1, dl = timed_d(c2d)
+        el, dl = timed_d(c2dp)
+        el_off, _ = timed_d(c2p)
         fr = int(dl.sum().item())
         res.append({'config': f'C2 with denoise=0.005 (Denoiser: STFT -> spectral subtraction -> ISTFT after the vocoder), batch {B}, fp32',
-                    'batch': B, 'ms_per_step': el * 1e3, 'value': fr * hop / el, 'unit': 'audio samples/s',
+                    'batch': B, 'ms_per_step': el * 1e3, 'ms_per_step_one_stream': el1 * 1e3, 'ms_per_step_denoise_off': el_off * 1e3,
+                    'denoise_cost_ms': (el - el_off) * 1e3,
+                    'schedule': 'two HIP streams as the headline (FastPitch of step i+1 under HiFi-GAN + denoiser of step i); '
+                                'ms_per_step_denoise_off = the same loop without the denoiser, timed right beside it',
+                    'value': fr * hop / el, 'unit': 'audio samples/s',
                     'rtf': el / (fr * hop / SAMPLE_RATE), 'frames': fr, 'steps': n, 'dtype': 'f32',
                     'parity': 'denoiser unpinned at the torchaudio boundary (golden made with a torch.stft stand-in; SURVEY §8c)'})
     except Exception as e:                                       # noqa: BLE001

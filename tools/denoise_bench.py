@@ -1,0 +1,52 @@
+"""The denoiser on the bench workload's waves (B = 32, ~448 frames each): ms per call; run under rocprofv3 --kernel-trace --stats for
+the per-kernel split.  gpurun -- 'python3 tools/denoise_bench.py'"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tts-arabic-pytorch_amd'))
+from ttsamd import synth  # noqa: E402
+from ttsamd.engine import HifiGanEngine  # noqa: E402
+from vocoder.hifigan.denoiser import Denoiser  # noqa: E402
+
+dev = torch.device('cuda:0')
+hg = HifiGanEngine(synth.hifigan_state_dict(), device=dev)
+
+
+class _Voc:
+    device = dev
+
+    def __call__(self, mel):
+        return hg.forward(mel)
+
+    def to(self, d):
+        return self
+
+
+den = Denoiser(_Voc())
+B = 32
+dur = synth.synth_durations(B, 64)
+lens = torch.from_numpy(dur.sum(1)).to(dev).to(torch.int64)
+T = int(lens.max())
+wave = torch.randn(B, T * 256, device=dev) * 0.1
+for _ in range(3):
+    den.forward_batch(wave.clone(), lens * 256, 0.005, nsamples_min=513)
+torch.cuda.synchronize()
+w = wave.clone()
+t0 = time.perf_counter()
+for _ in range(10):
+    den.forward_batch(w, lens * 256, 0.005, nsamples_min=513)
+torch.cuda.synchronize()
+print(f'denoise B = {B}, {int(lens.sum())} frames: {(time.perf_counter() - t0) * 100:.3f} ms per call')
+cpu, tot = [], []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    den.forward_batch(w, lens * 256, 0.005, nsamples_min=513)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    cpu.append(t1 - t0); tot.append(t2 - t0)
+print(f'one call at a time: host enqueue {sorted(cpu)[5] * 1e3:.3f} ms, until the GPU is done {sorted(tot)[5] * 1e3:.3f} ms')

@@ -262,6 +262,14 @@ struct SplitKScope {
     explicit SplitKScope(float* p) { t_splitk_ws = p; }
     ~SplitKScope() { t_splitk_ws = nullptr; }
 };
+// split-bf16 mode, batch <= 2: FastPitch is ~135 dependent launches of a few microseconds and the exact-fp32 engine's are the shorter ones
+// (tools/b1_parts.py: batch 1 1.17 ms against 1.58 on the x3 kernels, batch 2 1.50 / 1.60, batch 3 1.80 / 1.74, batch 4 1.89 / 1.73): the
+// call then runs its convs in fp32 (at least as accurate; HiFi-GAN stays on the split-bf16 octet engine)
+static thread_local bool t_small_f32 = false;
+struct SmallBatchScope {
+    explicit SmallBatchScope(int B) { t_small_f32 = default_precision() == 2 && B <= 2; }
+    ~SmallBatchScope() { t_small_f32 = false; }
+};
 
 static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, float* y, const float* res, int B, int S,
                         const int64_t* lens_in, int relu, hipStream_t s) {
@@ -269,7 +277,7 @@ static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, floa
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.x_bs = (int64_t)c.cin * S; p.x_cs = S;
     p.w = h->dev + c.w_off; p.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
-    p.w_bf16 = h->dev16 + c.w16_off; p.precision = default_precision();
+    p.w_bf16 = h->dev16 + c.w16_off; p.precision = t_small_f32 ? 0 : default_precision();
     p.w_wino = c.ww_off >= 0 ? h->dev + c.ww_off : nullptr;
     p.w_wino4 = c.ww4_off >= 0 ? h->dev + c.ww4_off : nullptr;
     p.y = y; p.y_bs = (int64_t)c.cout * S; p.y_cs = S; p.y_ts = 1;
@@ -335,7 +343,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
         }
         return 0;
     }
-    bool x3 = default_precision() == 2 && !(ffe && ffe[0] == '0') && (d == 384 || d == 256 || d == 512) && d_head % 8 == 0 && w.o3;
+    bool x3 = default_precision() == 2 && !t_small_f32 && !(ffe && ffe[0] == '0') && (d == 384 || d == 256 || d == 512) && d_head % 8 == 0 && w.o3;
     for (const FftLayer& l : layers)
         x3 = x3 && l.ff0.wo3_off >= 0 && l.ff2.wo3_off >= 0 && l.qkv.wo3_off >= 0 && l.o_net.wo3_off >= 0 && l.qkv.cout == 3 * d_head;
     if (x3) {
@@ -431,7 +439,7 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
         // split bf16: the same chain on the x3 kernels.  The x3 tensors are as large as the fp32 ones: the packed input ([B][cin][S] x 4
         // bytes, cin <= 2 filter would not fit) and the copy of the first LayerNorm's output both go to `px3`
         const char* ffe = opt_str(OPT_BFO_FF);
-        bool x3 = default_precision() == 2 && !(ffe && ffe[0] == '0') && pr.convs.size() == 2 && (pr.filter == 256 || pr.filter == 384 || pr.filter == 512) &&
+        bool x3 = default_precision() == 2 && !t_small_f32 && !(ffe && ffe[0] == '0') && pr.convs.size() == 2 && (pr.filter == 256 || pr.filter == 384 || pr.filter == 512) &&
                   pr.convs[0].cin % 8 == 0 && pr.convs[0].cin <= pr.filter * 2 && px3 != nullptr;
         for (const PConv& c : pr.convs) x3 = x3 && c.wo3_off >= 0;
         if (x3) {
@@ -515,6 +523,7 @@ int32_t fastpitch_encode(const FastPitch* h, const int64_t* ids, int32_t B, int3
     }
     const int d = c.d_model;
     SplitKScope splitk(w.f.splitk);
+    SmallBatchScope small_f32(B);
     float* x = enc_cond;
     const float* spk = (c.n_speakers > 1 && h->spk_emb >= 0) ? h->dev + h->spk_emb + (int64_t)speaker * d : nullptr;
     TTS_TRY(launch_embed(ids, h->dev + h->word_emb, h->dev + h->pos_enc, h->pos_cap, spk, c.padding_idx, c.n_symbols, B, L, d, x,
@@ -568,6 +577,7 @@ int32_t fastpitch_decode(const FastPitch* h, float* x, const int64_t* dec_lens, 
     }
     const ttsamd_fastpitch_cfg& c = h->cfg;
     SplitKScope splitk(w.splitk);
+    SmallBatchScope small_f32(B);
     // decoder input = len_regulated + pos_emb*mask (transformer.py:215-219, embed_input=False)
     TTS_TRY(launch_add_pos(x, h->dev + h->pos_dec, h->pos_cap, dec_lens, B, c.d_model, T, s));
     TTS_TRY(run_fft(h, h->dec, c.out_fft_d_head, x, dec_lens, B, T, w, s));

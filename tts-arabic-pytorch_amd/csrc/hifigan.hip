@@ -66,7 +66,9 @@ static bool use_branch_streams(const HifiGan* h, int32_t B, int32_t T) {
     // bf16 octet engine: the launches are power-bound at batch 32 and latency-bound below; the fork / join events cost more than the
     // overlap returns under ~8 k frames (batch 1: 2.09 -> 1.92 ms, batch 8: 4.35 -> 4.26 on one stream; batch 32: 10.02 -> 9.88 ms with
     // three under the two-stream pipeline)
-    if ((default_precision() == 1 || default_precision() == 2) && h->bfo_ok) {
+    // (split bf16, round 6: three streams win at every size -- batch 1 1.18 vs 1.25 ms, 2: 1.87 / 1.94, 4: 3.37 / 3.53, 8: 6.15 / 6.40,
+    // tools/b1_parts.py -- so the rule below is the plain-bf16 engine's only)
+    if (default_precision() == 1 && h->bfo_ok) {
         const char* bfo_env = opt_str(OPT_BFO);
         if (!(bfo_env && bfo_env[0] == '0')) return (int64_t)B * T >= 8192;
     }
