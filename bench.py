@@ -763,7 +763,7 @@ def main():
         # (profiles/rN/traffic.json; gpurun forbids mixing PMC with the timed run), newest round first
         traffic, traffic_src, traffic_alg = None, None, None
         if B == 32 and Lt == 64 and world == 1:
-            for rnd in ('r5', 'r4', 'r3', 'r2', 'r1'):
+            for rnd in ('r6', 'r5', 'r4', 'r3', 'r2', 'r1'):
                 try:
                     with open(os.path.join(REPO, 'profiles', rnd, 'traffic.json' if args.precision == 'f32' else f'traffic_{args.precision}.json')) as f:
                         tj = json.load(f)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r5'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r6'
 # bench line (with cpu_baseline and the batch-1 / batch-8 sub-results), rocprofv3 kernel stats of the same command,
 # FETCH_SIZE / WRITE_SIZE calibration on known-bytes kernels, separate PMC passes, the other precisions and configs.
 set -u
-R=${1:-r5}
+R=${1:-r6}
 O=gpurun_out/collect_$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -33,9 +33,11 @@ python3 profiles/pmc_summarize.py $O/xpmc_mfma > $O/bf16x3_pmc_mfma_by_kernel.tx
 cp $(ls $O/xstats1/*/*kernel_stats.csv | head -1) $O/bf16x3_kernel_stats_one_stream.csv
 python3 tools/bfo_bench.py --x3 --json $O/bfo3_layers.json > $O/bfo3_layers.txt 2>> $O/bench.err
 rm -rf $O/xstats1 $O/xpmc_mfma
-# fp32 with the direct k = 3 kernel instead of Winograd F(2,3): the same-box A/B behind DESIGN.md section 4
+# fp32 same-box A/B behind DESIGN.md section 4: default routing (F(4,3) + F(2,3)), the round-5 routing (F(2,3) only: TTSAMD_WINO4=0 and the
+# C = 64 pairs fused again), the direct kernels only
 python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_on_bench_line.json 2>> $O/bench.err
-TTSAMD_WINO=0 TTSAMD_FUSED2_WB=0 python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_off_bench_line.json 2>> $O/bench.err
+TTSAMD_WINO4=0 TTSAMD_FUSED2_MASK=07f python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino4_off_bench_line.json 2>> $O/bench.err
+TTSAMD_WINO=0 TTSAMD_FUSED2_WB=0 TTSAMD_FUSED2_MASK=07f python3 bench.py --no-cpu-baseline --no-small --no-extra --steps 20 > $O/wino_off_bench_line.json 2>> $O/bench.err
 # bf16 runs the two-stream schedule by default (FastPitch of step i+1 under HiFi-GAN of step i); the one-stream line of the same work:
 python3 bench.py --precision bf16 --no-pipeline --no-cpu-baseline --no-small --no-extra > $O/bf16_one_stream_bench_line.json 2>> $O/bench.err
 # config 3 (bf16 octet engine): kernel stats (three streams / one stream), HBM traffic and MFMA counters of the same command

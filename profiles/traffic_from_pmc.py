@@ -19,7 +19,7 @@ def dispatches(d, counter):
     rows = {}
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'resblock_pair', 'resblock_chain', 'convt_mfma', 'bfo_conv1d', 'bfo_convt')):
+            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('conv1d_mfma', 'conv1d_wino', 'resblock_pair', 'resblock_chain', 'convt_mfma', 'bfo_conv1d', 'bfo_convt', 'bfo3_conv1d', 'bfo3_convt')):
                 k = int(r['Dispatch_Id'])
                 name = r['Kernel_Name'].split('(')[0].replace('void ttsamd::', '')
                 g = None

@@ -122,20 +122,31 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     constexpr int NPH = G::NPH, NPOSP = G::NPOSP, NM = G::NM, DA = G::DA, LPG = G::LPG;
     const int dil = D1 ? 1 : p.dil;
     const int nt_eff = wino4_tile(dil, NTUP), ntup_eff = nt_eff / 4;
-    int b = blockIdx.z;
-    int q0 = blockIdx.x * nt_eff;
+    // Block -> (time tile, row block, C-in slice).  The 1-D grid is dealt to the 8 XCDs round-robin (workgroup s runs on XCD s % 8, each
+    // with its own L2); slot u = s / 8 of an XCD walks (row block, slice) fastest, so ALL row blocks of a time tile run on ONE XCD one
+    // after the other and share the tile's input window through that L2 (Cout = 128 / 256: 2 / 4 row blocks; measured HBM bytes of the
+    // C = 128 k = 11 c2 launch with the plain (x, y, z) grid: 1.38x the algorithmic bytes, profiles/r6/traffic_plain_grid.json).
+    const int tiles_y = p.CoutP / CO_BLK;
+    const int per_tile = tiles_y * p.ksplit;
+    const unsigned sidx = blockIdx.x, xcd = sidx & 7u, u = sidx >> 3;
+    const int yk = (int)(u % (unsigned)per_tile);
+    const unsigned gt = (u / (unsigned)per_tile) * 8u + xcd;            // global time-tile index (utterance-major)
+    const int n_tiles_x = (p.Nout + nt_eff - 1) / nt_eff;
+    int b = (int)(gt / (unsigned)n_tiles_x);
+    int q0 = (int)(gt % (unsigned)n_tiles_x) * nt_eff;
     if (p.compact) {   // dead blocks last (live_tile, common.hpp)
         int tile = 0;
-        if (!live_tile(p.lens_out, p.len_out_mul, p.Nout, nt_eff, p.batch, blockIdx.z * gridDim.x + blockIdx.x, b, tile)) return;
+        if (!live_tile(p.lens_out, p.len_out_mul, p.Nout, nt_eff, p.batch, gt, b, tile)) return;
         b = __builtin_amdgcn_readfirstlane(b);
         q0 = __builtin_amdgcn_readfirstlane(tile) * nt_eff;
+    } else if (b >= p.batch) {
+        return;                                                        // the grid is rounded up to whole groups of 8 tiles
     }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     // split K (small problems: launch_wino4_cfg): slice ks of the C-in chunks, raw partial sums to splitk_ws, epilogue in splitk_reduce_kernel
-    const int tiles_y = p.CoutP / CO_BLK;
-    const int ks = blockIdx.y / tiles_y;
-    const int co_blk0 = (blockIdx.y - ks * tiles_y) * CO_BLK;
+    const int ks = yk / tiles_y;
+    const int co_blk0 = (yk - ks * tiles_y) * CO_BLK;
     int n_out = p.Nout;
     if (p.lens_out) n_out = min(n_out, (int)p.lens_out[b] * p.len_out_mul);
     if (q0 >= n_out) return;
@@ -528,10 +539,13 @@ static int32_t launch_wino4_epi(const ConvParams& p, hipStream_t stream) {
     const auto kern = conv1d_wino4_f32<K, NOCT, NSTAGE, EPI, D1>;
     TTS_CHECK_HIP(lds_opt_in((const void*)kern, (int)lds, lds_done));
     const int nt = wino4_tile(p.dil, G::NTUP);
-    dim3 grid((p.Nout + nt - 1) / nt, p.CoutP / G::CO_BLK, p.batch);
     ConvParams q = p;
     q.ksplit = EPI == 0 ? wino4_ksplit(p) : 1;
-    grid.y *= q.ksplit;
+    // 1-D grid: (time tiles of the whole batch, rounded up to groups of 8) x row blocks x C-in slices; the kernel maps it XCD-aware
+    const int64_t n_tiles = (int64_t)((p.Nout + nt - 1) / nt) * p.batch;
+    const int64_t n_blocks = ((n_tiles + 7) / 8) * 8 * (p.CoutP / G::CO_BLK) * q.ksplit;
+    TTS_REQUIRE(n_blocks < ((int64_t)1 << 31), "wino4: %lld blocks", (long long)n_blocks);
+    dim3 grid((unsigned)n_blocks, 1, 1);
     q.compact = compact_order(p.lens_out, p.batch) ? 1 : 0;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
     TTS_CHECK_HIP(hipGetLastError());
