@@ -788,7 +788,7 @@ def main():
                 'algorithmic_bytes_per_step': byts / args.steps})
         else:
             roof = {'bound': 'mfma',
-                    'kernel': ('MFMA conv engine: conv1d_wino4_f32 (Winograd F(4,3) decomposition, k = 7 / 11, C >= 128) + conv1d_wino2_f32 (F(2,3), k = 3) + resblock_pair2 (fused C = 32 / 64 pairs, both phases on F(2,3)) + conv1d_mfma_f32 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
+                    'kernel': ('MFMA conv engine: conv1d_wino4_f32 (Winograd F(4,3) decomposition, k = 3 / 7 / 11, C >= 64) + resblock_pair2 (fused C = 32 / 64 pairs, both phases on F(2,3)) + conv1d_mfma_f32 + convt_mfma_f32' if args.precision == 'f32' else 'split-bf16 octet engine: bfo3_resblock_pair + bfo3_conv1d + bfo3_convt (HiFi-GAN, FastPitch FFT blocks and predictors)') + ' (all instantiations)',
                     'kernel_time_basis': time_basis, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak}
             if args.precision == 'f32':
                 # products the Winograd launches do NOT issue (conv_wino2.hip: k = 3 / 7 / 11 as F(2,3) sub-filters + single taps: 4/6,
@@ -801,9 +801,9 @@ def main():
                 roof['frac_issued'] = issued / peak
                 roof['flops_basis'] = ('`achieved` / `frac`: UN-REDUCED algorithmic FLOPs (2 Cout Cin K per valid output position) over kernel time.  '
                                        '`issued` / `frac_issued`: the same minus the products the Winograd launches do not issue, from the IDEAL product '
-                                       'counts of the routed kernels -- F(4,3) decomposition (conv_wino4.hip: 16/28, 23/44 of the direct products at k = 7 / 11; '
-                                       'HiFi-GAN C >= 128 un-fused), F(2,3) (4/6, 10/14, 16/22: k = 3 at C >= 128, both phases of the fused C = 32 / 64 pairs, '
-                                       'FastPitch decoder conv-FF).  Idle tuple slots at dilation 3 / 5, the fused pairs\' halo recompute and small launches '
+                                       'counts of the routed kernels -- F(4,3) decomposition (conv_wino4.hip: 6/12, 16/28, 23/44 of the direct products at k = 3 / 7 / 11; '
+                                       'every un-fused ResBlock conv of HiFi-GAN (C >= 64) and FastPitch\'s decoder conv-FF), F(2,3) (4/6, 10/14, 16/22: both phases of '
+                                       'the fused pairs -- C = 32 every k, C = 64 k = 3).  Idle tuple slots at dilation 3 / 5, the fused pairs\' halo recompute and small launches '
                                        'routed back to the direct kernel are NOT counted: a LOWER bound on what the MFMA pipe executed.  '
                                        'TTSAMD_WINO=0 runs the direct kernels, TTSAMD_WINO4=0 the round-5 F(2,3) routing')
         roof.update({'traffic': traffic, 'traffic_unit': 'B/launch', 'traffic_source': traffic_src,
@@ -1238,10 +1238,10 @@ def wino_product_ratio(ch, kk, dil=1, fused=None):
     f23 = (4 * (kk // 3) + 2 * (kk % 3)) / (2.0 * kk)
     f43 = {3: 6, 7: 16, 11: 23}[kk] / (4.0 * kk)
     if fused is None:
-        fused = ch <= 32 or (ch <= 128 and kk == 3)            # hifigan.hip: kFused2Mask 04f
+        fused = ch <= 32 or (ch == 64 and kk == 3)             # hifigan.hip: kFused2Mask 00f
     if fused:
         return f23 if os.environ.get('TTSAMD_FUSED2_WB', '1') != '0' else 1.0
-    m4, m2 = _env_int('TTSAMD_WINO4', 14), _env_int('TTSAMD_WINO2', 31)
+    m4, m2 = _env_int('TTSAMD_WINO4', 15), _env_int('TTSAMD_WINO2', 31)
     if (m4 & kbit) and (dil == 1 or (m4 & 8)):
         return f43
     if (m2 & kbit) and (dil == 1 or (m2 & 8)):
@@ -1251,7 +1251,7 @@ def wino_product_ratio(ch, kk, dil=1, fused=None):
 
 def hifigan_wino_saved_flops_per_frame(h):
     """Products per mel frame that the Winograd kernels do not issue (wino_product_ratio per ResBlock conv): the stages with >= 128 channels on
-    csrc/conv_wino4.hip (k = 7 / 11; C >= 64) and conv_wino2.hip (k = 3), both phases of the fused pairs (C = 32 every k, C = 64 / 128 k = 3) on F(2,3)
+    csrc/conv_wino4.hip (F(4,3): every un-fused conv, C >= 64), both phases of the fused pairs (C = 32 every k, C = 64 k = 3) on F(2,3)
     (csrc/resblock_fused2.hip)."""
     ch, mul, f = h['upsample_initial_channel'], 1, 0.0
     for u in h['upsample_rates']:

@@ -757,6 +757,7 @@ def test_fastpitch_deep_splitk_tiles(dev, fastpitch_engine, monkeypatch, ttsopt)
     from ttsamd import synth
     ids = torch.from_numpy(synth.synth_ids(8, 64)).to(dev)
     dur = torch.from_numpy(synth.synth_durations(8, 64)).to(dev)
+    ttsopt.set('TTSAMD_WINO4', '14')            # k = 3 off the F(4,3) kernel (which would take this shape with its own split K): the direct kernel's tiles
     ttsopt.set('TTSAMD_DEEP_SPLITK', '0')
     mel0, dl0, *_ = fastpitch_engine.infer(ids, dur_tgt=dur)
     ttsopt.set('TTSAMD_DEEP_SPLITK', '1')

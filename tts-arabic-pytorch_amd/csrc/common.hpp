@@ -75,10 +75,10 @@ inline hipError_t lds_opt_in(const void* fn, int bytes, std::atomic<uint64_t>& d
     X(HIFIGAN_STREAMS, 0, 0, 1)   /* ResBlock branches of a HiFi-GAN stage on one / three streams (default: by size) */ \
     X(WINO, 0, 0, 1)              /* fp32 engine: 0 = direct kernels only */                                \
     X(WINO2, 0, 0, 31)            /* F(2,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated, 4 = Cout 64 */ \
-    X(WINO4, 0, 0, 15)            /* F(4,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated (default 14) */ \
+    X(WINO4, 0, 0, 15)            /* F(4,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated (default 15) */ \
     X(FUSED_PAIR, 0, 0, 1)        /* fp32 fused c1 -> c2 pairs: 0 = every pair as two launches */           \
     X(FUSED2, 0, 0, 1)            /* second-generation fused pair off / on */                               \
-    X(FUSED2_MASK, 1, 0, 0x1ff)   /* which (C, k) pairs it takes: bit 3 ci + ki (default 04f) */            \
+    X(FUSED2_MASK, 1, 0, 0x1ff)   /* which (C, k) pairs it takes: bit 3 ci + ki (default 00f) */            \
     X(FUSED2_MASK_N1, 1, 0, 0x1ff) /* ... with 128-column direct-arithmetic blocks (default 000) */         \
     X(FUSED2_WB, 0, 0, 2)         /* its Winograd phases: 0 none, 1 phase B, 2 both (default) */            \
     X(CONVT, 0, 0, 1)             /* all-phase transposed conv (convt_mfma.hip) off / on */                 \

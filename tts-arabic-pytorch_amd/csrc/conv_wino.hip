@@ -411,12 +411,12 @@ int wino_route(const ConvParams& p) {
     const char* e = opt_str(OPT_WINO);
     if (e && e[0] == '0') return 0;
     if (p.w_wino4 != nullptr) {
-        // F(4,3) decomposition (conv_wino4.hip): TTSAMD_WINO4=<mask>, bit 0 / 1 / 2 = k 3 / 7 / 11, bit 3 = their dilated convs; default 14
-        // (k = 3 stays on F(2,3): 6 instead of 8 products per quad do not pay for the 32-row wave tiles -- 414 / 330 vs 392 / 315 us on
-        // FastPitch's conv-FF pair, 319 vs 308 us at C = 256).
+        // F(4,3) decomposition (conv_wino4.hip): TTSAMD_WINO4=<mask>, bit 0 / 1 / 2 = k 3 / 7 / 11, bit 3 = their dilated convs; default 15.
+        // (k = 3 -- 6 instead of 8 products per quad -- did not pay with the kernel's first staging path: 414 / 330 vs 392 / 315 us on
+        // FastPitch's conv-FF pair; with the aligned 16-byte window loads it does: same-box A/B of the step 55.46 (mask 14) vs 54.68 ms.)
         // 64 rows x 64 quads per block, float4-aligned rows, at least 192 blocks (below: the F(2,3) / direct routing that follows)
         const char* e4 = opt_str(OPT_WINO4);
-        const int mask4 = e4 ? atoi(e4) : 14;
+        const int mask4 = e4 ? atoi(e4) : 15;
         const int kbit4 = p.K == 3 ? 1 : (p.K == 7 ? 2 : 4);
         const bool ok4 = (mask4 & kbit4) && (p.dil == 1 || (mask4 & 8)) && (p.K != 3 || p.Cin % 16 == 0) &&
                          (p.dil == 1 || p.dil == 3 || p.dil == 5) && p.pad == p.dil * (p.K - 1) / 2 && p.n_phase == 1 && p.y_ts == 1 &&

@@ -16,11 +16,12 @@
 namespace ttsamd {
 
 // default routing of the second-generation fused pair (fused2_choice below), set from same-box A/B runs of the bench workload
-constexpr unsigned kFused2Mask = 0x04F;       // C = 32: k = 3 / 7 / 11; C = 64 and C = 128: k = 3.  Both convs of these pairs run on Winograd F(2,3) inside the
-                                              // launch (resblock_pair2<..., WM = 2>; C = 128: the 8-wave block).  Round 6: the k = 7 / 11 pairs of C = 64 run
-                                              // un-fused on the F(4,3) kernel (conv_wino4.hip, 64-row blocks = its native tile): same-box A/B 56.72 (07f) /
-                                              // 56.15 (06f: k = 7 un-fused) / 55.00 (05f: k = 11) / 54.81 ms (04f).  Round 5 on F(2,3): C = 64 k = 11 fused
-                                              // 61.93 vs 62.45; C = 128 k = 3 fused 63.90 vs 64.06, + k = 7 64.23, + k = 11 65.36
+constexpr unsigned kFused2Mask = 0x00F;       // C = 32: k = 3 / 7 / 11; C = 64: k = 3.  Both convs of these pairs run on Winograd F(2,3) inside the launch
+                                              // (resblock_pair2<..., WM = 2>).  Round 6: every other pair runs un-fused on the F(4,3) kernel (conv_wino4.hip,
+                                              // 64-row blocks): same-box A/B of the bench step (tools/ab_env.sh) 56.72 (07f, k = 7 / 11 only on F(4,3)) / 56.15
+                                              // (06f) / 55.00 (05f) / 54.81 ms (04f); then with k = 3 on F(4,3) too: 54.68 (04f) / 55.11 (047: C = 64 k = 3
+                                              // un-fused) / 54.59 (007) / 54.10 ms (00f: C = 128 k = 3 un-fused).  Round 5 on F(2,3): C = 64 k = 11 fused 61.93 vs
+                                              // 62.45; C = 128 k = 3 fused 63.90 vs 64.06
 constexpr unsigned kFused2MaskN1 = 0x000;     // 128-column blocks (the direct-arithmetic kernels only): none by default
 constexpr int64_t kFused2SmallColumns = 2 * 256 * 252;   // batch x positions under which a stage counts as a small problem
 
