@@ -104,6 +104,19 @@ struct Wino4Geo {
     __host__ __device__ static constexpr int tw0v(int ph) { return DAV + 2 * nljv(ph); }       // two activation jobs per vector, one per gap
     __host__ __device__ static constexpr int wsv(int ph) { return (ngap(ph) - tw0v(ph)) / nwj(ph); }
     static_assert(wsv(0) >= 1 && wsv(NPH - 1) >= 1, "one write job per gap at most (vector loads)");
+    // dilation 3 / 5, k = 7 / 11 (LP = 2 kernels): each wave fetches its two channel rows of the block's window CONTIGUOUSLY (80 aligned
+    // 16-byte vectors per row = 320 positions >= 240 + 13 x 5 + 3), activates them, parks them in a private LDS strip and reads its
+    // tuples' positions back at stride d (4-byte LDS reads instead of one 64-lane dword load per position through the L1: the dilated
+    // launches sat at 63-76 % matrix-pipe busy against 77-82 % of the dilation-1 ones).  Same wave writes and reads: no block barrier.
+    static constexpr int RAWW = 320;                                  // positions per row of the strip
+    static constexpr int RAW_BYTES = 4 * (2 * RAWW * 4 + 16);         // four waves x (two rows + a dump slot for the idle lanes of the second load)
+    static constexpr int DAT = K == 11 ? 12 : 16;                     // gaps between the row loads and their activation
+    __host__ __device__ static constexpr int nrj(int ph) { return 2 * ((npos(ph) + 1) / 2); }  // LDS read jobs: (pp, position pair)
+    __host__ __device__ static constexpr bool loads_in(int ph) { return ph == 0; }              // the rows are fetched once per chunk
+    __host__ __device__ static constexpr int tr_r0(int ph) { return loads_in(ph) ? DAT + 4 : 0; }            // first read job
+    __host__ __device__ static constexpr int tw0t(int ph) { return tr_r0(ph) + nrj(ph) + 1; }                 // first plane write
+    __host__ __device__ static constexpr int wst(int ph) { return (ngap(ph) - tw0t(ph)) / nwj(ph); }
+    static_assert(NOCT != 1 || (wst(0) >= 1 && wst(NPH - 1) >= 1), "one write job per gap at most (strip path)");
     static_assert((NOCT * ngq(0)) % PF == 0 && (NOCT * ngq(NPH - 1)) % PF == 0, "queue slots line up across steps");
     static_assert(ws(0) >= 1 && ws(NPH - 1) >= 1, "one write job per gap at most");
     static_assert((size_t)NSTAGE * BUF4 * 16 <= 80 * 1024, "two blocks per CU");
@@ -113,13 +126,14 @@ struct Wino4Geo {
 // outputs per tile at dilation d: the largest multiple of 4 d in 4 * ntup
 __device__ __host__ constexpr int wino4_tile(int d, int ntup) { return (4 * ntup / (4 * d)) * (4 * d); }
 
-template <int K, int NOCT_, int NSTAGE_, int EPI, bool D1>
+template <int K, int NOCT_, int NSTAGE_, int EPI, int LP>
 __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     using G = Wino4Geo<K, NOCT_, NSTAGE_, EPI>;
     constexpr int WN = G::WN, NSF = G::NSF, NOCT = G::NOCT, NSTAGE = G::NSTAGE, NPL = G::NPL, NGPM = G::NGPM;
     constexpr int CO_BLK = G::CO_BLK, NTUP = G::NTUP, NT_BLK = G::NT_BLK, PF = G::PF;
     constexpr int NPH = G::NPH, NPOSP = G::NPOSP, NM = G::NM, DA = G::DA, LPG = G::LPG;
+    constexpr bool D1 = LP == 1, TR = LP == 2;      // window loads: 0 one dword per position, 1 aligned vectors (dilation 1), 2 LDS strip
     const int dil = D1 ? 1 : p.dil;
     const int nt_eff = wino4_tile(dil, NTUP), ntup_eff = nt_eff / 4;
     // Block -> (time tile, row block, C-in slice).  The 1-D grid is dealt to the 8 XCDs round-robin (workgroup s runs on XCD s % 8, each
@@ -270,6 +284,39 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         sx[ol_][mi_].x = bfo_lrelu(sx[ol_][mi_].x, in_slope);                                       \
         sx[ol_][mi_].y = bfo_lrelu(sx[ol_][mi_].y, in_slope);                                        \
     }
+    // LP = 2: row job J -> (pp, vector set): lane l fetches vector l (set 0) or 64 + l (set 1: lanes 0..15) of row pp; positions A + 4 v .. + 3,
+    // A = the window start rounded down to a multiple of 4 (a vector is then entirely left of position 0 or not at all)
+    float* const strip = reinterpret_cast<float*>(smem4 + NSTAGE * G::BUF4) + wid * (2 * G::RAWW + 4);
+    const int tr_a = (q0 - pad_c * dil) & ~3;                 // position of strip column 0
+    const int tr_off = q0 + (dil == 1 ? 4 * spe : (spe / dil) * 4 * dil + spe % dil) - pad_c * dil - tr_a;   // strip column of the lane's position 0
+    w4_f32x4 rv[2][2];
+#define TTS_TLOAD_JOB(J, XSO)                                                                        \
+    {                                                                                                \
+        const int pp_ = (J) / 2, vs_ = (J) % 2;                                                      \
+        const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + 2 * pp_ * x_cs), (unsigned)in_len * 4u); \
+        const int v_ = lane + 64 * vs_;                                                              \
+        rv[pp_][vs_] = __builtin_bit_cast(w4_f32x4, bfo_ld16(xrs_, (vs_ == 1 && lane >= 16) ? BFO_OOB : (tr_a + 4 * v_) * 4, 0, 0)); \
+    }
+    // ... activation + the 16-byte strip write (idle lanes of set 1 write the dump slot behind the rows)
+#define TTS_TSTORE_JOB(J)                                                                            \
+    {                                                                                                \
+        const int pp_ = (J) / 2, vs_ = (J) % 2;                                                      \
+        w4_f32x4 a_ = rv[pp_][vs_];                                                                  \
+        a_.x = bfo_lrelu(a_.x, in_slope); a_.y = bfo_lrelu(a_.y, in_slope);                          \
+        a_.z = bfo_lrelu(a_.z, in_slope); a_.w = bfo_lrelu(a_.w, in_slope);                          \
+        const int v_ = lane + 64 * vs_;                                                              \
+        float* dst_ = (vs_ == 1 && lane >= 16) ? strip + 2 * G::RAWW : strip + pp_ * G::RAWW + 4 * v_;    \
+        *reinterpret_cast<w4_f32x4*>(dst_) = a_;                                                     \
+    }
+    // ... read job J of phase PH -> (pp, positions 2 jp, 2 jp + 1 of the phase's window) into the staged values
+#define TTS_TREAD_JOB(PH, J)                                                                         \
+    {                                                                                                \
+        const int npr_ = (G::npos(PH) + 1) / 2;                                                      \
+        const int pp_ = (J) / npr_, jp_ = (J) % npr_;                                                \
+        const float* src_ = strip + pp_ * G::RAWW + tr_off + (G::mlo(PH) + 2 * jp_) * dil;           \
+        sx[0][2 * jp_][pp_] = src_[0];                                                               \
+        if (2 * jp_ + 1 < G::npos(PH)) sx[0][2 * jp_ + 1][pp_] = src_[dil];                          \
+    }
     // plane g of octet ol from the staged values.  Job J -> (octet, group of the phase)
 #define TTS_SXV(M) (w4_f32x2{sv[ol_][0][G::fdiv4((M) - pad_c) - G::vlo(PH_)][((M) - pad_c) - 4 * G::fdiv4((M) - pad_c)],     \
                              sv[ol_][1][G::fdiv4((M) - pad_c) - G::vlo(PH_)][((M) - pad_c) - 4 * G::fdiv4((M) - pad_c)]})
@@ -315,6 +362,15 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
                 for (int J = 0; J < G::nljv(ph); ++J) TTS_VLOAD_JOB(ph, J, xso)
 #pragma unroll
                 for (int J = 0; J < 2 * G::nljv(ph); ++J) TTS_VACT_JOB(ph, J)
+            } else if constexpr (TR) {
+                if (G::loads_in(ph)) {
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) TTS_TLOAD_JOB(J, xso)
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) TTS_TSTORE_JOB(J)
+                }
+#pragma unroll
+                for (int J = 0; J < G::nrj(ph); ++J) TTS_TREAD_JOB(ph, J)
             } else {
 #pragma unroll
                 for (int J = 0; J < G::nlj(ph); ++J) TTS_LOAD_JOB(ph, J, xso)
@@ -370,6 +426,12 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
                         if (!(TTS_W4_EXP & 4) && t >= G::tw0v(tph) && (t - G::tw0v(tph)) % G::wsv(tph) == 0 &&
                             (t - G::tw0v(tph)) / G::wsv(tph) < G::nwj(tph))
                             TTS_WRITE_JOB(tph, (t - G::tw0v(tph)) / G::wsv(tph), wr)
+                    } else if constexpr (TR) {
+                        if (G::loads_in(tph) && t < 4) TTS_TLOAD_JOB(t, xso)
+                        if (G::loads_in(tph) && t >= G::DAT && t < G::DAT + 4) TTS_TSTORE_JOB(t - G::DAT)
+                        if (t >= G::tr_r0(tph) && t - G::tr_r0(tph) < G::nrj(tph)) TTS_TREAD_JOB(tph, t - G::tr_r0(tph))
+                        if (t >= G::tw0t(tph) && (t - G::tw0t(tph)) % G::wst(tph) == 0 && (t - G::tw0t(tph)) / G::wst(tph) < G::nwj(tph))
+                            TTS_WRITE_JOB(tph, (t - G::tw0t(tph)) / G::wst(tph), wr)
                     } else {
 #pragma unroll
                         for (int u = 0; u < LPG; ++u)
@@ -389,6 +451,9 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
             stage = stage_next;
         }
     }
+#undef TTS_TLOAD_JOB
+#undef TTS_TSTORE_JOB
+#undef TTS_TREAD_JOB
 #undef TTS_VLOAD_JOB
 #undef TTS_VACT_JOB
 #undef TTS_VJOB_IDX
@@ -528,15 +593,16 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     }
 }
 
-template <int K, int NOCT, int NSTAGE, int EPI, bool D1>
+template <int K, int NOCT, int NSTAGE, int EPI, int LP>
 static int32_t launch_wino4_epi(const ConvParams& p, hipStream_t stream) {
     using G = Wino4Geo<K, NOCT, NSTAGE, EPI>;
     constexpr size_t ring = (size_t)G::NSTAGE * G::BUF4 * sizeof(float4);
     constexpr size_t epi = ((size_t)G::CO_BLK * G::NT_BLK + G::CO_BLK) * sizeof(float);
-    constexpr size_t lds = ring > epi ? ring : epi;
+    constexpr size_t strip = LP == 2 ? (size_t)G::RAW_BYTES : 0;
+    constexpr size_t lds = ring + strip > epi ? ring + strip : epi;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static std::atomic<uint64_t> lds_done{0};
-    const auto kern = conv1d_wino4_f32<K, NOCT, NSTAGE, EPI, D1>;
+    const auto kern = conv1d_wino4_f32<K, NOCT, NSTAGE, EPI, LP>;
     TTS_CHECK_HIP(lds_opt_in((const void*)kern, (int)lds, lds_done));
     const int nt = wino4_tile(p.dil, G::NTUP);
     ConvParams q = p;
@@ -558,10 +624,12 @@ static int32_t launch_wino4_cfg(const ConvParams& p, hipStream_t stream) {
     // residual preload (16-byte loads of the lane's quad): dilation 1 -- every c2 conv of a ResBlock, the second conv-FF conv
     // dilation 1: the window as aligned 16-byte vectors (D1)
     if (p.dil == 1) {
-        if (p.res != nullptr && wino4_ksplit(p) == 1) return launch_wino4_epi<K, NOCT, NSTAGE, 3, true>(p, stream);
-        return launch_wino4_epi<K, NOCT, NSTAGE, 0, true>(p, stream);
+        if (p.res != nullptr && wino4_ksplit(p) == 1) return launch_wino4_epi<K, NOCT, NSTAGE, 3, 1>(p, stream);
+        return launch_wino4_epi<K, NOCT, NSTAGE, 0, 1>(p, stream);
     }
-    return launch_wino4_epi<K, NOCT, NSTAGE, 0, false>(p, stream);
+    // dilation 3 / 5: k = 7 / 11 through the per-wave LDS strip (two stages: the strip takes 10 KB), k = 3 one dword per position
+    if constexpr (K == 3) return launch_wino4_epi<K, NOCT, NSTAGE, 0, 0>(p, stream);
+    else return launch_wino4_epi<K, NOCT, 2, 0, 2>(p, stream);
 }
 
 int32_t launch_wino4(const ConvParams& p, hipStream_t stream) {
