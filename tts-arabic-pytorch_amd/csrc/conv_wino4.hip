@@ -21,8 +21,10 @@
 // 4.2e-6; tolerance 1e-4 / 1e-3).  tests/test_gpu_wino.py checks the kernel itself against float64.
 // Reference ops: vocoder/hifigan/models.py:30-53 (ResBlock1 convs), models/fastpitch/fastpitch/transformer.py:59-65 (conv-FF).
 //
-// Anatomy = conv_wino2.hip's (weights L2 -> register queue, LDS = the transformed planes only, range-checked row loads, one
-// activation per loaded value pair, single-instruction jobs in the gaps between MFMAs) with MT = 1: six or eight 32 x 32 planes per
+// Anatomy = conv_wino2.hip's (weights L2 -> register queue four groups ahead, LDS = the transformed planes only, halo zeros from the buffer
+// range check, one activation per loaded value, single-instruction jobs in the gaps between MFMAs) with two differences.  The WINDOW is
+// fetched as 16-byte vectors -- per lane at dilation 1, per wave through a private LDS strip at dilation 3 / 5 (Wino4Geo) -- because one
+// dword per position and lane (conv_wino2's way) saturates the L1 path at this kernel's MFMA count per staged value.  And MT = 1: six or eight 32 x 32 planes per
 // wave are 96 / 128 accumulator registers, so a wave owns ONE 32-row tile x 32 tuples; block = 2 x 2 waves = 64 rows x 64 tuples
 // (256 outputs).  k = 11 runs its 23 groups in two PHASES (12 + 11) so that two stages fit 48 KB; its packed weights carry a 24th
 // all-zero group that is fetched (queue slots line up) and never multiplied.
@@ -65,7 +67,6 @@ struct Wino4Geo {
     static constexpr int PF = 4;                                     // weight groups in flight ahead of the one being multiplied (16 MFMAs ~ 1000 cycles;
                                                                      // two groups -- 512 cycles, under the L2 latency -- measured 59-70 % matrix-pipe busy)
     static constexpr int NM = 4;                                     // MFMAs per operand group (the four channel pairs of the octet)
-    static constexpr int DA = 16;                                    // a value is activated 16 MFMAs (~1000 cycles) after its load was issued
     __host__ __device__ static constexpr int glo(int ph) { return NPH == 1 ? 0 : 12 * ph; }
     __host__ __device__ static constexpr int ngp(int ph) { return NPH == 1 ? NG : (ph == 0 ? 12 : NG - 12); }     // multiplied
     __host__ __device__ static constexpr int ngq(int ph) { return NPH == 1 ? NGQ : 12; }                          // fetched
@@ -86,11 +87,7 @@ struct Wino4Geo {
     __host__ __device__ static constexpr int npos(int ph) { return mhi(ph) - mlo(ph) + 1; }
     static constexpr int NPOSP = npos(0) > npos(NPH - 1) ? npos(0) : npos(NPH - 1);
     __host__ __device__ static constexpr int ngap(int ph) { return NOCT * ngp(ph) * NM; }     // gaps (one per MFMA) of a step
-    __host__ __device__ static constexpr int nlj(int ph) { return NOCT * 2 * npos(ph); }      // load jobs (one value each)
     __host__ __device__ static constexpr int nwj(int ph) { return NOCT * ngp(ph); }           // write jobs (one plane each)
-    static constexpr int LPG = 3 * (NOCT * 2 * NPOSP) > ngap(NPH - 1) ? 2 : 1;                // loads per gap
-    __host__ __device__ static constexpr int tw0(int ph) { return (nlj(ph) + LPG - 1) / LPG + DA; }    // first gap with every value activated
-    __host__ __device__ static constexpr int ws(int ph) { return (ngap(ph) - tw0(ph)) / nwj(ph); }     // one plane write every ws gaps after it
     // dilation 1 (D1 kernels): the window is fetched as ALIGNED 16-byte vectors -- vector v of a lane = positions 4 (tuple + v) .. + 3 of the
     // row (a vector is entirely left of position 0 -> zeros by the range check, which drops a WHOLE dwordx4 whose first dword is out of range
     // and checks the right edge dword by dword: tools/buf_range_probe.hip) -- instead of one dword per position: a wave instruction then
@@ -109,16 +106,16 @@ struct Wino4Geo {
     // tuples' positions back at stride d (4-byte LDS reads instead of one 64-lane dword load per position through the L1: the dilated
     // launches sat at 63-76 % matrix-pipe busy against 77-82 % of the dilation-1 ones).  Same wave writes and reads: no block barrier.
     static constexpr int RAWW = 320;                                  // positions per row of the strip
-    static constexpr int RAW_BYTES = 4 * (2 * RAWW * 4 + 16);         // four waves x (two rows + a dump slot for the idle lanes of the second load)
-    static constexpr int DAT = K == 11 ? 12 : 16;                     // gaps between the row loads and their activation
-    __host__ __device__ static constexpr int nrj(int ph) { return 2 * ((npos(ph) + 1) / 2); }  // LDS read jobs: (pp, position pair)
+    static constexpr int NROW = 2 * NOCT;                             // channel rows a wave stages per chunk
+    static constexpr int RAW_BYTES = 4 * (NROW * RAWW * 4 + 16);      // four waves x (their rows + a dump slot for the idle lanes of the second load)
+    static constexpr int DAT = K == 7 ? 16 : (K == 11 ? 12 : 8);      // gaps between the row loads and their activation
+    __host__ __device__ static constexpr int nrj(int ph) { return NROW * ((npos(ph) + 1) / 2); }  // LDS read jobs: (row, position pair)
     __host__ __device__ static constexpr bool loads_in(int ph) { return ph == 0; }              // the rows are fetched once per chunk
-    __host__ __device__ static constexpr int tr_r0(int ph) { return loads_in(ph) ? DAT + 4 : 0; }            // first read job
+    __host__ __device__ static constexpr int tr_r0(int ph) { return loads_in(ph) ? DAT + 2 * NROW : 0; }      // first read job
     __host__ __device__ static constexpr int tw0t(int ph) { return tr_r0(ph) + nrj(ph) + 1; }                 // first plane write
     __host__ __device__ static constexpr int wst(int ph) { return (ngap(ph) - tw0t(ph)) / nwj(ph); }
-    static_assert(NOCT != 1 || (wst(0) >= 1 && wst(NPH - 1) >= 1), "one write job per gap at most (strip path)");
+    static_assert(wst(0) >= 1 && wst(NPH - 1) >= 1, "one write job per gap at most (strip path)");
     static_assert((NOCT * ngq(0)) % PF == 0 && (NOCT * ngq(NPH - 1)) % PF == 0, "queue slots line up across steps");
-    static_assert(ws(0) >= 1 && ws(NPH - 1) >= 1, "one write job per gap at most");
     static_assert((size_t)NSTAGE * BUF4 * 16 <= 80 * 1024, "two blocks per CU");
     static_assert(NPH == 1 || NOCT == 1, "phases split an octet's groups");
 };
@@ -132,8 +129,9 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     using G = Wino4Geo<K, NOCT_, NSTAGE_, EPI>;
     constexpr int WN = G::WN, NSF = G::NSF, NOCT = G::NOCT, NSTAGE = G::NSTAGE, NPL = G::NPL, NGPM = G::NGPM;
     constexpr int CO_BLK = G::CO_BLK, NTUP = G::NTUP, NT_BLK = G::NT_BLK, PF = G::PF;
-    constexpr int NPH = G::NPH, NPOSP = G::NPOSP, NM = G::NM, DA = G::DA, LPG = G::LPG;
-    constexpr bool D1 = LP == 1, TR = LP == 2;      // window loads: 0 one dword per position, 1 aligned vectors (dilation 1), 2 LDS strip
+    constexpr int NPH = G::NPH, NPOSP = G::NPOSP, NM = G::NM;
+    constexpr bool D1 = LP == 1, TR = LP == 2;      // window loads: 1 aligned vectors per lane (dilation 1), 2 per-wave LDS strip (dilation 3 / 5)
+    static_assert(D1 || TR, "window path");
     const int dil = D1 ? 1 : p.dil;
     const int nt_eff = wino4_tile(dil, NTUP), ntup_eff = nt_eff / 4;
     // Block -> (time tile, row block, C-in slice).  The 1-D grid is dealt to the 8 XCDs round-robin (workgroup s runs on XCD s % 8, each
@@ -173,7 +171,6 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     const int n_groups = (p.Cin / 8) * G::NGQ;                // groups of the whole conv in the packed weights
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
     const float in_slope = p.in_slope;
-    const int pad = (K - 1) / 2;
 
     float ep_bias = 0.f;
     if (tid < CO_BLK && p.bias) ep_bias = p.bias[min(co_blk0 + tid, p.Cout - 1)];
@@ -235,25 +232,14 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     // [ol][kks][g][pc].  (h, kks) = the wave index: a wave instruction reads ONE channel row, so the row is the base of a raw buffer
     // descriptor of in_len * 4 bytes and the load's range check returns the zeros of the halo (conv_wino2.hip).
     const int sh = __builtin_amdgcn_readfirstlane((tid >> 7) & 1), skk = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);
-    w4_f32x2 sx[D1 ? 1 : NOCT][D1 ? 1 : NPOSP];              // [pp] = the two channels of the item, packed (one dword per position)
+    w4_f32x2 sx[D1 ? 1 : NOCT][D1 ? 1 : NPOSP];              // strip path: [pp] = the two channels of the item, one entry per position of the phase
     w4_f32x4 sv[D1 ? NOCT : 1][2][D1 ? G::NVP : 1];          // D1: [octet][pp][vector]
     w4_f32x2 ta[NOCT], tb[NOCT];                             // partial sums shared by two consecutive plane jobs
     const int spe = min(lane, ntup_eff - 1);                 // idle tuple slots (d > 1) repeat the last tuple: never stored
-    const int xv0 = (q0 + (dil == 1 ? 4 * spe : (spe / dil) * 4 * dil + spe % dil) - pad * dil) * 4;
-    const int xvd = 4 * dil;
     const int xw0 = (q0 + 4 * lane) * 4;                      // D1: byte offset of the lane's vector 0 in its row
     constexpr int pad_c = (K - 1) / 2;
     const int ch_off = (4 * sh + skk) * x_cs;                 // channel 2 (2 h) + kks; pp adds 2 rows, the octet 8
 
-#define TTS_JOB_IDX(PH, J)                                                                           \
-        const int np_ = G::npos(PH);                                                                 \
-        const int ol_ = (J) / (2 * np_), mi_ = ((J) / 2) % np_, pp_ = (J) % 2;
-#define TTS_LOAD_JOB(PH, J, XSO)                                                                     \
-    {                                                                                                \
-        TTS_JOB_IDX(PH, J)                                                                           \
-        const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + (8 * ol_ + 2 * pp_) * x_cs), (unsigned)in_len * 4u);     \
-        sx[ol_][mi_][pp_] = bfo_ld4f(xrs_, xv0 + xvd * (G::mlo(PH) + mi_), 0, 0);                   \
-    }
     // D1: vector job J -> (octet, pp, vector)
 #define TTS_VJOB_IDX(PH, J)                                                                          \
         const int nv_ = G::nvec(PH);                                                                 \
@@ -276,24 +262,16 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
             sv[ol_][pp_][vi_].w = bfo_lrelu(sv[ol_][pp_][vi_].w, in_slope);                          \
         }                                                                                            \
     }
-    // leaky-relu on load, once per value pair, after its second load (slopes in [0, 1]: max(x, slope x); slope 1 = the identity, exactly)
-#define TTS_ACT_JOB(PH, J)                                                                           \
-    if ((J) & 1) {                                                                                   \
-        TTS_JOB_IDX(PH, J)                                                                           \
-        (void)pp_;                                                                                   \
-        sx[ol_][mi_].x = bfo_lrelu(sx[ol_][mi_].x, in_slope);                                       \
-        sx[ol_][mi_].y = bfo_lrelu(sx[ol_][mi_].y, in_slope);                                        \
-    }
     // LP = 2: row job J -> (pp, vector set): lane l fetches vector l (set 0) or 64 + l (set 1: lanes 0..15) of row pp; positions A + 4 v .. + 3,
     // A = the window start rounded down to a multiple of 4 (a vector is then entirely left of position 0 or not at all)
-    float* const strip = reinterpret_cast<float*>(smem4 + NSTAGE * G::BUF4) + wid * (2 * G::RAWW + 4);
+    float* const strip = reinterpret_cast<float*>(smem4 + NSTAGE * G::BUF4) + wid * (G::NROW * G::RAWW + 4);
     const int tr_a = (q0 - pad_c * dil) & ~3;                 // position of strip column 0
     const int tr_off = q0 + (dil == 1 ? 4 * spe : (spe / dil) * 4 * dil + spe % dil) - pad_c * dil - tr_a;   // strip column of the lane's position 0
-    w4_f32x4 rv[2][2];
+    w4_f32x4 rv[TR ? G::NROW : 1][2];                          // row = 2 octet + pp
 #define TTS_TLOAD_JOB(J, XSO)                                                                        \
     {                                                                                                \
         const int pp_ = (J) / 2, vs_ = (J) % 2;                                                      \
-        const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + 2 * pp_ * x_cs), (unsigned)in_len * 4u); \
+        const bfo_i4 xrs_ = bfo_rsrc(xb + ((XSO) + ch_off + (8 * (pp_ / 2) + 2 * (pp_ % 2)) * x_cs), (unsigned)in_len * 4u); \
         const int v_ = lane + 64 * vs_;                                                              \
         rv[pp_][vs_] = __builtin_bit_cast(w4_f32x4, bfo_ld16(xrs_, (vs_ == 1 && lane >= 16) ? BFO_OOB : (tr_a + 4 * v_) * 4, 0, 0)); \
     }
@@ -305,7 +283,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         a_.x = bfo_lrelu(a_.x, in_slope); a_.y = bfo_lrelu(a_.y, in_slope);                          \
         a_.z = bfo_lrelu(a_.z, in_slope); a_.w = bfo_lrelu(a_.w, in_slope);                          \
         const int v_ = lane + 64 * vs_;                                                              \
-        float* dst_ = (vs_ == 1 && lane >= 16) ? strip + 2 * G::RAWW : strip + pp_ * G::RAWW + 4 * v_;    \
+        float* dst_ = (vs_ == 1 && lane >= 16) ? strip + G::NROW * G::RAWW : strip + pp_ * G::RAWW + 4 * v_;    \
         *reinterpret_cast<w4_f32x4*>(dst_) = a_;                                                     \
     }
     // ... read job J of phase PH -> (pp, positions 2 jp, 2 jp + 1 of the phase's window) into the staged values
@@ -314,8 +292,8 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         const int npr_ = (G::npos(PH) + 1) / 2;                                                      \
         const int pp_ = (J) / npr_, jp_ = (J) % npr_;                                                \
         const float* src_ = strip + pp_ * G::RAWW + tr_off + (G::mlo(PH) + 2 * jp_) * dil;           \
-        sx[0][2 * jp_][pp_] = src_[0];                                                               \
-        if (2 * jp_ + 1 < G::npos(PH)) sx[0][2 * jp_ + 1][pp_] = src_[dil];                          \
+        sx[pp_ / 2][2 * jp_][pp_ % 2] = src_[0];                                                     \
+        if (2 * jp_ + 1 < G::npos(PH)) sx[pp_ / 2][2 * jp_ + 1][pp_ % 2] = src_[dil];                \
     }
     // plane g of octet ol from the staged values.  Job J -> (octet, group of the phase)
 #define TTS_SXV(M) (w4_f32x2{sv[ol_][0][G::fdiv4((M) - pad_c) - G::vlo(PH_)][((M) - pad_c) - 4 * G::fdiv4((M) - pad_c)],     \
@@ -362,20 +340,15 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
                 for (int J = 0; J < G::nljv(ph); ++J) TTS_VLOAD_JOB(ph, J, xso)
 #pragma unroll
                 for (int J = 0; J < 2 * G::nljv(ph); ++J) TTS_VACT_JOB(ph, J)
-            } else if constexpr (TR) {
+            } else {
                 if (G::loads_in(ph)) {
 #pragma unroll
-                    for (int J = 0; J < 4; ++J) TTS_TLOAD_JOB(J, xso)
+                    for (int J = 0; J < 2 * G::NROW; ++J) TTS_TLOAD_JOB(J, xso)
 #pragma unroll
-                    for (int J = 0; J < 4; ++J) TTS_TSTORE_JOB(J)
+                    for (int J = 0; J < 2 * G::NROW; ++J) TTS_TSTORE_JOB(J)
                 }
 #pragma unroll
                 for (int J = 0; J < G::nrj(ph); ++J) TTS_TREAD_JOB(ph, J)
-            } else {
-#pragma unroll
-                for (int J = 0; J < G::nlj(ph); ++J) TTS_LOAD_JOB(ph, J, xso)
-#pragma unroll
-                for (int J = 0; J < G::nlj(ph); ++J) TTS_ACT_JOB(ph, J)
             }
             w4_f32x2* wr = sW + 2 * st * G::BUF4;
 #pragma unroll
@@ -417,7 +390,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     acc[plane] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m], bv[m], acc[plane], 0, 0, 0);
-                    // ---- gap work for the step NSTAGE - 1 ahead: LPG loads per gap first, each value activated DA gaps later, then
+                    // ---- gap work for the step NSTAGE - 1 ahead: the window loads first, each value activated DAV / DAT gaps later, then
                     // the plane writes into the stage the previous step has left
                     const int t = r * NM + m;
                     if constexpr (D1) {
@@ -426,21 +399,12 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
                         if (!(TTS_W4_EXP & 4) && t >= G::tw0v(tph) && (t - G::tw0v(tph)) % G::wsv(tph) == 0 &&
                             (t - G::tw0v(tph)) / G::wsv(tph) < G::nwj(tph))
                             TTS_WRITE_JOB(tph, (t - G::tw0v(tph)) / G::wsv(tph), wr)
-                    } else if constexpr (TR) {
-                        if (G::loads_in(tph) && t < 4) TTS_TLOAD_JOB(t, xso)
-                        if (G::loads_in(tph) && t >= G::DAT && t < G::DAT + 4) TTS_TSTORE_JOB(t - G::DAT)
+                    } else {
+                        if (G::loads_in(tph) && t < 2 * G::NROW) TTS_TLOAD_JOB(t, xso)
+                        if (G::loads_in(tph) && t >= G::DAT && t < G::DAT + 2 * G::NROW) TTS_TSTORE_JOB(t - G::DAT)
                         if (t >= G::tr_r0(tph) && t - G::tr_r0(tph) < G::nrj(tph)) TTS_TREAD_JOB(tph, t - G::tr_r0(tph))
                         if (t >= G::tw0t(tph) && (t - G::tw0t(tph)) % G::wst(tph) == 0 && (t - G::tw0t(tph)) / G::wst(tph) < G::nwj(tph))
                             TTS_WRITE_JOB(tph, (t - G::tw0t(tph)) / G::wst(tph), wr)
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < LPG; ++u)
-                            if (!(TTS_W4_EXP & 1) && t * LPG + u < G::nlj(tph)) TTS_LOAD_JOB(tph, t * LPG + u, xso)
-#pragma unroll
-                        for (int u = 0; u < LPG; ++u)
-                            if (!(TTS_W4_EXP & 2) && t >= DA && (t - DA) * LPG + u < G::nlj(tph)) TTS_ACT_JOB(tph, (t - DA) * LPG + u)
-                        if (!(TTS_W4_EXP & 4) && t >= G::tw0(tph) && (t - G::tw0(tph)) % G::ws(tph) == 0 && (t - G::tw0(tph)) / G::ws(tph) < G::nwj(tph))
-                            TTS_WRITE_JOB(tph, (t - G::tw0(tph)) / G::ws(tph), wr)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -458,9 +422,6 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
 #undef TTS_VACT_JOB
 #undef TTS_VJOB_IDX
 #undef TTS_SXV
-#undef TTS_LOAD_JOB
-#undef TTS_ACT_JOB
-#undef TTS_JOB_IDX
 #undef TTS_SX
 #undef TTS_WRITE_JOB
 
@@ -627,9 +588,8 @@ static int32_t launch_wino4_cfg(const ConvParams& p, hipStream_t stream) {
         if (p.res != nullptr && wino4_ksplit(p) == 1) return launch_wino4_epi<K, NOCT, NSTAGE, 3, 1>(p, stream);
         return launch_wino4_epi<K, NOCT, NSTAGE, 0, 1>(p, stream);
     }
-    // dilation 3 / 5: k = 7 / 11 through the per-wave LDS strip (two stages: the strip takes 10 KB), k = 3 one dword per position
-    if constexpr (K == 3) return launch_wino4_epi<K, NOCT, NSTAGE, 0, 0>(p, stream);
-    else return launch_wino4_epi<K, NOCT, 2, 0, 2>(p, stream);
+    // dilation 3 / 5: the window through the per-wave LDS strip (two stages: the strip takes 10 / 20 KB)
+    return launch_wino4_epi<K, NOCT, 2, 0, 2>(p, stream);
 }
 
 int32_t launch_wino4(const ConvParams& p, hipStream_t stream) {
