@@ -949,6 +949,9 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
                                 'split-bf16 MFMA on the octet engine (bfo3_*)')
         c3x['ms_per_step_one_stream'] = small_config(B, prec='bf16x3')['ms_per_step']
         res.append(c3x)
+        for b_small in (8, 1):                      # north star: batch 1 / 8 / 32 -- the in-tolerance mode at the small batches too (latency, one stream)
+            res.append(small_config(b_small, prec='bf16x3', name=f'C3 at batch {b_small} inside the tolerance: FastPitch+HiFi-GAN, synthetic 64-phoneme, split-bf16 MFMA'
+                                                                 + (' (FastPitch of a batch <= 2 call on the fp32 kernels)' if b_small <= 2 else '')))
         b_full = 256
         ids256 = torch.from_numpy(synth.synth_ids(b_full, ids.shape[1])).to(dev)
         dur256 = torch.from_numpy(synth.synth_durations(b_full, ids.shape[1])).to(dev)
@@ -958,7 +961,7 @@ def extra_configs(args, dev, fp, hg, ids, dur, hop, small_config, wall_roofline,
     except Exception as e:                                       # noqa: BLE001
         res.append({'config': 'C3 split-bf16', 'error': str(e)[:300]})
     torch.cuda.empty_cache()
-    lap('C3 (bf16 32 / 8 / 1 / 256, bf16x3 32 / 256)')
+    lap('C3 (bf16 32 / 8 / 1 / 256, bf16x3 32 / 8 / 1 / 256)')
     n = max(args.steps, 10)
     hgf = hifigan_flops_per_frame(HIFIGAN_CONFIG)
     # ---- C4
