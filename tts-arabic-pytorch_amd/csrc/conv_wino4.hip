@@ -607,13 +607,8 @@ int wino4_block_outputs(int dil) { return wino4_tile(dil, 64); }
 int wino4_ksplit(const ConvParams& p) {
     const int bo = wino4_block_outputs(p.dil);
     const int64_t blocks = (int64_t)((p.Nout + bo - 1) / bo) * (p.CoutP / 64) * p.batch;
-#ifdef TTS_EXPERIMENT      /* (std::getenv directly: exp_env is an inline function, one definition per library) */
-    static const int sk_blocks = [] { const char* e = std::getenv("TTSAMD_W4_SPLITK_BLOCKS"); return e ? atoi(e) : 192; }();
-    static const int sk_target = [] { const char* e = std::getenv("TTSAMD_W4_SPLITK_TARGET"); return e ? atoi(e) : 224; }();
-    if (std::getenv("TTSAMD_W4_SPLITK_LOG")) fprintf(stderr, "wino4 K=%d Cin=%d Nout=%d blocks=%lld\n", p.K, p.Cin, p.Nout, (long long)blocks);
-#else
+    // (more slices / a higher block threshold were measured: no change at batch 1, 2.34-2.40 ms at every setting -- profiles/r6/NOTES.md)
     constexpr int sk_blocks = 192, sk_target = 224;
-#endif
     if (blocks >= sk_blocks || p.splitk_ws == nullptr) return 1;
     const int n_chunks = p.Cin / (p.K == 3 ? 16 : 8);
     const int64_t per = (int64_t)p.batch * p.Cout * p.Nout;
