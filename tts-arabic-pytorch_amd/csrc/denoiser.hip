@@ -95,7 +95,7 @@ __global__ void frame_counts_kernel(const int64_t* __restrict__ ns, int B, int64
 
 // X[b][k][t] = x_reflect[b][t*HOP + k - NFFT/2]      (im2col of the centred, reflect-padded signal)
 __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restrict__ wave, int64_t wave_bs,
-                                                          const int64_t* __restrict__ ns, int F,
+                                                          const int64_t* __restrict__ ns, int F, int Fs,
                                                           float* __restrict__ X) {
     const int b = blockIdx.z, k = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -112,17 +112,17 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restric
         i = min(max(i, 0), max(n - 1, 0));
         v = n > 0 ? wave[(int64_t)b * wave_bs + i] : 0.f;
     }
-    X[((int64_t)b * NFFT + k) * F + t] = v;
+    X[((int64_t)b * NFFT + k) * Fs + t] = v;
 }
 
 // S[b][f | NBIN+f][t] *= max(0, |S| - strength*bias[f]) / |S|     (denoiser.py:68-71)
 __global__ __launch_bounds__(256) void spec_gain_kernel(float* __restrict__ S, const float* __restrict__ bias,
-                                                        float strength, int F) {
+                                                        float strength, int F, int Fs) {
     const int b = blockIdx.z, f = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= F) return;
-    float* sb = S + (int64_t)b * SPEC_CP * F;
-    const float re = sb[(int64_t)f * F + t], im = sb[(int64_t)(NBIN + f) * F + t];
+    float* sb = S + (int64_t)b * SPEC_CP * Fs;
+    const float re = sb[(int64_t)f * Fs + t], im = sb[(int64_t)(NBIN + f) * Fs + t];
     const float mag = sqrtf(re * re + im * im);
     const float md = fmaxf(mag - bias[f] * strength, 0.f);
     float ore, oim;
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void spec_gain_kernel(float* __restrict__ S, c
         ore = md;      // angle(0) = 0
         oim = 0.f;
     }
-    sb[(int64_t)f * F + t] = ore;
-    sb[(int64_t)(NBIN + f) * F + t] = oim;
+    sb[(int64_t)f * Fs + t] = ore;
+    sb[(int64_t)(NBIN + f) * Fs + t] = oim;
 }
 
 // out[b][m] = sum_t Y[b][m + pad - t*HOP][t] / sum_t w^2[m + pad - t*HOP],  m < HOP*frames - (1024 - 2*pad - HOP)...
@@ -176,7 +176,7 @@ int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* fram
 __global__ void mag_frame0_kernel(const float* __restrict__ S, int F, float* __restrict__ out) {
     const int f = blockIdx.x * 64 + threadIdx.x;
     if (f >= NBIN) return;
-    const float re = S[(int64_t)f * F], im = S[(int64_t)(NBIN + f) * F];
+    const float re = S[(int64_t)f * F], im = S[(int64_t)(NBIN + f) * F];   /* F = the row stride here */
     out[f] = sqrtf(re * re + im * im);
 }
 
@@ -184,10 +184,13 @@ struct DnWs {
     float *X, *S;
     int64_t* frames;
 };
+// row stride of the frame / spectrum matrices: F rounded up to 4 so that every row is 16-byte aligned -- the conv engine then takes its
+// float4 row epilogue and vector loads for the two DFT GEMMs (F = n_max / 256 + 1 is odd for whole-frame lengths: the per-lane epilogue)
+static inline int dn_stride(int F) { return (F + 3) & ~3; }
 
 static void carve(Arena& a, int B, int F, DnWs& w) {
-    w.X = a.take<float>((int64_t)B * NFFT * F);        // frames matrix, reused for the time-domain frames
-    w.S = a.take<float>((int64_t)B * SPEC_CP * F);
+    w.X = a.take<float>((int64_t)B * NFFT * dn_stride(F));        // frames matrix, reused for the time-domain frames
+    w.S = a.take<float>((int64_t)B * SPEC_CP * dn_stride(F));
     w.frames = a.take<int64_t>(B);
 }
 
@@ -203,9 +206,10 @@ static int32_t dft_gemm(const Denoiser* h, bool inverse, const float* x, float* 
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     const int cin = inverse ? SPEC_CP : NFFT, cout = inverse ? NFFT : SPEC_CP;
-    p.x = x; p.x_bs = (int64_t)cin * F; p.x_cs = F;
+    const int Fs = dn_stride(F);
+    p.x = x; p.x_bs = (int64_t)cin * Fs; p.x_cs = Fs;
     p.w = h->dev + (inverse ? h->w_inv : h->w_fwd); p.bias = nullptr;
-    p.y = y; p.y_bs = (int64_t)cout * F; p.y_cs = F; p.y_ts = 1;
+    p.y = y; p.y_bs = (int64_t)cout * Fs; p.y_cs = Fs; p.y_ts = 1;
     p.lens_in = frames; p.lens_out = frames; p.len_in_mul = 1; p.len_out_mul = 1;
     p.Lin = F; p.Nout = F; p.Cin = cin; p.Cout = cout; p.CoutP = cout; p.K = 1;
     p.dil = 1; p.pad = 0; p.n_phase = 1; p.in_slope = 1.f; p.mode = 0; p.div = 1.f; p.batch = B;
@@ -218,7 +222,7 @@ static int32_t dft_gemm(const Denoiser* h, bool inverse, const float* x, float* 
 static int32_t stft(const Denoiser* h, const float* wave, int64_t wave_bs, const int64_t* ns, int B, int F,
                     const DnWs& w, hipStream_t s) {
     hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ns, B, w.frames);
-    hipLaunchKernelGGL(stft_frames_kernel, dim3((F + 255) / 256, NFFT, B), dim3(256), 0, s, wave, wave_bs, ns, F, w.X);
+    hipLaunchKernelGGL(stft_frames_kernel, dim3((F + 255) / 256, NFFT, B), dim3(256), 0, s, wave, wave_bs, ns, F, dn_stride(F), w.X);
     TTS_CHECK_HIP(hipGetLastError());
     return dft_gemm(h, false, w.X, w.S, w.frames, B, F, s);
 }
@@ -236,7 +240,7 @@ int32_t denoiser_bias_spec(const Denoiser* h, const float* audio, const int64_t*
         return TTSAMD_ENOMEM;
     }
     TTS_TRY(stft(h, audio, n, n_dev, 1, F, w, s));
-    hipLaunchKernelGGL(mag_frame0_kernel, dim3((NBIN + 63) / 64), dim3(64), 0, s, w.S, F, bias_out);
+    hipLaunchKernelGGL(mag_frame0_kernel, dim3((NBIN + 63) / 64), dim3(64), 0, s, w.S, dn_stride(F), bias_out);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -254,11 +258,11 @@ int32_t denoise(const Denoiser* h, float* wave, int64_t wave_bs, const int64_t* 
         return TTSAMD_ENOMEM;
     }
     TTS_TRY(stft(h, wave, wave_bs, nsamples, B, F, w, s));
-    hipLaunchKernelGGL(spec_gain_kernel, dim3((F + 255) / 256, NBIN, B), dim3(256), 0, s, w.S, bias_spec, strength, F);
+    hipLaunchKernelGGL(spec_gain_kernel, dim3((F + 255) / 256, NBIN, B), dim3(256), 0, s, w.S, bias_spec, strength, F, dn_stride(F));
     TTS_CHECK_HIP(hipGetLastError());
     TTS_TRY(dft_gemm(h, true, w.S, w.X, w.frames, B, F, s));
     // center=True: frames = n/HOP + 1 (w.frames), pad = NFFT/2, n_out = HOP*(frames-1)
-    return launch_overlap_add(w.X, h->dev + h->window, w.frames, 1, 0, NFFT / 2, B, F, n_max, wave, wave_bs, s);
+    return launch_overlap_add(w.X, h->dev + h->window, w.frames, 1, 0, NFFT / 2, B, dn_stride(F), n_max, wave, wave_bs, s);
 }
 
 }  // namespace ttsamd
