@@ -4,7 +4,7 @@ and the fused routings must agree with the un-fused engine to fp32 rounding.   p
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tts-arabic-pytorch_amd'))
 import torch
-from ttsamd import synth
+from ttsamd import synth, lib
 from ttsamd.engine import FastPitchEngine, HifiGanEngine
 from ttsamd.pipeline import FastPitchHifiGan
 
@@ -20,13 +20,12 @@ for b, lt in ((32, 64), (1, 64), (3, 40), (8, 64)):
     dur = synth.synth_durations(b, lt) * (ids != 0)
     cases.append((torch.from_numpy(ids).to(dev), torch.from_numpy(dur).to(dev)))
 routes = [{}, {'TTSAMD_FUSED2_MASK': '1ff', 'TTSAMD_FUSED2_MASK_N1': '000'}, {'TTSAMD_FUSED2_MASK': '1ff', 'TTSAMD_FUSED2_MASK_N1': '1ff'},
-          {'TTSAMD_FUSED2': '0'}]
+          {'TTSAMD_FUSED2': '0'}, {'TTSAMD_WINO4': '0'}]
 ref, bad, worst = {}, 0, 0.0
 for it in range(n):
     k, r = it % len(cases), (it // len(cases)) % len(routes)
-    for key in ('TTSAMD_FUSED2', 'TTSAMD_FUSED2_MASK', 'TTSAMD_FUSED2_MASK_N1'):
-        os.environ.pop(key, None)
-    os.environ.update(routes[r])
+    for key in ('TTSAMD_FUSED2', 'TTSAMD_FUSED2_MASK', 'TTSAMD_FUSED2_MASK_N1', 'TTSAMD_WINO4'):      # routing options go through the C ABI
+        lib.set_option(key, routes[r].get(key))
     ids, dur = cases[k]
     if it % 2:
         wave = pipe.submit(ids, dur_tgt=dur)[2]

@@ -20,7 +20,7 @@ def main():
     ids = torch.from_numpy(synth_ids(B, L)).to(dev)
     lens = torch.full((B,), L, dtype=torch.int64, device=dev)
     sids = torch.zeros(B, dtype=torch.int64, device=dev)
-    os.environ['TTSAMD_TACO_PERSISTENT'] = '2'
+    __import__('ttsamd.lib', fromlist=['x']).set_option('TTSAMD_TACO_PERSISTENT', '2')
     os.environ['TTSAMD_TACO_DUMP'] = '/tmp/taco_dump.bin'
     for _ in range(2):
         eng.infer(ids, sids, lens, max_step=steps, dropout_seed=1)

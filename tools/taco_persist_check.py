@@ -26,7 +26,7 @@ def main():
                 for seed in (-1, 5):
                     out = {}
                     for mode in ('0', '1'):
-                        os.environ['TTSAMD_TACO_PERSISTENT'] = mode
+                        __import__('ttsamd.lib', fromlist=['x']).set_option('TTSAMD_TACO_PERSISTENT', mode)
                         mel, ml, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=seed)
                         out[mode] = (mel.cpu(), ml.cpu(), al.cpu())
                     dm = (out['0'][0] - out['1'][0]).abs().amax(dim=(0, 1))

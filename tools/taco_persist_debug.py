@@ -28,7 +28,7 @@ def main():
     for steps in (1, 2):
         tr = {}
         mel_ref, _, al_ref = T.tacotron2_infer(sd, cfg, tok, sids, lens, max_step=steps, seed=-1, trace=tr)
-        os.environ['TTSAMD_TACO_PERSISTENT'] = os.environ.get('PMODE', '1')
+        __import__('ttsamd.lib', fromlist=['x']).set_option('TTSAMD_TACO_PERSISTENT', os.environ.get('PMODE', '1'))
         os.environ['TTSAMD_TACO_DUMP'] = '/tmp/taco_dump.bin'
         mel, ml, al = eng.infer(tok, sids, lens, max_step=steps, dropout_seed=-1)
         raw = open('/tmp/taco_dump.bin', 'rb').read()

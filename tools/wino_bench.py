@@ -33,7 +33,8 @@ for C, mul in ((256, 8), (128, 64), (64, 128)):
                 continue
             if os.environ.get('WINO_BENCH_ONLY') and name not in os.environ['WINO_BENCH_ONLY'].split(','):
                 continue
-            os.environ.update(env)
+            for k_, v_ in env.items():                   # routing options live in the library's table (ttsamd_set_option), not in the environment
+                lib.set_option(k_, v_)
             def call():
                 lib.check(L.ttsamd_conv1d_ex(_ptr(x), _ptr(w), _ptr(b), _ptr(res), None, B, C, C, k, 1, n, 0.1, 0, 0, 1.0, _ptr(y),
                                              _ptr(packed), _stream()), 'conv1d')
