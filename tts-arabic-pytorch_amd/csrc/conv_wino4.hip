@@ -603,7 +603,7 @@ int32_t launch_wino4(const ConvParams& p, hipStream_t stream) {
 int wino4_block_outputs(int dil) { return wino4_tile(dil, 64); }
 
 // C-in slices of a launch that cannot fill the chip by its tiles alone (batch 1: HiFi-GAN's C = 256 stage is 56 blocks): enough for
-// ~224 blocks, at least four chunks per slice, partial sums within the caller's split-K workspace.  1 = no split.
+// ~224 blocks, at least eight chunks per slice, partial sums within the caller's split-K workspace.  1 = no split.
 int wino4_ksplit(const ConvParams& p) {
     const int bo = wino4_block_outputs(p.dil);
     const int64_t blocks = (int64_t)((p.Nout + bo - 1) / bo) * (p.CoutP / 64) * p.batch;
@@ -612,7 +612,9 @@ int wino4_ksplit(const ConvParams& p) {
     if (blocks >= sk_blocks || p.splitk_ws == nullptr) return 1;
     const int n_chunks = p.Cin / (p.K == 3 ? 16 : 8);
     const int64_t per = (int64_t)p.batch * p.Cout * p.Nout;
-    int64_t ks = std::min<int64_t>((sk_target + blocks - 1) / blocks, n_chunks / 4);
+    // at least 8 chunks per slice: a block of 4-5 chunks is mostly prologue and output transform (FastPitch's conv-FF at batch 1 -- 48 / 12
+    // blocks x 24 / 96 chunks -- ran 30 % slower on 5 / 19 slices than on the direct kernel's split-K tiles)
+    int64_t ks = std::min<int64_t>((sk_target + blocks - 1) / blocks, n_chunks / 8);
     ks = std::min<int64_t>(ks, p.splitk_floats / std::max<int64_t>(per, 1));
     return ks >= 2 ? (int)ks : 1;
 }
