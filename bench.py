@@ -1244,7 +1244,7 @@ def wino_product_ratio(ch, kk, dil=1, fused=None):
         fused = ch <= 32 or (ch == 64 and kk == 3)             # hifigan.hip: kFused2Mask 00f
     if fused:
         return f23 if os.environ.get('TTSAMD_FUSED2_WB', '1') != '0' else 1.0
-    m4, m2 = _env_int('TTSAMD_WINO4', 15), _env_int('TTSAMD_WINO2', 31)
+    m4, m2 = _env_int('TTSAMD_WINO4', 31), _env_int('TTSAMD_WINO2', 31)
     if (m4 & kbit) and (dil == 1 or (m4 & 8)):
         return f43
     if (m2 & kbit) and (dil == 1 or (m2 & 8)):

@@ -180,3 +180,56 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, m
         conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), dilation=d, in_slope=0.1, res=None if res is None else res.to(dev),
                mode=mode or 0, div=3.0, y=y)
         assert not torch.equal(outs['1'], y.cpu())
+
+
+@pytest.mark.parametrize('cin,cout,L,B,act,mode', [
+    (512, 1536, 496, 12, 2, None),       # Vocos pwconv1 + GELU
+    (1536, 512, 500, 12, 0, 0),          # pwconv2 + residual
+    (384, 192, 1030, 8, 0, None),        # FastPitch's qkv projection: three 64-row blocks
+    (64, 384, 1030, 8, 0, 0),            # ... o_net: two 32-channel chunks
+    (256, 256, 777, 8, 1, 0), (256, 256, 777, 8, 0, 1), (256, 128, 2052, 4, 0, 2), (512, 512, 300, 24, 3, None),
+])
+def test_k1_gemm_on_the_wino4_skeleton(dev, cin, cout, L, B, act, mode, ttsopt):
+    """k = 1 (conv_wino4.hip, Wino4Geo::WSHARE -- TTSAMD_WINO4 bit 4): a pointwise conv as the four single-tap planes of the F(4,3) kernel,
+    one weight fragment per octet for 16 MFMAs, the direct engine's packed weights as they are.  Same products in the same order as
+    conv1d_mfma_f32<1> (bit-identical results where that kernel does not split K); float64 checker; GELU / ReLU / tanh, residual, accumulate modes, ragged
+    odd lengths (reference ops: vocoder/vocos/modules.py ConvNeXtBlock pwconv1 / pwconv2, models/fastpitch/fastpitch/transformer.py:96-99)."""
+    from ttsamd.engine import conv1d
+    g = torch.Generator().manual_seed(cin + 7 * cout + L)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, 1, generator=g) / np.sqrt(cin)
+    b = torch.randn(cout, generator=g) * 0.3
+    res = torch.randn(B, cout, L, generator=g) if mode is not None else None
+    y0 = torch.randn(B, cout, L, generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0], lens[1], lens[2], lens[3] = L, L - 1, 131, 1
+    outs = {}
+    for mask in ('31', '15'):
+        ttsopt.set('TTSAMD_WINO4', mask)
+        y = y0.clone().to(dev)
+        conv1d(x.to(dev), w.to(dev), b.to(dev), lens=lens.to(dev), in_slope=0.1, relu_out=act, res=None if res is None else res.to(dev),
+               mode=mode or 0, div=3.0, y=y)
+        outs[mask] = y.cpu()
+    worst = 0.0
+    for i in range(B):
+        n = int(lens[i])
+        v = F.conv1d(F.leaky_relu(x[i:i + 1, :, :n].double(), 0.1), w.double(), b.double())[0]
+        if act == 2:
+            v = F.gelu(v)
+        if res is not None:
+            v = v + res[i, :, :n].double()
+        if act == 1:
+            v = F.relu(v)
+        if act == 3:
+            v = torch.tanh(v)
+        ref = v if not mode else (y0[i, :, :n].double() + v if mode == 1 else (y0[i, :, :n].double() + v) / 3.0)
+        worst = max(worst, float((outs['31'][i, :, :n].double() - ref).abs().max()))
+        assert torch.equal(outs['31'][i, :, n:], y0[i, :, n:]), 'positions past the utterance must stay untouched'
+    print(f'k=1 cin={cin} cout={cout} act={act} mode={mode}: max-abs {worst:.2e}')
+    assert worst < 2e-5
+    # same products in the same order: bit for bit the direct kernel's result unless that one splits K (under 320 blocks of its own tiles)
+    same = torch.equal(outs['31'], outs['15'])
+    print('   bit-identical to conv1d_mfma_f32<1>:', same)
+    assert float((outs['31'] - outs['15']).abs().max()) < 2e-5
+    if (cin, cout) == (512, 1536):
+        assert same

@@ -75,7 +75,7 @@ inline hipError_t lds_opt_in(const void* fn, int bytes, std::atomic<uint64_t>& d
     X(HIFIGAN_STREAMS, 0, 0, 1)   /* ResBlock branches of a HiFi-GAN stage on one / three streams (default: by size) */ \
     X(WINO, 0, 0, 1)              /* fp32 engine: 0 = direct kernels only */                                \
     X(WINO2, 0, 0, 31)            /* F(2,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated, 4 = Cout 64 */ \
-    X(WINO4, 0, 0, 15)            /* F(4,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated (default 15) */ \
+    X(WINO4, 0, 0, 31)            /* F(4,3) decomposition kernel: bit 0 / 1 / 2 = k 3 / 7 / 11, 3 = dilated, 4 = k 1 (default 31) */ \
     X(FUSED_PAIR, 0, 0, 1)        /* fp32 fused c1 -> c2 pairs: 0 = every pair as two launches */           \
     X(FUSED2, 0, 0, 1)            /* second-generation fused pair off / on */                               \
     X(FUSED2_MASK, 1, 0, 0x1ff)   /* which (C, k) pairs it takes: bit 3 ci + ki (default 00f) */            \

@@ -407,16 +407,31 @@ static int32_t launch_wino_epi(const ConvParams& q, dim3 grid, hipStream_t strea
 //                        = Cout = 64.  Default 31 (same-box A/B of the bench step, tools/ab_env.sh: 74.2 ms with none, 73.1 with k = 3,
 //                        68.5 with k = 7 + 11, 67.5 with the three, 65.6 with dilations, 64.6-65.1 with Cout = 64)
 int wino_route(const ConvParams& p) {
-    if ((p.w_wino == nullptr && p.w_wino4 == nullptr) || p.precision != 0 || (p.K != 3 && p.K != 7 && p.K != 11)) return 0;
+    if (p.precision != 0) return 0;
     const char* e = opt_str(OPT_WINO);
     if (e && e[0] == '0') return 0;
+    if (p.K == 1) {
+        // k = 1 (Vocos' pointwise convs, the denoiser's DFT, FastPitch's projections) on the F(4,3) kernel's skeleton with nothing to transform
+        // (conv_wino4.hip, Wino4Geo::WSHARE): the direct engine's packed weights as they are; TTSAMD_WINO4 bit 4.  Same tile, same block rule.
+        const char* e4 = opt_str(OPT_WINO4);
+        const int mask4 = e4 ? atoi(e4) : 31;
+        const bool ok1 = (mask4 & 16) && p.w != nullptr && p.dil == 1 && p.pad == 0 && p.n_phase == 1 && p.y_ts == 1 && p.CoutP % 64 == 0 &&
+                         p.Cin % 32 == 0 && p.in_slope >= 0.f && p.in_slope <= 1.f && !p.x_packed && !p.y_packed &&
+                         (p.y_cs & 3) == 0 && (p.y_bs & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
+                         (!p.res || ((p.r_cs & 3) == 0 && (p.r_bs & 3) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                         (int64_t)p.Cout * std::max(std::max(p.r_cs, p.y_cs), 1) * 4 < ((int64_t)1 << 31);
+        if (!ok1) return 0;
+        const int64_t blocks1 = (int64_t)((p.Nout + 255) / 256) * (p.CoutP / 64) * p.batch * wino4_ksplit(p);
+        return (blocks1 >= 192 && p.Nout >= 256) ? 3 : 0;
+    }
+    if ((p.w_wino == nullptr && p.w_wino4 == nullptr) || (p.K != 3 && p.K != 7 && p.K != 11)) return 0;
     if (p.w_wino4 != nullptr) {
         // F(4,3) decomposition (conv_wino4.hip): TTSAMD_WINO4=<mask>, bit 0 / 1 / 2 = k 3 / 7 / 11, bit 3 = their dilated convs; default 15.
         // (k = 3 -- 6 instead of 8 products per quad -- did not pay with the kernel's first staging path: 414 / 330 vs 392 / 315 us on
         // FastPitch's conv-FF pair; with the aligned 16-byte window loads it does: same-box A/B of the step 55.46 (mask 14) vs 54.68 ms.)
         // 64 rows x 64 quads per block, float4-aligned rows, at least 192 blocks (below: the F(2,3) / direct routing that follows)
         const char* e4 = opt_str(OPT_WINO4);
-        const int mask4 = e4 ? atoi(e4) : 15;
+        const int mask4 = e4 ? atoi(e4) : 31;
         const int kbit4 = p.K == 3 ? 1 : (p.K == 7 ? 2 : 4);
         const bool ok4 = (mask4 & kbit4) && (p.dil == 1 || (mask4 & 8)) && (p.K != 3 || p.Cin % 16 == 0) &&
                          (p.dil == 1 || p.dil == 3 || p.dil == 5) && p.pad == p.dil * (p.K - 1) / 2 && p.n_phase == 1 && p.y_ts == 1 &&

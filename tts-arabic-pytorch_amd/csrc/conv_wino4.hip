@@ -28,6 +28,11 @@
 // wave are 96 / 128 accumulator registers, so a wave owns ONE 32-row tile x 32 tuples; block = 2 x 2 waves = 64 rows x 64 tuples
 // (256 outputs).  k = 11 runs its 23 groups in two PHASES (12 + 11) so that two stages fit 48 KB; its packed weights carry a 24th
 // all-zero group that is fetched (queue slots line up) and never multiplied.
+// k = 1 (Vocos' pwconv1 / pwconv2, FastPitch's qkv / o_net: vocoder/vocos/modules.py ConvNeXtBlock, transformer.py:96-99) runs on the same
+// skeleton as a plain GEMM: nothing to transform, the tuple's four positions ARE the four single-tap planes P0 / P6 / P7 / P5, one weight
+// fragment per octet (the direct engine's packed weights as they are) feeds 16 MFMAs, the epilogue also knows GELU / tanh / the per-row
+// factor of the direct kernel.  Same products in the same order as conv1d_mfma_f32<1>; 251 / 217 vs 263 / 233 us on Vocos' two GEMMs
+// (512 <-> 1536 rows x 15 872 frames: matrix pipe 65 / 75 % busy against 61 / 70 %), Vocos at batch 32 4.99 -> 4.67 ms.
 #include <cstdlib>
 #include <cstring>
 
@@ -51,12 +56,17 @@ typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
 template <int K, int NOCT_, int NSTAGE_, int EPI_ = 0>
 struct Wino4Geo {
     static constexpr int WM = 2, WN = 2;
-    static constexpr int NSF = K == 3 ? 1 : (K == 7 ? 2 : 4);        // sub-filters (k = 11: the fourth is taps 9, 10 + a zero tap)
-    static constexpr int NL = K == 7 ? 1 : 0;                        // single taps
-    static constexpr int NG = K == 3 ? 6 : (K == 7 ? 16 : 23);       // operand groups per octet that are multiplied
+    static constexpr int NSF = K == 1 ? 0 : (K == 3 ? 1 : (K == 7 ? 2 : 4));     // sub-filters (k = 11: the fourth is taps 9, 10 + a zero tap)
+    static constexpr int NL = (K == 7 || K == 1) ? 1 : 0;            // single taps
+    static constexpr int NG = K == 1 ? 4 : (K == 3 ? 6 : (K == 7 ? 16 : 23));    // operand groups per octet that are multiplied
     static constexpr int NGQ = (NG + 1) & ~1;                        // ... in the packed weights (k = 11: + one zero group)
+    // k = 1 (a plain GEMM on this kernel's skeleton: no transform, the tuple's four positions are the four single-tap planes P0 / P6 / P7 / P5):
+    // the four groups of an octet multiply the SAME filter, so the queue holds one fragment per octet -- the direct engine's packed weights
+    // [Cin/8][1][2][CoutP][4] as they are -- and each fragment feeds 16 MFMAs
+    static constexpr bool WSHARE = K == 1;
+    static constexpr int NGW = WSHARE ? 1 : NGQ;                     // weight groups per octet in memory
     static constexpr int NPL = (NL || EPI_ == 3) ? 8 : 6;            // accumulator planes (P6 / P7: the single tap of k = 7, the preloaded residual)
-    static constexpr int NPOS = K == 3 ? 6 : (K == 7 ? 10 : 14);     // input positions of a tuple's window
+    static constexpr int NPOS = K == 1 ? 4 : (K == 3 ? 6 : (K == 7 ? 10 : 14));     // input positions of a tuple's window
     static constexpr int NOCT = NOCT_, NSTAGE = NSTAGE_;
     static constexpr int NPH = K == 11 ? 2 : 1;
     static constexpr int NGPM = NPH == 1 ? NG : 12;                  // group slots of a stage
@@ -97,7 +107,7 @@ struct Wino4Geo {
     __host__ __device__ static constexpr int nvec(int ph) { return fdiv4(mhi(ph) - (K - 1) / 2) - vlo(ph) + 1; }
     static constexpr int NVP = nvec(0) > nvec(NPH - 1) ? nvec(0) : nvec(NPH - 1);
     __host__ __device__ static constexpr int nljv(int ph) { return NOCT * 2 * nvec(ph); }     // vector load jobs
-    static constexpr int DAV = K == 3 ? 8 : 16;
+    static constexpr int DAV = (K == 3 || K == 1) ? 8 : 16;
     __host__ __device__ static constexpr int tw0v(int ph) { return DAV + 2 * nljv(ph); }       // two activation jobs per vector, one per gap
     __host__ __device__ static constexpr int wsv(int ph) { return (ngap(ph) - tw0v(ph)) / nwj(ph); }
     static_assert(wsv(0) >= 1 && wsv(NPH - 1) >= 1, "one write job per gap at most (vector loads)");
@@ -115,7 +125,7 @@ struct Wino4Geo {
     __host__ __device__ static constexpr int tw0t(int ph) { return tr_r0(ph) + nrj(ph) + 1; }                 // first plane write
     __host__ __device__ static constexpr int wst(int ph) { return (ngap(ph) - tw0t(ph)) / nwj(ph); }
     static_assert(wst(0) >= 1 && wst(NPH - 1) >= 1, "one write job per gap at most (strip path)");
-    static_assert((NOCT * ngq(0)) % PF == 0 && (NOCT * ngq(NPH - 1)) % PF == 0, "queue slots line up across steps");
+    static_assert((WSHARE ? NOCT : NOCT * ngq(0)) % PF == 0 && (NOCT * ngq(NPH - 1)) % PF == 0, "queue slots line up across steps");
     static_assert((size_t)NSTAGE * BUF4 * 16 <= 80 * 1024, "two blocks per CU");
     static_assert(NPH == 1 || NOCT == 1, "phases split an octet's groups");
 };
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
     const int x_cs = p.x_cs, CoutP = p.CoutP;
     const int chunks_all = p.Cin / (8 * NOCT);
     const int c_beg = (int)((int64_t)ks * chunks_all / p.ksplit), n_chunks = (int)((int64_t)(ks + 1) * chunks_all / p.ksplit);   // [c_beg, n_chunks)
-    const int n_groups = (p.Cin / 8) * G::NGQ;                // groups of the whole conv in the packed weights
+    const int n_groups = (p.Cin / 8) * G::NGW;                // groups of the whole conv in the packed weights
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
     const float in_slope = p.in_slope;
 
@@ -216,10 +226,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
 
     // ---- weight queue: group gf = octet * NGQ + g sits at w_wino4 + gf * 2 CoutP float4 (the scalar offset of the buffer load, advanced by
     // one group per refill and clamped at the conv's last group: an L1 hit, unused); this lane's fragment at + kk * CoutP + row
-    const bfo_i4 wrs = bfo_rsrc(p.w_wino4, (unsigned)n_groups * 2u * (unsigned)CoutP * 16u);
+    const bfo_i4 wrs = bfo_rsrc(K == 1 ? p.w : p.w_wino4, (unsigned)n_groups * 2u * (unsigned)CoutP * 16u);
     const int wv = (kk * CoutP + co_blk0 + wm * 32 + l31) * 16;
     const int wstep = 2 * CoutP * 16, wlast = (n_groups - 1) * wstep;
-    int wso = c_beg * NOCT * G::NGQ * wstep;
+    int wso = c_beg * NOCT * G::NGW * wstep;
     w4_f32x4 aq[PF];
 #pragma unroll
     for (int g = 0; g < PF; ++g) {
@@ -373,10 +383,13 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
 #pragma unroll
             for (int gs = 0; gs < NOCT * G::ngq(ph); ++gs) {
                 const int ol = gs / G::ngq(ph), gl = gs % G::ngq(ph);
-                const w4_f32x4 a4 = aq[gs % PF];
-                // refill the queue slot with the group PF ahead
-                if (!(TTS_W4_EXP & 8)) aq[gs % PF] = __builtin_bit_cast(w4_f32x4, bfo_ld16(wrs, wv, wso, 0));
-                wso = min(wso + wstep, wlast);
+                const int qs = G::WSHARE ? ol % PF : gs % PF;
+                const w4_f32x4 a4 = aq[qs];
+                // refill the queue slot with the group PF ahead (k = 1: one fragment per octet, refilled behind its last group)
+                if (!G::WSHARE || gl == G::ngq(ph) - 1) {
+                    if (!(TTS_W4_EXP & 8)) aq[qs] = __builtin_bit_cast(w4_f32x4, bfo_ld16(wrs, wv, wso, 0));
+                    wso = min(wso + wstep, wlast);
+                }
                 if (gl >= G::ngp(ph)) continue;                    // the zero group of k = 11: fetched, never multiplied
                 const int r = ol * G::ngp(ph) + gl;                // multiplied groups of the step so far
                 const int cur = r & 1, nxt = cur ^ 1;
@@ -446,6 +459,7 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         float y1 = d12 + 2.f * d34;
         float y2 = s12 + 4.f * s34;
         float y3 = d12 + 8.f * d34 + acc[5][r];
+        if constexpr (NSF == 0) { y0 = acc[0][r]; y1 = 0.f; y2 = 0.f; y3 = acc[5][r]; }     // k = 1: P1..P4 do not exist
         if constexpr (NPL == 8) {
             y1 += acc[6][r];
             y2 += acc[7][r];
@@ -486,7 +500,10 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
         }
         return;
     }
-    if (preload || (!rb && mode == 0)) {
+    // k = 1 only (Vocos' pointwise convs): GELU behind the bias, a per-row factor before the residual, tanh at the end (conv_mfma.hip's epilogue)
+    const float* __restrict__ scale = K == 1 ? p.scale : nullptr;
+    const bool plain_act = K != 1 || (relu_out < 2 && scale == nullptr);
+    if (plain_act && (preload || (!rb && mode == 0))) {
         // nothing to read from memory: a loop without a single vmcnt wait (conv_mfma.hip: why)
         const float lo = relu_out == 1 ? 0.f : -__builtin_inff();
         const bool do_div = preload && mode == 2;
@@ -536,10 +553,17 @@ __global__ __launch_bounds__(256, TTS_MINWAVES) void conv1d_wino4_f32(const Conv
                     if (mode != 0) pp4[e] = yp[e];
                 }
         }
+        const float scv = (K == 1 && scale) ? scale[co] : 1.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e] + bsv + rr4[e];
+            float x = v[e] + bsv;
+            if constexpr (K == 1) {
+                if (relu_out == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));   // nn.GELU()
+                x = x * scv;
+            }
+            x += rr4[e];
             if (relu_out == 1) x = fmaxf(x, 0.f);
+            if constexpr (K == 1) { if (relu_out == 3) x = tanhf(x); }
             if (mode == 1) x = pp4[e] + x;
             else if (mode == 2) x = (pp4[e] + x) / div;
             v[e] = x;
@@ -593,10 +617,11 @@ static int32_t launch_wino4_cfg(const ConvParams& p, hipStream_t stream) {
 }
 
 int32_t launch_wino4(const ConvParams& p, hipStream_t stream) {
+    if (p.K == 1) return launch_wino4_epi<1, 4, 2, 0, 1>(p, stream);   // 32-channel chunks: 64 MFMAs per wave between barriers, 64 KB ring
     if (p.K == 3) return launch_wino4_cfg<3, 2, 3>(p, stream);       // 16-channel chunks: 48 MFMAs per wave between barriers, 72 KB ring
     if (p.K == 7) return launch_wino4_cfg<7, 1, 2>(p, stream);       // 64 MFMAs, 64 KB ring
     if (p.K == 11) return launch_wino4_cfg<11, 1, 3>(p, stream);     // two phases of 12 / 11 groups: 48 / 44 MFMAs, 72 KB ring
-    set_error("wino4: kernel size %d not built (3, 7, 11)", p.K);
+    set_error("wino4: kernel size %d not built (1, 3, 7, 11)", p.K);
     return TTSAMD_EINVAL;
 }
 
@@ -610,7 +635,7 @@ int wino4_ksplit(const ConvParams& p) {
     // (more slices / a higher block threshold were measured: no change at batch 1, 2.34-2.40 ms at every setting -- profiles/r6/NOTES.md)
     constexpr int sk_blocks = 192, sk_target = 224;
     if (blocks >= sk_blocks || p.splitk_ws == nullptr) return 1;
-    const int n_chunks = p.Cin / (p.K == 3 ? 16 : 8);
+    const int n_chunks = p.Cin / (p.K == 1 ? 32 : (p.K == 3 ? 16 : 8));
     const int64_t per = (int64_t)p.batch * p.Cout * p.Nout;
     // at least 8 chunks per slice: a block of 4-5 chunks is mostly prologue and output transform (FastPitch's conv-FF at batch 1 -- 48 / 12
     // blocks x 24 / 96 chunks -- ran 30 % slower on 5 / 19 slices than on the direct kernel's split-K tiles)
