@@ -1160,7 +1160,9 @@ def c1_configs(dev):
                     'timing': 'median of 3 whole calls, host wall time incl. tokenisation and the device -> host copies',
                     'schedule': 'three HIP streams over the chunks of the list (FastPitch2Wave._tts_list_pipelined): tokenise + FastPitch of the next '
                                 'chunks (each chunk = the reference\'s padded batch of `batch_size` lines) under vocoder + denoiser of the previous '
-                                'ones, D2H on a third stream; the batch-independent vocoder takes the mels of up to 16 utterances per ragged call'})
+                                'ones, D2H on a third stream; the batch-independent vocoder takes the mels of up to 16 utterances per ragged call; '
+                                'batch_size 1: the lines sorted by length through FastPitch AND the vocoder in balanced ragged groups of <= 32 whose '
+                                'FastPitch rows are computed as if alone (ttsamd_fastpitch_set_batch_mode 1), waves back in input order'})
     return res
 
 

@@ -110,7 +110,7 @@ const char* ttsamd_last_error(void);
  * bound twice per process, one communicator per stream; 4: ttsamd_bfo_resblock_chain takes the kernel size as its last argument; 5: the ttsamd_bfo3_* entries, ttsamd_conv1d_ex; 6: ttsamd_set_option / ttsamd_get_option / ttsamd_option_name / ttsamd_options_check replace the per-call
  * environment reads, ttsamd_resblock_pair takes the size of `packed`, ttsamd_resblock_pair_packed_floats).  ttsamd_version() returns the value the library was BUILT with: a caller
  * compiled against another revision must refuse to run (ttsamd/lib.py does). */
-#define TTSAMD_ABI_VERSION 6
+#define TTSAMD_ABI_VERSION 7
 int32_t ttsamd_version(void);
 /* Run-time routing options: every switch that routes between kernels / schedules that both ship (INTEGRATION.md lists them with their
  * defaults).  An option's value is seeded ONCE from the environment variable of the same name (TTSAMD_<NAME>) when the library is first
@@ -183,6 +183,16 @@ int32_t ttsamd_length_regulate(const float* enc, const int64_t* reps, int32_t ba
 int32_t ttsamd_fastpitch_decode(void* handle, float* x, const int64_t* dec_lens, int32_t batch,
                                 int32_t t_max, float* mel, void* workspace,
                                 int64_t workspace_bytes, void* stream);
+
+/* How a BATCH of utterances goes through ttsamd_fastpitch_encode / _decode of this handle (default 0; not a per-call argument: set it
+ * between calls, not under a running one).
+ *   0  the reference's padded-batch arithmetic: the hidden activations of the conv-FF blocks and of the predictors are not masked, so
+ *      the last frames of an utterance depend on the longest one of its batch (FastPitch.infer on a padded batch,
+ *      models/fastpitch/fastpitch/transformer.py:72-90, model.py:129-133) -- what tts(list, batch_size > 1) returns.
+ *   1  every utterance as if it were alone in the call: those two convs read their input masked at the utterance's own length (every
+ *      other op already masks), so row b equals FastPitch.infer(ids[b:b+1, :len_b]) -- the reference's batch_size = 1 loop
+ *      (models/fastpitch/networks.py:402-411) as ONE ragged call.  Equal to the one-by-one calls within fp32 summation order. */
+int32_t ttsamd_fastpitch_set_batch_mode(void* handle, int32_t mode);
 
 /* ---- HiFi-GAN bias denoiser: replaces vocoder.hifigan.denoiser.Denoiser
  *      (vocoder/hifigan/denoiser.py:32-64 __init__, :66-72 forward).  STFT/ISTFT with

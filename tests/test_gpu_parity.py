@@ -730,6 +730,8 @@ def test_dropin_tts_list_pipeline_matches_the_one_stream_loop(dev, golden, check
     of the previous ones, D2H on a third stream) whose vocoder takes the mels of up to 16 utterances per ragged call: same lengths
     and -- the vocoder being batch-independent up to its fp32 summation order -- the same waves as the one-stream loop to 1e-5
     (north-star tolerance 1e-4), for batch_size 1 (tts_single per line), 2 and 5 (tts_batch), denoiser on; prints both timings.
+    batch_size 1 additionally runs FastPitch itself on ragged groups of length-sorted lines whose rows are computed as if alone (engine batch
+    mode 1, tests/test_gpu_alone.py; TTSAMD_TTS_ALONE=0 = the line-by-line FastPitch calls under the same pipeline): all three agree.
     (Both paths are checked against the oracle: test_dropin_tts_matches_reference, test_config1_all_100_lines_batch_size_1.)"""
     import time
     from models.fastpitch import FastPitch2Wave
@@ -747,6 +749,12 @@ def test_dropin_tts_list_pipeline_matches_the_one_stream_loop(dev, golden, check
         assert len(a) == len(b) == len(lines)
         for x, y in zip(a, b):
             assert x.device.type == 'cpu' and x.shape == y.shape and float((x - y).abs().max()) < 1e-5
+        if bs == 1:
+            monkeypatch.setenv('TTSAMD_TTS_ALONE', '0')
+            c = model.tts(lines, batch_size=bs)
+            monkeypatch.delenv('TTSAMD_TTS_ALONE')
+            for x, y in zip(a, c):
+                assert x.shape == y.shape and float((x - y).abs().max()) < 1e-5
         with capsys.disabled():
             print(f'\n[tts list, {len(lines)} lines, batch_size {bs}] one stream {res["0"][1] * 1e3:.1f} ms, pipelined {res["1"][1] * 1e3:.1f} ms')
 

@@ -115,6 +115,7 @@ int64_t fastpitch_decode_workspace_bytes(const FastPitch*, int32_t, int32_t);
 int32_t fastpitch_encode(const FastPitch*, const int64_t*, int32_t, int32_t, int32_t, float, const float*,
                          const float*, const float*, float, float, float, float*, float*, float*, float*, int64_t*,
                          int64_t*, void*, int64_t, hipStream_t);
+void fastpitch_set_batch_mode(const FastPitch*, int);
 int32_t fastpitch_decode(const FastPitch*, float*, const int64_t*, int32_t, int32_t, float*, void*, int64_t,
                          hipStream_t);
 
@@ -295,6 +296,12 @@ int32_t ttsamd_length_regulate(const float* enc, const int64_t* reps, int32_t ba
                 "length_regulate: bad argument");
     return launch_regulate_gather(enc, reps, nullptr, 0, batch, n_tokens, channels, t_max, out, idx,
                                   (hipStream_t)stream);
+}
+int32_t ttsamd_fastpitch_set_batch_mode(void* handle, int32_t mode) {
+    TTS_REQUIRE(handle != nullptr, "fastpitch_set_batch_mode: null handle");
+    TTS_REQUIRE(mode == 0 || mode == 1, "fastpitch_set_batch_mode: mode %d (0 = padded-batch arithmetic, 1 = every utterance alone)", mode);
+    fastpitch_set_batch_mode((const FastPitch*)handle, mode);
+    return 0;
 }
 int32_t ttsamd_fastpitch_decode(void* handle, float* x, const int64_t* dec_lens, int32_t batch, int32_t t_max,
                                 float* mel, void* workspace, int64_t workspace_bytes, void* stream) {

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,6 +47,10 @@ struct FastPitch {
     PConv proj;
     int64_t pitch_emb_w, pitch_emb_b, energy_emb_w = -1, energy_emb_b = -1;
     int pos_cap = 0;
+    // ttsamd_fastpitch_set_batch_mode: 0 = the reference's padded-batch arithmetic (hidden activations of conv-FF / the predictors are NOT
+    // masked, so an utterance's result depends on the longest one of its batch: SURVEY 3.4-1); 1 = every utterance as if it were alone --
+    // those two second convs read their input masked at the utterance's own length, which is all it takes: every other op already masks
+    mutable std::atomic<int> alone{0};
 };
 
 using TensorMap = std::map<std::string, const ttsamd_tensor*>;
@@ -299,6 +304,8 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
                        const int64_t* lens, int B, int S, const FftWs& w, hipStream_t s) {
     const int d = h->cfg.d_model;
     const float scale = 1.0f / std::sqrt((float)d_head);
+    const bool alone = h->alone.load(std::memory_order_relaxed) != 0;
+    const PConv* ff2_of = nullptr;                      // the layer's second conv-FF conv (octet paths: set per layer below)
     const char* ffe = opt_str(OPT_BFO_FF);              // read per call: the tests and A/B runs flip it
     bool octet = default_precision() == 1 && !(ffe && ffe[0] == '0') && d % 64 == 0 && d <= 512 && d_head == 64;
     for (const FftLayer& l : layers)
@@ -326,6 +333,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
             cp.ln_g = ln_g; cp.ln_b = ln_b; cp.ln_octet = ln_o; cp.ln_lens = ln_g ? lens : nullptr;
             cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
             cp.x = in; cp.y = out_o; cp.y_f32 = out_f; cp.res_f32 = res_f;
+            if (alone && &c == ff2_of) { cp.lens = lens; cp.out_all = 1; }      // batch mode 1: the hidden activation masked on load
             cp.w = h->dev16 + c.wo_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
             cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = out_slope;
             cp.splitk_ws = t_splitk_ws; cp.splitk_floats = t_splitk_ws ? kSplitKFloatsFp : 0;
@@ -335,6 +343,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
             return rc;
         };
         for (const FftLayer& l : layers) {
+            ff2_of = &l.ff2;
             TTS_TRY(conv(l.qkv, xo, nullptr, w.q, nullptr, 1.f));
             TTS_TRY(launch_attention_bf16(w.q, lens, B, d_head, S, scale, nullptr, s, ao));
             TTS_TRY(conv(l.o_net, ao, nullptr, w.y, x, 1.f, h->dev + l.ln1_g, h->dev + l.ln1_b, yo));   // + LayerNorm 1 -> y, yo
@@ -364,6 +373,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
             std::memset(&cp, 0, sizeof(cp));
             cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
             cp.x = in; cp.y = out_o; cp.y_f32 = out_f; cp.res_f32 = res_f;
+            if (alone && &c == ff2_of) { cp.lens = lens; cp.out_all = 1; }
             cp.w = h->dev16 + c.wo3_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
             cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = out_slope;
             prof_begin(s, 2.0 * c.cout * c.cin * c.k);
@@ -372,6 +382,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
             return rc;
         };
         for (const FftLayer& l : layers) {
+            ff2_of = &l.ff2;
             TTS_TRY(conv(l.qkv, xo, nullptr, w.q, nullptr, 1.f));
             TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s, t_splitk_ws, t_splitk_ws ? kSplitKFloatsFp : 0));
             TTS_TRY(bfo3_launch_pack(w.a, B, d_head, S, 1.f, ao, s));
@@ -389,7 +400,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
         TTS_TRY(run_conv(h, l.o_net, w.a, w.y, x, B, S, nullptr, 0, s));
         TTS_TRY(launch_layernorm_cf(w.y, w.y, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
         TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s));
-        TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, nullptr, 0, s));
+        TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, alone ? lens : nullptr, 0, s));
         TTS_TRY(launch_layernorm_cf(x, x, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
     }
     return 0;
@@ -430,7 +441,7 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
             // LayerNorm of layer 0 in place (fp32, t0) + its octet copy into t1 (the packed input there is dead now)
             TTS_TRY(launch_layernorm_cf_octet(t0, t0, t1, h->dev + pr.ln_g[0], h->dev + pr.ln_b[0], nullptr, 0, B, pr.filter, S, s));
             // the second conv reads the octet copy; the fp32 LayerNorm output in t0 is dead, so its result goes there
-            TTS_TRY(conv(pr.convs[1], t1, t0, nullptr));
+            TTS_TRY(conv(pr.convs[1], t1, t0, h->alone.load(std::memory_order_relaxed) ? lens : nullptr));
             TTS_TRY(launch_layernorm_cf(t0, t0, h->dev + pr.ln_g[1], h->dev + pr.ln_b[1], nullptr, 0, B, pr.filter, S, s));
             return launch_pred_fc(t0, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul, add, s);
         }
@@ -458,14 +469,14 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
             TTS_TRY(bfo3_launch_pack(x, B, pr.convs[0].cin, S, 1.f, px3, s));
             TTS_TRY(conv(pr.convs[0], px3, t0, lens));
             TTS_TRY(launch_layernorm_cf_x3(t0, t0, px3, h->dev + pr.ln_g[0], h->dev + pr.ln_b[0], nullptr, 0, B, pr.filter, S, s));
-            TTS_TRY(conv(pr.convs[1], px3, t1, nullptr));
+            TTS_TRY(conv(pr.convs[1], px3, t1, h->alone.load(std::memory_order_relaxed) ? lens : nullptr));
             TTS_TRY(launch_layernorm_cf(t1, t1, h->dev + pr.ln_g[1], h->dev + pr.ln_b[1], nullptr, 0, B, pr.filter, S, s));
             return launch_pred_fc(t1, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul, add, s);
         }
     }
     for (size_t i = 0; i < pr.convs.size(); ++i) {
         float* dst = bufs[i & 1];
-        TTS_TRY(run_conv(h, pr.convs[i], src, dst, nullptr, B, S, i == 0 ? lens : nullptr, 1, s));
+        TTS_TRY(run_conv(h, pr.convs[i], src, dst, nullptr, B, S, (i == 0 || h->alone.load(std::memory_order_relaxed)) ? lens : nullptr, 1, s));
         TTS_TRY(launch_layernorm_cf(dst, dst, h->dev + pr.ln_g[i], h->dev + pr.ln_b[i], nullptr, 0, B, pr.filter, S, s));
         src = dst;
     }
@@ -584,6 +595,8 @@ int32_t fastpitch_decode(const FastPitch* h, float* x, const int64_t* dec_lens, 
     // proj + permute (model.py:406-408): channel-first output IS the permuted layout
     return run_conv(h, h->proj, x, mel, nullptr, B, T, nullptr, 0, s);
 }
+
+void fastpitch_set_batch_mode(const FastPitch* h, int mode) { h->alone.store(mode != 0 ? 1 : 0, std::memory_order_relaxed); }
 
 void fastpitch_blobs(const void* hv, void** f32, int64_t* n_f32, void** b16, int64_t* n_b16) {
     const FastPitch* h = (const FastPitch*)hv;

@@ -79,7 +79,9 @@ class FastPitch(_HipModule):
     # ---- FastPitch.infer (models/fastpitch/fastpitch/model.py:351-353) -------------------
     @torch.inference_mode()
     def infer(self, inputs, pace=1.0, dur_tgt=None, pitch_tgt=None, energy_tgt=None, pitch_transform=None,
-              max_duration=75, speaker=0):
+              max_duration=75, speaker=0, alone=False):
+        """`alone=True` (not in the reference): every row of the batch as if it were the only utterance of the call, i.e. row b ==
+        infer(inputs[b:b+1, :len_b]) within fp32 summation order (FastPitchEngine.infer) -- the batch_size = 1 loop as one ragged call."""
         ids = torch.as_tensor(inputs).long()
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.net_config['n_symbols']):
             raise IndexError(f'token id out of range [0, {self.net_config["n_symbols"]}) (nn.Embedding raises here too)')
@@ -96,14 +98,14 @@ class FastPitch(_HipModule):
                 mul, add = pitch_transform.affine
             else:
                 # arbitrary callable: run the predictor, transform on the host side, feed back
-                _, _, _, pp, _ = eng.infer(ids, pace=pace, dur_tgt=dur_tgt, max_duration=max_duration, speaker=speaker)
+                _, _, _, pp, _ = eng.infer(ids, pace=pace, dur_tgt=dur_tgt, max_duration=max_duration, speaker=speaker, alone=alone)
                 mean, std = (218.14, 67.24) if self.pitch_std == 0.0 else (self.pitch_mean, self.pitch_std)
                 pp = pitch_transform(pp, lens.to(pp.device), mean, std)
                 out = eng.infer(ids, pace=pace, dur_tgt=dur_tgt, pitch_tgt=pp if pitch_tgt is None else pitch_tgt,
-                                energy_tgt=energy_tgt, max_duration=max_duration, speaker=speaker)
+                                energy_tgt=energy_tgt, max_duration=max_duration, speaker=speaker, alone=alone)
                 return out[0], out[1], out[2], pp, out[4]
         return eng.infer(ids, pace=pace, dur_tgt=dur_tgt, pitch_tgt=pitch_tgt, energy_tgt=energy_tgt,
-                         pitch_mul=mul, pitch_add=add, max_duration=max_duration, speaker=speaker)
+                         pitch_mul=mul, pitch_add=add, max_duration=max_duration, speaker=speaker, alone=alone)
 
     # ---- text -> mel (reference :77-253) -----------------------------------------------
     def _vowelize(self, utterance: str, vowelizer=None):
@@ -152,6 +154,20 @@ class FastPitch(_HipModule):
                                        pitch_transform=self._ptrf(pitch_mul, pitch_add, pitch_transform),
                                        max_duration=max_duration)
         return mel, dec_lens, reverse_ids
+
+    @torch.inference_mode()
+    def ttmel_lines_alone(self, lines: List[str], speed: float = 1, speaker_id: int = 0, vowelizer=None,
+                          pitch_mul: float = 1., pitch_add: float = 0., max_duration=75):
+        """`[ttmel_single(l) for l in lines]` as ONE ragged FastPitch call (infer(..., alone=True)): (mel [B, 80, T_max], dec_lens int64
+        [B]) in HBM, rows in the order of `lines`; mel[b, :, :dec_lens[b]] equals ttmel_single(lines[b]) within fp32 summation order
+        (frames past dec_lens[b] are undefined).  What `FastPitch2Wave.tts(list, batch_size=1)` runs per group of lines."""
+        batch_ids = [text.tokens_to_ids(self._tokenize(line, vowelizer), self.phon_to_id) for line in lines]
+        ids = torch.zeros(len(batch_ids), max(len(i) for i in batch_ids), dtype=torch.int64)
+        for b, i in enumerate(batch_ids):
+            ids[b, :len(i)] = torch.as_tensor(i, dtype=torch.int64)
+        mel, dec_lens, *_ = self.infer(ids, pace=speed, speaker=speaker_id, pitch_transform=self._ptrf(pitch_mul, pitch_add, None),
+                                       max_duration=max_duration, alone=True)
+        return mel, dec_lens
 
     @torch.inference_mode()
     def ttmel_batch(self, batch: List[str], speed: float = 1, speaker_id: int = 0, vowelizer=None,
@@ -260,6 +276,8 @@ class FastPitch2Wave(nn.Module):
     # utterances per vocoder call of the list pipeline: chunks of `batch_size` lines go through FastPitch one by one (a chunk is the
     # reference's padded batch: its results depend on the chunk's composition), their mels are vocoded together
     _VOCODER_GROUP = 16
+    # lines per ragged FastPitch + vocoder call of the batch_size = 1 list path (rows computed as if alone: FastPitch.infer(alone=True))
+    _ALONE_GROUP = 32
 
     @torch.inference_mode()
     def _tts_list_pipelined(self, text_input, batch_size, speed, denoise, speaker_id, vowelizer, pitch_mul, pitch_add,
@@ -272,7 +290,12 @@ class FastPitch2Wave(nn.Module):
         (networks.py:340-345; tests: test_hifigan_ragged_batch_matches_unbatched, test_full_size_bench_workload_properties) -- and
         therefore takes the mels of up to _VOCODER_GROUP utterances in ONE ragged call: at batch_size 1 its launches fill the chip
         like a batch-16 call instead of 100 batch-1 calls (C1, 100 lines: 861 -> see DESIGN.md).  Waves equal the one-stream loop's
-        within the vocoder's fp32 summation-order noise (1e-6; a larger batch picks other tiles), lengths exactly."""
+        within the vocoder's fp32 summation-order noise (1e-6; a larger batch picks other tiles), lengths exactly.
+        batch_size 1 (TTSAMD_TTS_ALONE=0 restores the line-by-line FastPitch calls): FastPitch too is made batch-independent -- batch mode 1
+        of the engine computes every row of a ragged batch as if it were alone (ttsamd_fastpitch_set_batch_mode; tests/test_gpu_alone.py) --
+        so the lines are sorted by length and go through FastPitch AND the vocoder in balanced groups of up to _ALONE_GROUP similar
+        lengths (little padding), waves handed back in input order: 100 launch-bound batch-1 calls of ~1.7 ms become 4 chip-filling ones
+        (C1, 100 lines: 500 -> see DESIGN.md); each wave equals its line-by-line result within fp32 summation order, lengths exactly."""
         dev = self.device
         if getattr(self, '_pipe_streams', None) is None or self._pipe_streams[0].device != dev:
             self._pipe_streams = tuple(torch.cuda.Stream(dev) for _ in range(3))
@@ -284,6 +307,14 @@ class FastPitch2Wave(nn.Module):
         hop = eng.hop
         out, pending = [], None
         group = max(1, self._VOCODER_GROUP // batch_size)           # chunks per vocoder call
+        n_in = len(text_input)
+        order = list(range(n_in))
+        alone_ok = batch_size == 1 and n_in > 1 and os.environ.get('TTSAMD_TTS_ALONE', '1') != '0'
+        if alone_ok:
+            order.sort(key=lambda i: len(text_input[i]))
+            n_groups = (n_in + self._ALONE_GROUP - 1) // self._ALONE_GROUP
+            group = (n_in + n_groups - 1) // n_groups
+            text_input = [text_input[i] for i in order]
 
         def flush(item):
             wave, n, done = item
@@ -296,7 +327,14 @@ class FastPitch2Wave(nn.Module):
         for g0 in range(0, len(chunks), group):
             mels, lens = [], []                                     # this group's utterances in input order
             with torch.cuda.stream(s_fp):
-                for chunk in chunks[g0:g0 + group]:
+                alone = alone_ok and len(chunks[g0:g0 + group]) > 1
+                if alone:
+                    # the batch_size = 1 loop of this group's lines as ONE ragged FastPitch call whose rows are computed as if alone
+                    # (ttsamd_fastpitch_set_batch_mode 1); the mel batch and its lengths go to the vocoder as they are
+                    mel_b, lens_d = self.model.ttmel_lines_alone([c[0] for c in chunks[g0:g0 + group]], speed, speaker_id, vowelizer,
+                                                                 pitch_mul=pitch_mul, pitch_add=pitch_add)
+                    lens = lens_d.cpu().tolist()
+                for chunk in ([] if alone else chunks[g0:g0 + group]):
                     if batch_size == 1:
                         mel = self.model.ttmel_single(chunk[0], speed, speaker_id, vowelizer, pitch_mul=pitch_mul, pitch_add=pitch_add)
                         mels.append(mel)
@@ -307,13 +345,16 @@ class FastPitch2Wave(nn.Module):
                         for j in rev.tolist():
                             mels.append(mel[j, :, :dl[j]])
                             lens.append(int(dl[j]))
-                if len(mels) == 1:
+                if alone:
+                    pass
+                elif len(mels) == 1:
                     mel_b = mels[0][None]
                 else:
                     mel_b = torch.zeros(len(mels), mels[0].shape[0], max(lens), dtype=mels[0].dtype, device=dev)
                     for i, m in enumerate(mels):
                         mel_b[i, :, :lens[i]] = m
-                lens_d = torch.tensor(lens, dtype=torch.int64).to(dev, non_blocking=True)
+                if not alone:
+                    lens_d = torch.tensor(lens, dtype=torch.int64).to(dev, non_blocking=True)
             s_hg.wait_stream(s_fp)
             with torch.cuda.stream(s_hg):
                 mel_b.record_stream(s_hg)
@@ -331,4 +372,9 @@ class FastPitch2Wave(nn.Module):
             flush(pending)
         cur.wait_stream(s_hg)
         cur.wait_stream(s_cp)
+        if alone_ok:                                                # back to the order of the input
+            res = [None] * n_in
+            for pos, w in enumerate(out):
+                res[order[pos]] = w
+            return res
         return out

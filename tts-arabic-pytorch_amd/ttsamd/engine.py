@@ -153,6 +153,7 @@ class FastPitchEngine:
             L.check(self.lib.ttsamd_fastpitch_create(arr, len(arr), C.byref(cfg), C.byref(handle)), 'fastpitch_create')
         self.handle = handle
         self.ws = _Workspace()
+        self._alone = False
 
     def __del__(self):
         if getattr(self, 'handle', None):
@@ -160,13 +161,18 @@ class FastPitchEngine:
             self.handle = None
 
     def infer(self, ids, pace=1.0, dur_tgt=None, pitch_tgt=None, energy_tgt=None, pitch_mul=1.0, pitch_add=0.0,
-              max_duration=75, speaker=0, return_idx=False, lens_hook=None):
+              max_duration=75, speaker=0, return_idx=False, lens_hook=None, alone=False):
         """Same contract as FastPitch.infer (model.py:351-353) with pitch_transform restricted to
         the affine pitch_trf the reference wrappers install (networks.py:38-42,121-122).
         ids int64 [B,L] zero-padded at the end.  Returns (mel [B,80,T_max], dec_lens int64 [B],
         dur_pred [B,L], pitch_pred [B,1,L], energy_pred [B,L] or None).
         `lens_hook(dec_lens_device) -> host ints [B]` replaces the one device->host read of the call (the
-        data-parallel path all-gathers every rank's lengths in that same synchronisation, ttsamd.dp)."""
+        data-parallel path all-gathers every rank's lengths in that same synchronisation, ttsamd.dp).
+        `alone=True`: every row as if it were the only utterance of the call (ttsamd_fastpitch_set_batch_mode 1) -- row b equals
+        infer(ids[b:b+1, :len_b]) within fp32 summation order: the reference's batch_size = 1 loop as one ragged call."""
+        if bool(alone) != self._alone:
+            L.check(self.lib.ttsamd_fastpitch_set_batch_mode(self.handle, int(bool(alone))), 'fastpitch_set_batch_mode')
+            self._alone = bool(alone)
         dev = self.device
         ids = torch.as_tensor(ids).to(device=dev, dtype=torch.int64).contiguous()
         B, Lt = ids.shape

@@ -71,6 +71,7 @@ SYMBOLS = {
                                        _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     'ttsamd_length_regulate': (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'ttsamd_fastpitch_decode': (_I32, [_P, _P, _P, _I32, _I32, _P, _P, _I64, _P]),
+    'ttsamd_fastpitch_set_batch_mode': (_I32, [_P, _I32]),
     'ttsamd_denoiser_create': (_I32, [C.POINTER(_P)]),
     'ttsamd_denoiser_destroy': (_I32, [_P]),
     'ttsamd_denoiser_workspace_bytes': (_I64, [_I32, _I32]),
@@ -128,7 +129,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 6            # == TTSAMD_ABI_VERSION of include/ttsamd.h (struct layouts and argument meanings of this binding)
+ABI_VERSION = 7            # == TTSAMD_ABI_VERSION of include/ttsamd.h (struct layouts and argument meanings of this binding)
 
 
 def load():
