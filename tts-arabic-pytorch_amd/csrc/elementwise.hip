@@ -709,4 +709,16 @@ int32_t launch_add_pos(float* x, const float* pos_table, int32_t pos_stride, con
     return 0;
 }
 
+// out[b] = min(lens[b] + 1, S): how far FastPitch's first conv-FF conv has to compute a row (fastpitch.hip: run_fft)
+__global__ void lens_plus1_kernel(const int64_t* __restrict__ lens, int S, int B, int64_t* __restrict__ out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < B) out[b] = min(lens[b] + 1, (int64_t)S);
+}
+
+int32_t launch_lens_plus1(const int64_t* lens, int32_t S, int32_t B, int64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(lens_plus1_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, S, B, out);
+    TTS_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace ttsamd

@@ -259,6 +259,8 @@ void fastpitch_destroy(FastPitch* h) {
 struct FftWs {
     float *q, *a, *y, *hid, *splitk;
     float* o3;          // split-bf16 mode: the x3 copies of x, y and the attention output ((2 d + d_head) x 4 bytes per position)
+    int64_t* lens1;     // [B] min(len + 1, S), filled by encode / decode for batches of 2 and more (run_fft: ragged conv-FF)
+    bool ragged;        // lens1 is valid
 };
 
 // split-K scratch of the call in flight on this thread (carved from the caller's workspace by encode / decode)
@@ -277,7 +279,7 @@ struct SmallBatchScope {
 };
 
 static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, float* y, const float* res, int B, int S,
-                        const int64_t* lens_in, int relu, hipStream_t s) {
+                        const int64_t* lens_in, int relu, hipStream_t s, const int64_t* lens_out = nullptr) {
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.x = x; p.x_bs = (int64_t)c.cin * S; p.x_cs = S;
@@ -287,7 +289,7 @@ static int32_t run_conv(const FastPitch* h, const PConv& c, const float* x, floa
     p.w_wino4 = c.ww4_off >= 0 ? h->dev + c.ww4_off : nullptr;
     p.y = y; p.y_bs = (int64_t)c.cout * S; p.y_cs = S; p.y_ts = 1;
     p.res = res; p.r_bs = (int64_t)c.cout * S; p.r_cs = S;
-    p.lens_in = lens_in; p.lens_out = nullptr; p.len_in_mul = 1; p.len_out_mul = 1;
+    p.lens_in = lens_in; p.lens_out = lens_out; p.len_in_mul = 1; p.len_out_mul = 1;
     p.Lin = S; p.Nout = S;
     p.Cin = c.cin; p.Cout = c.cout; p.CoutP = cout_padded(c.cout); p.K = c.k;
     p.dil = 1; p.pad = c.k / 2;
@@ -305,7 +307,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
     const int d = h->cfg.d_model;
     const float scale = 1.0f / std::sqrt((float)d_head);
     const bool alone = h->alone.load(std::memory_order_relaxed) != 0;
-    const PConv* ff2_of = nullptr;                      // the layer's second conv-FF conv (octet paths: set per layer below)
+    const PConv *ff2_of = nullptr, *ff0_of = nullptr;   // the layer's conv-FF convs (octet paths: set per layer below)
     const char* ffe = opt_str(OPT_BFO_FF);              // read per call: the tests and A/B runs flip it
     bool octet = default_precision() == 1 && !(ffe && ffe[0] == '0') && d % 64 == 0 && d <= 512 && d_head == 64;
     for (const FftLayer& l : layers)
@@ -373,7 +375,10 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
             std::memset(&cp, 0, sizeof(cp));
             cp.batch = B; cp.len_mul = 1; cp.Lin = S; cp.dil = 1; cp.up = 1; cp.div = 1.f; cp.res_slope = 1.f;
             cp.x = in; cp.y = out_o; cp.y_f32 = out_f; cp.res_f32 = res_f;
-            if (alone && &c == ff2_of) { cp.lens = lens; cp.out_all = 1; }
+            // ragged conv-FF as on the fp32 path below (one length per launch here -- it masks the input and bounds the output): hid on
+            // [0, len], the second conv reads it masked past that and writes x on [0, len] (frame len: finite, zeroed by LayerNorm 2)
+            if (w.ragged && (&c == ff2_of || &c == ff0_of)) cp.lens = (alone && &c == ff2_of) ? lens : w.lens1;
+            else if (alone && &c == ff2_of) { cp.lens = lens; cp.out_all = 1; }
             cp.w = h->dev16 + c.wo3_off; cp.bias = c.b_off >= 0 ? h->dev + c.b_off : nullptr;
             cp.Cin = c.cin; cp.Cout = c.cout; cp.K = c.k; cp.out_slope = out_slope;
             prof_begin(s, 2.0 * c.cout * c.cin * c.k);
@@ -382,7 +387,7 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
             return rc;
         };
         for (const FftLayer& l : layers) {
-            ff2_of = &l.ff2;
+            ff2_of = &l.ff2; ff0_of = &l.ff0;
             TTS_TRY(conv(l.qkv, xo, nullptr, w.q, nullptr, 1.f));
             TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s, t_splitk_ws, t_splitk_ws ? kSplitKFloatsFp : 0));
             TTS_TRY(bfo3_launch_pack(w.a, B, d_head, S, 1.f, ao, s));
@@ -399,8 +404,14 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
         TTS_TRY(launch_attention(w.q, lens, B, d_head, S, scale, w.a, s, t_splitk_ws, t_splitk_ws ? kSplitKFloatsFp : 0));
         TTS_TRY(run_conv(h, l.o_net, w.a, w.y, x, B, S, nullptr, 0, s));
         TTS_TRY(launch_layernorm_cf(w.y, w.y, h->dev + l.ln1_g, h->dev + l.ln1_b, lens, 1, B, d, S, s));
-        TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s));
-        TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, alone ? lens : nullptr, 0, s));
+        // conv-FF (97 % of the layer's FLOPs) only as far as a row's valid frames need it: y is zero past len (LayerNorm 1 masks), frame
+        // len - 1 of the second conv reads hid[len] -- the one un-masked hidden frame that makes a padded batch composition-dependent
+        //  -- so hid is computed on [0, len] (lens1 = min(len + 1, S)), read masked past that, and x written on [0, len):
+        // the tiles past a row's end are never launched (ragged-batch block compaction, common.hpp: live_tile), the result is the
+        // reference's padded-batch arithmetic bit for bit; frames >= len of x keep finite stale values that LayerNorm 2 zeroes
+        const int64_t* l1 = w.ragged ? w.lens1 : nullptr;
+        TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s, l1));
+        TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, alone ? lens : l1, 0, s, w.ragged ? lens : nullptr));
         TTS_TRY(launch_layernorm_cf(x, x, h->dev + l.ln2_g, h->dev + l.ln2_b, lens, 1, B, d, S, s));
     }
     return 0;
@@ -504,6 +515,8 @@ static void carve_enc(const FastPitch* h, Arena& a, int B, int L, EncWs& w) {
     w.log_dur = a.take<float>((int64_t)B * L);
     w.lens = a.take<int64_t>(B);
     w.f.splitk = a.take<float>(kSplitKFloatsFp);
+    w.f.lens1 = a.take<int64_t>(B);
+    w.f.ragged = false;
 }
 
 int64_t fastpitch_encode_workspace_bytes(const FastPitch* h, int32_t B, int32_t L) {
@@ -539,6 +552,10 @@ int32_t fastpitch_encode(const FastPitch* h, const int64_t* ids, int32_t B, int3
     const float* spk = (c.n_speakers > 1 && h->spk_emb >= 0) ? h->dev + h->spk_emb + (int64_t)speaker * d : nullptr;
     TTS_TRY(launch_embed(ids, h->dev + h->word_emb, h->dev + h->pos_enc, h->pos_cap, spk, c.padding_idx, c.n_symbols, B, L, d, x,
                          w.lens, s));
+    if (B >= 2) {
+        TTS_TRY(launch_lens_plus1(w.lens, L, B, w.f.lens1, s));
+        w.f.ragged = true;
+    }
     TTS_TRY(run_fft(h, h->enc, c.in_fft_d_head, x, w.lens, B, L, w.f, s));
     // durations (model.py:367-368)
     TTS_TRY(run_predictor(h, h->dur, x, w.lens, B, L, w.p0, w.p1, w.log_dur, dur_pred, max_duration, 1.f, 0.f, s, w.f.o3));
@@ -565,6 +582,8 @@ static void carve_dec(const FastPitch* h, Arena& a, int B, int T, FftWs& w) {
     w.hid = a.take<float>((int64_t)B * c.out_fft_filter * T);
     w.splitk = a.take<float>(kSplitKFloatsFp);
     w.o3 = a.take<float>((int64_t)B * (2 * c.d_model + c.out_fft_n_heads * c.out_fft_d_head) * T);
+    w.lens1 = a.take<int64_t>(B);
+    w.ragged = false;
 }
 
 int64_t fastpitch_decode_workspace_bytes(const FastPitch* h, int32_t B, int32_t T) {
@@ -591,6 +610,10 @@ int32_t fastpitch_decode(const FastPitch* h, float* x, const int64_t* dec_lens, 
     SmallBatchScope small_f32(B);
     // decoder input = len_regulated + pos_emb*mask (transformer.py:215-219, embed_input=False)
     TTS_TRY(launch_add_pos(x, h->dev + h->pos_dec, h->pos_cap, dec_lens, B, c.d_model, T, s));
+    if (B >= 2) {
+        TTS_TRY(launch_lens_plus1(dec_lens, T, B, w.lens1, s));
+        w.ragged = true;
+    }
     TTS_TRY(run_fft(h, h->dec, c.out_fft_d_head, x, dec_lens, B, T, w, s));
     // proj + permute (model.py:406-408): channel-first output IS the permuted layout
     return run_conv(h, h->proj, x, mel, nullptr, B, T, nullptr, 0, s);
