@@ -407,8 +407,11 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
         // conv-FF (97 % of the layer's FLOPs) only as far as a row's valid frames need it: y is zero past len (LayerNorm 1 masks), frame
         // len - 1 of the second conv reads hid[len] -- the one un-masked hidden frame that makes a padded batch composition-dependent
         //  -- so hid is computed on [0, len] (lens1 = min(len + 1, S)), read masked past that, and x written on [0, len):
-        // the tiles past a row's end are never launched (ragged-batch block compaction, common.hpp: live_tile), the result is the
-        // reference's padded-batch arithmetic bit for bit; frames >= len of x keep finite stale values that LayerNorm 2 zeroes
+        // the tiles past a row's end are never launched (ragged-batch block compaction, common.hpp: live_tile).  Every product the
+        // reference's padded-batch arithmetic feeds into a valid frame is still there; what changes is rounding: an F(4,3) output quad
+        // shares its transformed window, so the frames next to a row's end see zeros instead of the dead hidden frames in terms that
+        // cancel only in exact arithmetic (mel of the B = 32 bench batch: 5e-6 max-abs against the all-frames schedule, tools/fp_digest.py;
+        // the split-bf16 path, which has no transform, is bit-identical).  Frames >= len of x keep finite stale values that LayerNorm 2 zeroes
         const int64_t* l1 = w.ragged ? w.lens1 : nullptr;
         TTS_TRY(run_conv(h, l.ff0, w.y, w.hid, nullptr, B, S, nullptr, 1, s, l1));
         TTS_TRY(run_conv(h, l.ff2, w.hid, x, w.y, B, S, alone ? lens : l1, 0, s, w.ragged ? lens : nullptr));
