@@ -1,8 +1,10 @@
 // HiFi-GAN bias denoiser (vocoder/hifigan/denoiser.py:32-72) on the GPU:
 //   STFT(n_fft 1024, hop 256, hann, center/reflect)  ->  |X| - strength*bias, clamp >= 0, keep
 //   phase  ->  ISTFT (window, overlap-add, divide by the window envelope).
-// Both DFTs run as GEMMs on the MFMA conv engine (a 1x1 "conv" over the frame axis with the
-// windowed DFT matrix as weights): 4.2 MFLOP per frame, 0.7 % of the vocoder's FLOPs.
+// denoise() runs ONE kernel per call for STFT -> gain -> ISTFT frames (denoise_fft_kernel: a block per frame, two radix-4 Stockham
+// FFTs of 1024 points in LDS, 0.1 MFLOP per frame) + the overlap-add; rounds 1-5 ran both DFTs as GEMMs on the MFMA conv engine
+// (a 1x1 "conv" over the frame axis with the windowed DFT matrix as weights: 4.2 MFLOP per frame, two 59 MB matrices through HBM,
+// 0.96 ms per B = 32 call against 0.1x now) -- that path still serves denoiser_bias_spec (one frame, once per model) and Vocos' head.
 // torchaudio itself is absent from the reference tree; semantics are those of
 // torch.stft/istft(center=True, pad_mode='reflect', onesided, unnormalised).
 #include <cmath>
@@ -17,7 +19,7 @@ constexpr int NFFT = 1024, HOP = 256, NBIN = NFFT / 2 + 1;        // 513
 constexpr int SPEC_CP = 1152;                                     // padded to 9 x 128 (co tiles) and % 16
 struct Denoiser {
     float* dev = nullptr;
-    int64_t w_fwd = 0, w_inv = 0, window = 0;
+    int64_t w_fwd = 0, w_inv = 0, window = 0, twiddle = 0;
 };
 
 static const double kTwoPi = 6.283185307179586476925286766559;
@@ -69,6 +71,12 @@ int32_t denoiser_create(Denoiser** out) {
     blob.insert(blob.end(), inv.begin(), inv.end());
     h->window = (int64_t)blob.size();
     blob.insert(blob.end(), wnd.begin(), wnd.end());
+    // twiddles exp(-2 pi i m / 1024) as (cos, -sin) pairs, rounded once from double (denoise_fft_kernel)
+    h->twiddle = (int64_t)blob.size();
+    for (int m = 0; m < NFFT; ++m) {
+        blob.push_back((float)std::cos(kTwoPi * m / NFFT));
+        blob.push_back((float)(-std::sin(kTwoPi * m / NFFT)));
+    }
     hipError_t e = hipMalloc((void**)&h->dev, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void spec_gain_kernel(float* __restrict__ S, c
 // Vocos 'same' (spectral_ops.py:47-75): pad = 384, n_out = HOP*frames.
 __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ Y, const float* __restrict__ win,
                                                           const int64_t* __restrict__ frames, int frames_mul,
-                                                          int frames_add, int pad, int F,
+                                                          int frames_add, int pad, int F, int ks, int ts,
                                                           float* __restrict__ wave, int64_t wave_bs) {
     const int b = blockIdx.y;
     const int m = blockIdx.x * 256 + threadIdx.x;
@@ -157,17 +165,18 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
     for (int t = t_lo; t <= t_hi; ++t) {
         const int k = mp - t * HOP;
         if (k < 0 || k >= NFFT) continue;
-        acc += Y[((int64_t)b * NFFT + k) * F + t];
+        acc += Y[(int64_t)b * NFFT * F + (int64_t)k * ks + (int64_t)t * ts];      // [b][k][F] (ks = F, ts = 1) or [b][F][k] (ks = 1, ts = NFFT)
         env += win[k] * win[k];
     }
     wave[(int64_t)b * wave_bs + m] = acc / env;
 }
 
 int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* frames, int32_t frames_mul, int32_t frames_add,
-                           int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s) {
+                           int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s,
+                           int32_t frame_major) {
     if (n_max <= 0 || B <= 0) return 0;
     hipLaunchKernelGGL(overlap_add_kernel, dim3((n_max + 255) / 256, B), dim3(256), 0, s, Y, win, frames, frames_mul,
-                       frames_add, pad, F, wave, wave_bs);
+                       frames_add, pad, F, frame_major ? 1 : F, frame_major ? NFFT : 1, wave, wave_bs);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -178,6 +187,85 @@ __global__ void mag_frame0_kernel(const float* __restrict__ S, int F, float* __r
     if (f >= NBIN) return;
     const float re = S[(int64_t)f * F], im = S[(int64_t)(NBIN + f) * F];   /* F = the row stride here */
     out[f] = sqrtf(re * re + im * im);
+}
+
+// ---- denoise(): one block per frame.  x_w = window * reflect-padded frame -> X = FFT(x_w) -> X' = X * max(|X| - strength * bias, 0) / |X|
+// (denoiser.py:68-71; the gain is real and depends on |X[k]| = |X[1024 - k]| only, so the Hermitian symmetry of a real signal's spectrum
+// survives and the complex inverse transform of X' is real: exactly irfft of its one-sided half, whose DC / Nyquist bins are real already)
+// -> y = Re(FFT(conj X')) / 1024 * window -> Y[b][t][k], frame-major for the overlap-add.  FFT = five radix-4 Stockham autosort passes
+// over two LDS buffers of 1024 complex (thread i: inputs a[i + 256 r], twiddles tw[r k 256 / p], outputs b[4 (i - k) + k + p r], k = i % p;
+// checked against numpy.fft in double before it was written: 4e-14).
+__device__ __forceinline__ float2 cmul(const float2 a, const float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__device__ __forceinline__ void fft1024_stockham(float2* a, float2* b, const float2* tw, const int i) {
+    // in: a (natural order), out: b after five passes (5 is odd), natural order; both clobbered
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int p = 1 << (2 * s);
+        const int k = i & (p - 1), j = ((i - k) << 2) + k, tstep = 256 >> (2 * s);
+        float2 u0 = a[i], u1 = a[i + 256], u2 = a[i + 512], u3 = a[i + 768];
+        if (s > 0) {
+            u1 = cmul(u1, tw[(k * tstep) & 1023]);
+            u2 = cmul(u2, tw[(2 * k * tstep) & 1023]);
+            u3 = cmul(u3, tw[(3 * k * tstep) & 1023]);
+        }
+        const float2 a0 = make_float2(u0.x + u2.x, u0.y + u2.y), a1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+        const float2 a2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+        const float2 a3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));            // (u1 - u3) * (-i)
+        b[j] = make_float2(a0.x + a2.x, a0.y + a2.y);
+        b[j + p] = make_float2(a1.x + a3.x, a1.y + a3.y);
+        b[j + 2 * p] = make_float2(a0.x - a2.x, a0.y - a2.y);
+        b[j + 3 * p] = make_float2(a1.x - a3.x, a1.y - a3.y);
+        __syncthreads();
+        float2* t = a; a = b; b = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void denoise_fft_kernel(const float* __restrict__ wave, int64_t wave_bs, const int64_t* __restrict__ ns,
+                                                          const float* __restrict__ bias, float strength,
+                                                          const float* __restrict__ win, const float2* __restrict__ tw_g, int F,
+                                                          float* __restrict__ Y) {
+    __shared__ float2 buf[2][NFFT];
+    __shared__ float2 tw[NFFT];
+    const int b = blockIdx.y, t = blockIdx.x, i = threadIdx.x;
+    const int n = (int)ns[b];
+    if (t >= n / HOP + 1) return;                               // frames the overlap-add never reads
+    const float* wb = wave + (int64_t)b * wave_bs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = i + 256 * r;
+        tw[k] = tw_g[k];
+        int m = t * HOP + k - NFFT / 2;                         // centred frame, reflect padding (stft_frames_kernel)
+        if (m < 0) m = -m;
+        if (m >= n) m = 2 * (n - 1) - m;
+        m = min(max(m, 0), max(n - 1, 0));
+        buf[0][k] = make_float2(n > 0 ? wb[m] * win[k] : 0.f, 0.f);
+    }
+    __syncthreads();
+    fft1024_stockham(buf[0], buf[1], tw, i);                    // X in buf[1]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = i + 256 * r;
+        const float2 x = buf[1][k];
+        const float mag = sqrtf(x.x * x.x + x.y * x.y);
+        const float md = fmaxf(mag - bias[k <= NFFT / 2 ? k : NFFT - k] * strength, 0.f);
+        float2 o;
+        if (mag > 0.f) {
+            const float g = md / mag;
+            o = make_float2(x.x * g, -(x.y * g));               // conj(X'): the inverse transform as a forward one
+        } else {
+            o = make_float2(md, 0.f);                           // angle(0) = 0
+        }
+        buf[0][k] = o;
+    }
+    __syncthreads();
+    fft1024_stockham(buf[0], buf[1], tw, i);
+    float* yb = Y + ((int64_t)b * F + t) * NFFT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = i + 256 * r;
+        yb[k] = buf[1][k].x * (1.0f / NFFT) * win[k];
+    }
 }
 
 struct DnWs {
@@ -257,12 +345,13 @@ int32_t denoise(const Denoiser* h, float* wave, int64_t wave_bs, const int64_t* 
         set_error("denoise: workspace of %lld bytes needed, %lld given", (long long)a.off, (long long)ws_bytes);
         return TTSAMD_ENOMEM;
     }
-    TTS_TRY(stft(h, wave, wave_bs, nsamples, B, F, w, s));
-    hipLaunchKernelGGL(spec_gain_kernel, dim3((F + 255) / 256, NBIN, B), dim3(256), 0, s, w.S, bias_spec, strength, F, dn_stride(F));
+    hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamples, B, w.frames);
+    // STFT -> gain -> ISTFT frames, one block per frame, time-domain frames into X as [b][frame][k]
+    hipLaunchKernelGGL(denoise_fft_kernel, dim3(F, B), dim3(256), 0, s, wave, wave_bs, nsamples, bias_spec, strength, h->dev + h->window,
+                       reinterpret_cast<const float2*>(h->dev + h->twiddle), F, w.X);
     TTS_CHECK_HIP(hipGetLastError());
-    TTS_TRY(dft_gemm(h, true, w.S, w.X, w.frames, B, F, s));
     // center=True: frames = n/HOP + 1 (w.frames), pad = NFFT/2, n_out = HOP*(frames-1)
-    return launch_overlap_add(w.X, h->dev + h->window, w.frames, 1, 0, NFFT / 2, B, dn_stride(F), n_max, wave, wave_bs, s);
+    return launch_overlap_add(w.X, h->dev + h->window, w.frames, 1, 0, NFFT / 2, B, F, n_max, wave, wave_bs, s, /*frame_major=*/1);
 }
 
 }  // namespace ttsamd

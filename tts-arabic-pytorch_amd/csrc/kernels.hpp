@@ -71,7 +71,8 @@ int32_t launch_dwconv7(const float* x, const float* w, const float* bias, const 
 // denoiser and the Vocos ISTFT head
 void build_idft_packed(std::vector<float>& packed_inv, std::vector<float>& window);
 int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* frames, int32_t frames_mul, int32_t frames_add,
-                           int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s);
+                           int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s,
+                           int32_t frame_major = 0);   // Y as [b][k][F] (0) or [b][F][k] (1)
 
 // Profiling of conv launches (bench roofline)
 void prof_begin(hipStream_t s, double flops);
