@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "fft1024.hpp"
 
 namespace ttsamd {
 
@@ -19,7 +20,7 @@ constexpr int NFFT = 1024, HOP = 256, NBIN = NFFT / 2 + 1;        // 513
 constexpr int SPEC_CP = 1152;                                     // padded to 9 x 128 (co tiles) and % 16
 struct Denoiser {
     float* dev = nullptr;
-    int64_t w_fwd = 0, w_inv = 0, window = 0, twiddle = 0;
+    int64_t w_fwd = 0, window = 0, twiddle = 0;
 };
 
 static const double kTwoPi = 6.283185307179586476925286766559;
@@ -29,21 +30,10 @@ static void hann(std::vector<double>& win) {
     for (int k = 0; k < NFFT; ++k) win[k] = 0.5 - 0.5 * std::cos(kTwoPi * k / NFFT);   // periodic hann
 }
 
-// irfft(n=1024, onesided) * window as a 1x1 conv: torch-layout weight [Cout = 1024 (k)][Cin = SPEC_CP]
-void build_idft_packed(std::vector<float>& packed_inv, std::vector<float>& window) {
+// the periodic hann window of both STFT paths (also Vocos' ISTFT head, vocos.hip)
+void hann_window_1024(std::vector<float>& window) {
     std::vector<double> win;
     hann(win);
-    std::vector<float> wi((size_t)NFFT * SPEC_CP, 0.f);
-    for (int f = 0; f < NBIN; ++f) {
-        const double cf = (f == 0 || f == NFFT / 2) ? 1.0 : 2.0;
-        for (int k = 0; k < NFFT; ++k) {
-            const double ang = kTwoPi * (double)((int64_t)f * k % NFFT) / NFFT;
-            wi[(size_t)k * SPEC_CP + f] = (float)(cf * std::cos(ang) * win[k] / NFFT);
-            wi[(size_t)k * SPEC_CP + NBIN + f] = (float)(-cf * std::sin(ang) * win[k] / NFFT);
-        }
-    }
-    packed_inv.resize((size_t)SPEC_CP * NFFT);
-    pack_conv_weight(wi.data(), NFFT, SPEC_CP, 1, packed_inv.data());
     window.resize(NFFT);
     for (int k = 0; k < NFFT; ++k) window[k] = (float)win[k];
 }
@@ -65,18 +55,11 @@ int32_t denoiser_create(Denoiser** out) {
     h->w_fwd = 0;
     blob.resize((size_t)NFFT * SPEC_CP);
     pack_conv_weight(wf.data(), SPEC_CP, NFFT, 1, blob.data());
-    std::vector<float> inv, wnd;
-    build_idft_packed(inv, wnd);
-    h->w_inv = (int64_t)blob.size();
-    blob.insert(blob.end(), inv.begin(), inv.end());
+    std::vector<float> wnd;
+    hann_window_1024(wnd);
     h->window = (int64_t)blob.size();
     blob.insert(blob.end(), wnd.begin(), wnd.end());
-    // twiddles exp(-2 pi i m / 1024) as (cos, -sin) pairs, rounded once from double (denoise_fft_kernel)
-    h->twiddle = (int64_t)blob.size();
-    for (int m = 0; m < NFFT; ++m) {
-        blob.push_back((float)std::cos(kTwoPi * m / NFFT));
-        blob.push_back((float)(-std::sin(kTwoPi * m / NFFT)));
-    }
+    h->twiddle = fft1024_append_twiddles(blob);                 // denoise_fft_kernel
     hipError_t e = hipMalloc((void**)&h->dev, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -121,29 +104,6 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restric
         v = n > 0 ? wave[(int64_t)b * wave_bs + i] : 0.f;
     }
     X[((int64_t)b * NFFT + k) * Fs + t] = v;
-}
-
-// S[b][f | NBIN+f][t] *= max(0, |S| - strength*bias[f]) / |S|     (denoiser.py:68-71)
-__global__ __launch_bounds__(256) void spec_gain_kernel(float* __restrict__ S, const float* __restrict__ bias,
-                                                        float strength, int F, int Fs) {
-    const int b = blockIdx.z, f = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= F) return;
-    float* sb = S + (int64_t)b * SPEC_CP * Fs;
-    const float re = sb[(int64_t)f * Fs + t], im = sb[(int64_t)(NBIN + f) * Fs + t];
-    const float mag = sqrtf(re * re + im * im);
-    const float md = fmaxf(mag - bias[f] * strength, 0.f);
-    float ore, oim;
-    if (mag > 0.f) {
-        const float g = md / mag;
-        ore = re * g;
-        oim = im * g;
-    } else {
-        ore = md;      // angle(0) = 0
-        oim = 0.f;
-    }
-    sb[(int64_t)f * Fs + t] = ore;
-    sb[(int64_t)(NBIN + f) * Fs + t] = oim;
 }
 
 // out[b][m] = sum_t Y[b][m + pad - t*HOP][t] / sum_t w^2[m + pad - t*HOP],  m < HOP*frames - (1024 - 2*pad - HOP)...
@@ -195,32 +155,6 @@ __global__ void mag_frame0_kernel(const float* __restrict__ S, int F, float* __r
 // -> y = Re(FFT(conj X')) / 1024 * window -> Y[b][t][k], frame-major for the overlap-add.  FFT = five radix-4 Stockham autosort passes
 // over two LDS buffers of 1024 complex (thread i: inputs a[i + 256 r], twiddles tw[r k 256 / p], outputs b[4 (i - k) + k + p r], k = i % p;
 // checked against numpy.fft in double before it was written: 4e-14).
-__device__ __forceinline__ float2 cmul(const float2 a, const float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-
-__device__ __forceinline__ void fft1024_stockham(float2* a, float2* b, const float2* tw, const int i) {
-    // in: a (natural order), out: b after five passes (5 is odd), natural order; both clobbered
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int p = 1 << (2 * s);
-        const int k = i & (p - 1), j = ((i - k) << 2) + k, tstep = 256 >> (2 * s);
-        float2 u0 = a[i], u1 = a[i + 256], u2 = a[i + 512], u3 = a[i + 768];
-        if (s > 0) {
-            u1 = cmul(u1, tw[(k * tstep) & 1023]);
-            u2 = cmul(u2, tw[(2 * k * tstep) & 1023]);
-            u3 = cmul(u3, tw[(3 * k * tstep) & 1023]);
-        }
-        const float2 a0 = make_float2(u0.x + u2.x, u0.y + u2.y), a1 = make_float2(u0.x - u2.x, u0.y - u2.y);
-        const float2 a2 = make_float2(u1.x + u3.x, u1.y + u3.y);
-        const float2 a3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));            // (u1 - u3) * (-i)
-        b[j] = make_float2(a0.x + a2.x, a0.y + a2.y);
-        b[j + p] = make_float2(a1.x + a3.x, a1.y + a3.y);
-        b[j + 2 * p] = make_float2(a0.x - a2.x, a0.y - a2.y);
-        b[j + 3 * p] = make_float2(a1.x - a3.x, a1.y - a3.y);
-        __syncthreads();
-        float2* t = a; a = b; b = t;
-    }
-}
-
 __global__ __launch_bounds__(256) void denoise_fft_kernel(const float* __restrict__ wave, int64_t wave_bs, const int64_t* __restrict__ ns,
                                                           const float* __restrict__ bias, float strength,
                                                           const float* __restrict__ win, const float2* __restrict__ tw_g, int F,
@@ -289,14 +223,15 @@ int64_t denoiser_workspace_bytes(int32_t B, int32_t n_max) {
     return a.off;
 }
 
-static int32_t dft_gemm(const Denoiser* h, bool inverse, const float* x, float* y, const int64_t* frames, int B,
+// forward DFT of the frame matrix as a GEMM on the conv engine (denoiser_bias_spec only: one utterance, once per model)
+static int32_t dft_gemm(const Denoiser* h, const float* x, float* y, const int64_t* frames, int B,
                         int F, hipStream_t s) {
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
-    const int cin = inverse ? SPEC_CP : NFFT, cout = inverse ? NFFT : SPEC_CP;
+    const int cin = NFFT, cout = SPEC_CP;
     const int Fs = dn_stride(F);
     p.x = x; p.x_bs = (int64_t)cin * Fs; p.x_cs = Fs;
-    p.w = h->dev + (inverse ? h->w_inv : h->w_fwd); p.bias = nullptr;
+    p.w = h->dev + h->w_fwd; p.bias = nullptr;
     p.y = y; p.y_bs = (int64_t)cout * Fs; p.y_cs = Fs; p.y_ts = 1;
     p.lens_in = frames; p.lens_out = frames; p.len_in_mul = 1; p.len_out_mul = 1;
     p.Lin = F; p.Nout = F; p.Cin = cin; p.Cout = cout; p.CoutP = cout; p.K = 1;
@@ -312,7 +247,7 @@ static int32_t stft(const Denoiser* h, const float* wave, int64_t wave_bs, const
     hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ns, B, w.frames);
     hipLaunchKernelGGL(stft_frames_kernel, dim3((F + 255) / 256, NFFT, B), dim3(256), 0, s, wave, wave_bs, ns, F, dn_stride(F), w.X);
     TTS_CHECK_HIP(hipGetLastError());
-    return dft_gemm(h, false, w.X, w.S, w.frames, B, F, s);
+    return dft_gemm(h, w.X, w.S, w.frames, B, F, s);
 }
 
 int32_t denoiser_bias_spec(const Denoiser* h, const float* audio, const int64_t* n_dev, int32_t n, float* bias_out,

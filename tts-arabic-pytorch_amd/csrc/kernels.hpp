@@ -69,7 +69,7 @@ int32_t launch_dwconv7(const float* x, const float* w, const float* bias, const 
 
 // inverse-DFT (irfft * hann / N) weights in the conv engine's packed layout + the window; shared by the
 // denoiser and the Vocos ISTFT head
-void build_idft_packed(std::vector<float>& packed_inv, std::vector<float>& window);
+void hann_window_1024(std::vector<float>& window);   // periodic hann, n = 1024 (denoiser.hip)
 int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* frames, int32_t frames_mul, int32_t frames_add,
                            int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s,
                            int32_t frame_major = 0);   // Y as [b][k][F] (0) or [b][F][k] (1)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "fft1024.hpp"
 
 namespace ttsamd {
 
@@ -31,7 +32,7 @@ struct Vocos {
     uint16_t* dev16 = nullptr;
     int in_ch = 80, dim = 512, inter = 1536;
     VConv embed, head;
-    int64_t n0_g, n0_b, fl_g, fl_b, w_inv, window;
+    int64_t n0_g, n0_b, fl_g, fl_b, window, twiddle;
     std::vector<VBlock> blocks;
 };
 
@@ -121,12 +122,11 @@ int32_t vocos_create(const ttsamd_tensor* weights, int32_t n, int32_t in_ch, int
     h->head = b.conv("head.out", dim, V_NFFT + 2, 1, V_SPEC_CP);
     int32_t rc = b.rc;
     if (rc == 0) {
-        std::vector<float> inv, wnd;
-        build_idft_packed(inv, wnd);
-        h->w_inv = (int64_t)b.blob.size();
-        b.blob.insert(b.blob.end(), inv.begin(), inv.end());
+        std::vector<float> wnd;
+        hann_window_1024(wnd);
         h->window = (int64_t)b.blob.size();
         b.blob.insert(b.blob.end(), wnd.begin(), wnd.end());
+        h->twiddle = fft1024_append_twiddles(b.blob);            // vocos_istft_kernel
         hipError_t e = hipMalloc((void**)&h->dev, b.blob.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->dev, b.blob.data(), b.blob.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&h->dev16, b.blob16.size() * sizeof(uint16_t));
@@ -152,19 +152,66 @@ void vocos_destroy(Vocos* h) {
     delete h;
 }
 
-// S[f][t] = clamp(exp(O[f]) - dn*bias[f], 0, 100) * cos(O[513+f]);  S[513+f][t] = ... * sin   (pretrained.py:79-90)
-__global__ __launch_bounds__(256) void vocos_spec_kernel(float* __restrict__ O, const float* __restrict__ bias,
-                                                         float denoise, int T) {
-    const int b = blockIdx.z, f = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    float* ob = O + (int64_t)b * V_SPEC_CP * T;
-    const float lm = ob[(int64_t)f * T + t], ph = ob[(int64_t)(V_NBIN + f) * T + t];
-    float mag = expf(lm);
-    if (bias) mag -= denoise * bias[f];
-    mag = fminf(fmaxf(mag, 0.f), 100.f);
-    ob[(int64_t)f * T + t] = mag * cosf(ph);
-    ob[(int64_t)(V_NBIN + f) * T + t] = mag * sinf(ph);
+// ISTFT head (pretrained.py:79-90, spectral_ops.py:47-75) in two launches + the overlap-add.
+// 1. S[b][t][f] = clamp(exp(O[f][t]) - dn * bias[f], 0, 100) * (cos, sin)(O[513 + f][t]): the head's channel-first output [1026][T] read along t,
+//    the complex spectrum written FRAME-major (f contiguous) through a 32 x 33 LDS tile, so that
+// 2. one block per frame reads its 513 bins contiguously, builds conj(X) of the Hermitian extension (X[k] = S[k], X[1024 - k] = conj S[k]; the
+//    imaginary parts of DC and Nyquist dropped as irfft does), runs ONE 1024-point FFT in LDS (fft1024.hpp) and writes Re / 1024 * window as
+//    Y[b][t][k].  Rounds 1-5 ran the inverse DFT as a [1152 -> 1024] GEMM on the conv engine: 300 us per B = 32 call (40x the FLOPs).
+__global__ __launch_bounds__(256) void vocos_spec_t_kernel(const float* __restrict__ O, const float* __restrict__ bias, float denoise,
+                                                           const int64_t* __restrict__ lens, int T, float2* __restrict__ S) {
+    __shared__ float2 tile[32][33];
+    const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int len = lens ? min((int)lens[b], T) : T;
+    if (t0 >= len) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const float* ob = O + (int64_t)b * V_SPEC_CP * T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + ty + 8 * r, t = t0 + tx;
+        float2 v = make_float2(0.f, 0.f);
+        if (f < V_NBIN && t < len) {
+            const float lm = ob[(int64_t)f * T + t], ph = ob[(int64_t)(V_NBIN + f) * T + t];
+            float mag = expf(lm);
+            if (bias) mag -= denoise * bias[f];
+            mag = fminf(fmaxf(mag, 0.f), 100.f);
+            v = make_float2(mag * cosf(ph), mag * sinf(ph));
+        }
+        tile[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, f = f0 + tx;
+        if (t < len && f < V_NBIN) S[((int64_t)b * T + t) * V_NBIN + f] = tile[tx][ty + 8 * r];
+    }
+}
+
+__global__ __launch_bounds__(256) void vocos_istft_kernel(const float2* __restrict__ S, const int64_t* __restrict__ lens,
+                                                          const float* __restrict__ win, const float2* __restrict__ tw_g, int T,
+                                                          float* __restrict__ Y) {
+    __shared__ float2 buf[2][V_NFFT];
+    __shared__ float2 tw[V_NFFT];
+    const int b = blockIdx.y, t = blockIdx.x, i = threadIdx.x;
+    if (lens && t >= (int)lens[b]) return;                       // frames the overlap-add never reads
+    const float2* sb = S + ((int64_t)b * T + t) * V_NBIN;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = i + 256 * r;
+        tw[k] = tw_g[k];
+        float2 x = sb[k <= V_NFFT / 2 ? k : V_NFFT - k];         // conj(X)[k]: conj S[k] below Nyquist, S[1024 - k] above
+        if (k <= V_NFFT / 2) x.y = -x.y;
+        if (k == 0 || k == V_NFFT / 2) x.y = 0.f;
+        buf[0][k] = x;
+    }
+    __syncthreads();
+    fft1024_stockham(buf[0], buf[1], tw, i);
+    float* yb = Y + ((int64_t)b * T + t) * V_NFFT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = i + 256 * r;
+        yb[k] = buf[1][k].x * (1.0f / V_NFFT) * win[k];
+    }
 }
 
 // bias_vec[f] = min(exp(O[f][0]), 100)   (pretrained.py:65-69)
@@ -263,24 +310,17 @@ int32_t vocos_forward(const Vocos* h, const float* mel, const int64_t* lens, int
         return TTSAMD_ENOMEM;
     }
     TTS_TRY(vocos_features(h, mel, lens, B, T, w, s));
-    hipLaunchKernelGGL(vocos_spec_kernel, dim3((T + 255) / 256, V_NBIN, B), dim3(256), 0, s, w.o,
-                       denoise != 0.f ? bias_vec : nullptr, denoise, T);
+    // complex spectrum frame-major into the (dead) hidden buffer of the backbone: 513 float2 per frame <= inter floats
+    TTS_REQUIRE(2 * V_NBIN <= h->inter, "vocos_forward: the spectrum does not fit the hidden buffer (inter %d)", h->inter);
+    float2* S = reinterpret_cast<float2*>(w.h);
+    hipLaunchKernelGGL(vocos_spec_t_kernel, dim3((T + 31) / 32, (V_NBIN + 31) / 32, B), dim3(256), 0, s, w.o,
+                       denoise != 0.f ? bias_vec : nullptr, denoise, lens, T, S);
+    hipLaunchKernelGGL(vocos_istft_kernel, dim3(T, B), dim3(256), 0, s, S, lens, h->dev + h->window,
+                       reinterpret_cast<const float2*>(h->dev + h->twiddle), T, w.y);
     TTS_CHECK_HIP(hipGetLastError());
-    // inverse DFT * window as a 1x1 conv [V_SPEC_CP -> 1024], then overlap-add with "same" trimming
-    ConvParams p;
-    std::memset(&p, 0, sizeof(p));
-    p.x = w.o; p.x_bs = (int64_t)V_SPEC_CP * T; p.x_cs = T;
-    p.w = h->dev + h->w_inv; p.bias = nullptr;
-    p.y = w.y; p.y_bs = (int64_t)V_NFFT * T; p.y_cs = T; p.y_ts = 1;
-    p.lens_in = lens; p.lens_out = lens; p.len_in_mul = 1; p.len_out_mul = 1;
-    p.Lin = T; p.Nout = T; p.Cin = V_SPEC_CP; p.Cout = V_NFFT; p.CoutP = V_NFFT; p.K = 1;
-    p.dil = 1; p.pad = 0; p.n_phase = 1; p.in_slope = 1.f; p.mode = 0; p.div = 1.f; p.batch = B;
-    prof_begin(s, 2.0 * V_SPEC_CP * V_NFFT);
-    const int32_t rc = launch_conv(p, s);
-    prof_end(s);
-    TTS_TRY(rc);
+    // overlap-add with "same" trimming (pad = (n_fft - hop) / 2, n_out = hop * frames) over the frame-major time-domain frames
     return launch_overlap_add(w.y, h->dev + h->window, lens, 1, 0, (V_NFFT - V_HOP) / 2, B, T, V_HOP * T, wave,
-                              (int64_t)V_HOP * T, s);
+                              (int64_t)V_HOP * T, s, /*frame_major=*/1);
 }
 
 }  // namespace ttsamd
