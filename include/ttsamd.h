@@ -369,7 +369,7 @@ int32_t ttsamd_bfo3_conv_post(const void* x, const float* w, const float* bias, 
  *   1 bf16 operands, fp32 accumulate — config 3: HiFi-GAN on the octet engine above (v_mfma_f32_32x32x16_bf16, bf16
  *     activations in HBM), the other models on v_mfma_f32_32x32x8_bf16_1k with fp32 activations;
  *   2 split bf16 (x = hi + lo, 3 MFMAs per product): fp32-class accuracy at bf16 MFMA rate.
- * Activations, LayerNorm, softmax, tanh, the DFTs and all integer work stay fp32/int64. */
+ * Activations, LayerNorm, softmax, tanh, the FFTs and all integer work stay fp32/int64. */
 int32_t ttsamd_set_precision(int32_t precision);
 int32_t ttsamd_get_precision(void);
 

@@ -4,8 +4,8 @@
 // Replaces every F.conv1d / F.conv_transpose1d / F.linear the reference issues on the hot
 // path: HiFi-GAN conv_pre / ups / ResBlock1 convs (vocoder/hifigan/models.py:46-53,
 // 111-127), FastPitch conv-FF, qkv/o_net/proj, predictor convs
-// (models/fastpitch/fastpitch/transformer.py:59-65,122,148; model.py:54-57,406) and the
-// two DFT GEMMs of the denoiser.
+// (models/fastpitch/fastpitch/transformer.py:59-65,122,148; model.py:54-57,406), Vocos' pointwise convs and the
+// forward DFT of the denoiser's bias spectrum.
 //
 // GEMM view per utterance b:  Y[co][q] = sum_{ci,tap} W[co][ci][tap] * X[ci][q + tap*dil - pad]
 //   M = co (A operand = weights), N = q (time, B operand = activations), K = (ci, tap).

@@ -411,7 +411,7 @@ int wino_route(const ConvParams& p) {
     const char* e = opt_str(OPT_WINO);
     if (e && e[0] == '0') return 0;
     if (p.K == 1) {
-        // k = 1 (Vocos' pointwise convs, the denoiser's DFT, FastPitch's projections) on the F(4,3) kernel's skeleton with nothing to transform
+        // k = 1 (Vocos' pointwise convs and head, FastPitch's qkv / o_net projections) on the F(4,3) kernel's skeleton with nothing to transform
         // (conv_wino4.hip, Wino4Geo::WSHARE): the direct engine's packed weights as they are; TTSAMD_WINO4 bit 4.  Same tile, same block rule.
         const char* e4 = opt_str(OPT_WINO4);
         const int mask4 = e4 ? atoi(e4) : 31;

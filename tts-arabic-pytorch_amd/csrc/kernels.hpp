@@ -67,8 +67,7 @@ int32_t launch_add_pos(float* x, const float* pos_table, int32_t pos_stride, con
 int32_t launch_dwconv7(const float* x, const float* w, const float* bias, const int64_t* lens, int32_t B, int32_t C,
                        int32_t S, float* y, hipStream_t s);
 
-// inverse-DFT (irfft * hann / N) weights in the conv engine's packed layout + the window; shared by the
-// denoiser and the Vocos ISTFT head
+// the window and the overlap-add shared by the denoiser and the Vocos ISTFT head
 void hann_window_1024(std::vector<float>& window);   // periodic hann, n = 1024 (denoiser.hip)
 int32_t launch_overlap_add(const float* Y, const float* win, const int64_t* frames, int32_t frames_mul, int32_t frames_add,
                            int32_t pad, int32_t B, int32_t F, int32_t n_max, float* wave, int64_t wave_bs, hipStream_t s,

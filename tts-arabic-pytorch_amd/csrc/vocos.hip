@@ -2,9 +2,9 @@
 // Replaces vocoder/vocos/pretrained.py:34-93 (MelVocos.__init__/make_denoising_vector/forward),
 // models.py:77-89 (VocosBackbone.forward), modules.py:43-60 (ConvNeXtBlock.forward),
 // heads.py:41 (ISTFTHead.out) and spectral_ops.py:33-75 (ISTFT.forward, padding="same").
-// embed / pwconv1 (+GELU) / pwconv2 (x gamma, + residual) / head.out and the inverse DFT all run
-// on the MFMA conv engine; depthwise conv, LayerNorm (eps 1e-6), exp/cos/sin and the
-// overlap-add are HBM-bound kernels.  Ragged batches: every layer reads positions >= lens[b]
+// embed / pwconv1 (+GELU) / pwconv2 (x gamma, + residual) / head.out run on the MFMA conv engine; the
+// ISTFT is one 1024-point FFT per frame in LDS (vocos_istft_kernel, fft1024.hpp); depthwise conv,
+// LayerNorm (eps 1e-6), exp/cos/sin (+ the transposition to frame-major) and the overlap-add are HBM-bound kernels.  Ragged batches: every layer reads positions >= lens[b]
 // as zero, i.e. utterance b equals MelVocos.forward(mel[b:b+1, :, :lens[b]]).
 #include <cmath>
 #include <cstring>
