@@ -278,6 +278,7 @@ class FastPitch2Wave(nn.Module):
     _VOCODER_GROUP = 16
     # lines per ragged FastPitch + vocoder call of the batch_size = 1 list path (rows computed as if alone: FastPitch.infer(alone=True))
     _ALONE_GROUP = 32
+    _ALONE_CHARS = 12288         # ... and at most this many characters x lines per call (lines x the longest line: bounds the padded batch)
 
     @torch.inference_mode()
     def _tts_list_pipelined(self, text_input, batch_size, speed, denoise, speaker_id, vowelizer, pitch_mul, pitch_add,
@@ -324,17 +325,29 @@ class FastPitch2Wave(nn.Module):
                 out.extend(wave[j, :n[j]].cpu() for j in range(len(n)))      # blocks the host on THIS group's audio only
 
         chunks = [text_input[k:k + batch_size] for k in range(0, len(text_input), batch_size)]
-        for g0 in range(0, len(chunks), group):
+        groups = [chunks[g0:g0 + group] for g0 in range(0, len(chunks), group)]
+        if alone_ok:
+            # lines are sorted by length: fill a group until it has `group` lines or lines x longest line passes the budget (a list of very
+            # long lines must not become one 32-row batch padded to the longest)
+            groups, fill = [], []
+            for ch in chunks:
+                if fill and (len(fill) >= group or (len(fill) + 1) * len(ch[0]) > self._ALONE_CHARS):
+                    groups.append(fill)
+                    fill = []
+                fill.append(ch)
+            if fill:
+                groups.append(fill)
+        for grp in groups:
             mels, lens = [], []                                     # this group's utterances in input order
             with torch.cuda.stream(s_fp):
-                alone = alone_ok and len(chunks[g0:g0 + group]) > 1
+                alone = alone_ok and len(grp) > 1
                 if alone:
                     # the batch_size = 1 loop of this group's lines as ONE ragged FastPitch call whose rows are computed as if alone
                     # (ttsamd_fastpitch_set_batch_mode 1); the mel batch and its lengths go to the vocoder as they are
-                    mel_b, lens_d = self.model.ttmel_lines_alone([c[0] for c in chunks[g0:g0 + group]], speed, speaker_id, vowelizer,
+                    mel_b, lens_d = self.model.ttmel_lines_alone([c[0] for c in grp], speed, speaker_id, vowelizer,
                                                                  pitch_mul=pitch_mul, pitch_add=pitch_add)
                     lens = lens_d.cpu().tolist()
-                for chunk in ([] if alone else chunks[g0:g0 + group]):
+                for chunk in ([] if alone else grp):
                     if batch_size == 1:
                         mel = self.model.ttmel_single(chunk[0], speed, speaker_id, vowelizer, pitch_mul=pitch_mul, pitch_add=pitch_add)
                         mels.append(mel)
