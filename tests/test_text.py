@@ -56,3 +56,26 @@ def test_text_collate_fn(golden):
     assert torch.equal(padded, torch.from_numpy(g['collate5_padded']))
     assert torch.equal(lens, torch.from_numpy(g['collate5_lens']))
     assert torch.equal(rev, torch.from_numpy(g['collate5_rev']))
+
+
+def test_list_path_groups_of_the_batch_size_1_pipeline():
+    """Host logic of `FastPitch2Wave.tts(list, batch_size=1)` (models/fastpitch/networks.py: _alone_groups): length-sorted lines go to the
+    ragged FastPitch call in groups of at most `group` lines AND at most budget characters x lines (lines x the longest line of the group);
+    every line lands in exactly one group, in order."""
+    pytest.importorskip('ttsamd.lib')
+    from ttsamd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        pytest.skip('libttsamd.so not built')
+    from models.fastpitch.networks import FastPitch2Wave
+    f = FastPitch2Wave._alone_groups
+    assert f([], 25, 1000) == []
+    assert f([5], 25, 1000) == [[0]]
+    lens = sorted([35 + 3 * i for i in range(100)])
+    g = f(lens, 25, 12288)
+    assert [len(x) for x in g] == [25, 25, 25, 25] and sum(g, []) == list(range(100))
+    g = f([1000] * 40, 32, 12288)                                   # very long lines: 12 per call, not 32
+    assert [len(x) for x in g] == [12, 12, 12, 4] and sum(g, []) == list(range(40))
+    g = f([10, 10, 10, 5000, 20000], 32, 12288)                     # a line longer than the budget still goes through, alone
+    assert g == [[0, 1, 2], [3], [4]]
+    for x in f(lens, 7, 600):
+        assert len(x) <= 7 and (len(x) == 1 or len(x) * lens[x[-1]] <= 600)

@@ -280,6 +280,20 @@ class FastPitch2Wave(nn.Module):
     _ALONE_GROUP = 32
     _ALONE_CHARS = 12288         # ... and at most this many characters x lines per call (lines x the longest line: bounds the padded batch)
 
+    @staticmethod
+    def _alone_groups(lengths, group, budget):
+        """Index groups over lines SORTED by length (ascending `lengths`): a group is filled until it has `group` lines or
+        lines x longest line would pass `budget` -- a list of very long lines must not become one 32-row batch padded to the longest."""
+        groups, fill = [], []
+        for i, n in enumerate(lengths):
+            if fill and (len(fill) >= group or (len(fill) + 1) * n > budget):
+                groups.append(fill)
+                fill = []
+            fill.append(i)
+        if fill:
+            groups.append(fill)
+        return groups
+
     @torch.inference_mode()
     def _tts_list_pipelined(self, text_input, batch_size, speed, denoise, speaker_id, vowelizer, pitch_mul, pitch_add,
                             return_mel=False):
@@ -327,16 +341,7 @@ class FastPitch2Wave(nn.Module):
         chunks = [text_input[k:k + batch_size] for k in range(0, len(text_input), batch_size)]
         groups = [chunks[g0:g0 + group] for g0 in range(0, len(chunks), group)]
         if alone_ok:
-            # lines are sorted by length: fill a group until it has `group` lines or lines x longest line passes the budget (a list of very
-            # long lines must not become one 32-row batch padded to the longest)
-            groups, fill = [], []
-            for ch in chunks:
-                if fill and (len(fill) >= group or (len(fill) + 1) * len(ch[0]) > self._ALONE_CHARS):
-                    groups.append(fill)
-                    fill = []
-                fill.append(ch)
-            if fill:
-                groups.append(fill)
+            groups = [[chunks[i] for i in g] for g in self._alone_groups([len(ch[0]) for ch in chunks], group, self._ALONE_CHARS)]
         for grp in groups:
             mels, lens = [], []                                     # this group's utterances in input order
             with torch.cuda.stream(s_fp):
