@@ -654,6 +654,30 @@ def test_negative_forced_durations_give_zero_repeats(dev, fastpitch_engine):
     assert int(dec_lens[0]) == 3 and mel.shape[2] == 3 and bool(torch.isfinite(mel).all())
 
 
+def test_denoiser_ragged_batch_equals_the_oracle_per_utterance(dev):
+    """`denoise_fft_kernel` (one block per frame: window x reflect-padded samples -> FFT-1024 in LDS -> spectral subtraction -> inverse FFT) +
+    the overlap-add on a ragged batch -- lengths that are and are not multiples of the hop, one just above the reflect-pad minimum, strong
+    setting: every row equals the oracle's torch.stft / istft run on that row alone (vocoder/hifigan/denoiser.py:66-72); samples past a
+    row's length stay untouched."""
+    import tts_oracle as O
+    from ttsamd.engine import DenoiserEngine
+    g = torch.Generator().manual_seed(11)
+    ns = [256 * 37, 256 * 12 + 100, 513, 256 * 40, 3000]
+    wave = torch.randn(len(ns), max(ns), generator=g) * 0.2
+    bias = torch.rand(1, 513, 1, generator=g) * 3.0
+    eng = DenoiserEngine(device=dev)
+    out = eng.denoise(wave.to(dev).clone().contiguous(), torch.tensor(ns).to(dev), bias.to(dev), 1.0).cpu()
+    worst = 0.0
+    for b, n in enumerate(ns):
+        ref = O.denoise(wave[b:b + 1, :n], bias, 1.0)
+        m = ref.shape[1]                                                   # istft(center) returns hop * (frames - 1) samples
+        worst = max(worst, float((out[b, :m] - ref[0]).abs().max()))
+        assert float((ref[0] - wave[b, :m]).abs().max()) > 1e-2           # the setting changes the signal
+        assert torch.equal(out[b, n:], wave[b, n:])
+    print(f'ragged denoise, 5 rows: max-abs {worst:.2e} (tol {WAVE_TOL})')
+    assert worst < WAVE_TOL
+
+
 def test_denoiser_rejects_utterances_of_at_most_512_samples(dev, hifigan_engine):
     """torch's reflect pad (Spectrogram(center=True), denoiser.py:43-48) raises when n <= n_fft/2; the ragged batch
     path must not read outside the row instead (2 mel frames = 512 samples next to a normal utterance)."""
