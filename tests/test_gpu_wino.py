@@ -183,11 +183,12 @@ def test_wino_decomposition_k3_k7_k11(dev, monkeypatch, k, d, cin, cout, L, B, m
 
 
 @pytest.mark.parametrize('cin,cout,L,B,act,mode', [
+    # (every case is >= 512 blocks of 64 rows x 256 outputs: what wino_route asks of a k = 1 launch)
     (512, 1536, 496, 12, 2, None),       # Vocos pwconv1 + GELU
-    (1536, 512, 500, 12, 0, 0),          # pwconv2 + residual
-    (384, 192, 1030, 8, 0, None),        # FastPitch's qkv projection: three 64-row blocks
-    (64, 384, 1030, 8, 0, 0),            # ... o_net: two 32-channel chunks
-    (256, 256, 777, 8, 1, 0), (256, 256, 777, 8, 0, 1), (256, 128, 2052, 4, 0, 2), (512, 512, 300, 24, 3, None),
+    (1536, 512, 500, 32, 0, 0),          # pwconv2 + residual
+    (384, 192, 1030, 36, 0, None),       # FastPitch's qkv projection: three 64-row blocks
+    (64, 384, 1030, 18, 0, 0),           # ... o_net: two 32-channel chunks
+    (256, 256, 777, 32, 1, 0), (256, 256, 777, 32, 0, 1), (256, 128, 2052, 32, 0, 2), (512, 512, 300, 32, 3, None),
 ])
 def test_k1_gemm_on_the_wino4_skeleton(dev, cin, cout, L, B, act, mode, ttsopt):
     """k = 1 (conv_wino4.hip, Wino4Geo::WSHARE -- TTSAMD_WINO4 bit 4): a pointwise conv as the four single-tap planes of the F(4,3) kernel,
@@ -228,6 +229,7 @@ def test_k1_gemm_on_the_wino4_skeleton(dev, cin, cout, L, B, act, mode, ttsopt):
     print(f'k=1 cin={cin} cout={cout} act={act} mode={mode}: max-abs {worst:.2e}')
     assert worst < 2e-5
     # same products in the same order: bit for bit the direct kernel's result unless that one splits K (under 320 blocks of its own tiles)
+    # or preloads the residual into its accumulators (other summation order of the epilogue terms)
     same = torch.equal(outs['31'], outs['15'])
     print('   bit-identical to conv1d_mfma_f32<1>:', same)
     assert float((outs['31'] - outs['15']).abs().max()) < 2e-5

@@ -412,7 +412,7 @@ int wino_route(const ConvParams& p) {
     if (e && e[0] == '0') return 0;
     if (p.K == 1) {
         // k = 1 (Vocos' pointwise convs and head, FastPitch's qkv / o_net projections) on the F(4,3) kernel's skeleton with nothing to transform
-        // (conv_wino4.hip, Wino4Geo::WSHARE): the direct engine's packed weights as they are; TTSAMD_WINO4 bit 4.  Same tile, same block rule.
+        // (conv_wino4.hip, Wino4Geo::WSHARE): the direct engine's packed weights as they are; TTSAMD_WINO4 bit 4.  Same tile as the F(4,3) launches.
         const char* e4 = opt_str(OPT_WINO4);
         const int mask4 = e4 ? atoi(e4) : 31;
         const bool ok1 = (mask4 & 16) && p.w != nullptr && p.dil == 1 && p.pad == 0 && p.n_phase == 1 && p.y_ts == 1 && p.CoutP % 64 == 0 &&
@@ -422,7 +422,9 @@ int wino_route(const ConvParams& p) {
                          (int64_t)p.Cout * std::max(std::max(p.r_cs, p.y_cs), 1) * 4 < ((int64_t)1 << 31);
         if (!ok1) return 0;
         const int64_t blocks1 = (int64_t)((p.Nout + 255) / 256) * (p.CoutP / 64) * p.batch * wino4_ksplit(p);
-        return (blocks1 >= 192 && p.Nout >= 256) ? 3 : 0;
+        // one full round of the chip's 512 block slots or more: Vocos' GEMMs (512 ... 1536 blocks); FastPitch's qkv / o_net at batch 32 (192 / 384
+        // blocks) stay on the direct kernel's smaller tiles -- same-box A/B of the step: 52.43 ms with them here, 52.33 without
+        return (blocks1 >= 512 && p.Nout >= 256) ? 3 : 0;
     }
     if ((p.w_wino == nullptr && p.w_wino4 == nullptr) || (p.K != 3 && p.K != 7 && p.K != 11)) return 0;
     if (p.w_wino4 != nullptr) {
