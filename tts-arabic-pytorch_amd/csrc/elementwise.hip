@@ -378,6 +378,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const float* qb = qkv + (int64_t)b * 3 * ATT_D * S;
     const float* kb = qb + (int64_t)ATT_D * S;
     const float* vb = kb + (int64_t)ATT_D * S;
+    if (qbase >= len) {
+        // a block of queries past the utterance's end (ragged batch: the longest of config 1's lines is 1.55x the mean of its group):
+        // their rows are masked by the LayerNorm behind o_net (a k = 1 conv: no neighbour reads them), so zeros instead of a walk over
+        // all key tiles -- finite, because that LayerNorm masks by multiplication
+        float* ob = out + (int64_t)b * ATT_D * S;
+        for (int e = tid; e < ATT_D * QT; e += 256) {
+            const int d = e / QT, i = qbase + e % QT;
+            if (i < S) ob[(int64_t)d * S + i] = 0.f;
+        }
+        return;
+    }
 
     for (int e = tid; e < ATT_D * QT; e += 256) {
         const int d = e / QT, i = e % QT;
