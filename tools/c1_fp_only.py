@@ -1,0 +1,23 @@
+"""FastPitch alone on config 1's lines as the batch_size = 1 list path runs it (4 ragged calls of 25 length-sorted lines, batch mode 1), a few
+times -- for a rocprofv3 kernel table (tools/c1_fp_prof.sh)."""
+import json, os, sys, tempfile, time
+import torch
+REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, os.path.join(REPO, 'tts-arabic-pytorch_amd'))
+import text
+from ttsamd import synth
+from ttsamd.config import NET_CONFIG
+from models.fastpitch.networks import FastPitch
+lines = json.load(open(os.path.join(REPO, 'tests', 'golden', 'infer_text_lines.json'), encoding='utf-8'))
+with tempfile.TemporaryDirectory() as d:
+    fp_sd = {k: torch.from_numpy(v.copy()) for k, v in synth.fastpitch_state_dict().items()}
+    torch.save({'model': fp_sd, 'config': dict(NET_CONFIG), 'symbols': list(text.symbols)}, os.path.join(d, 'fp.pth'))
+    model = FastPitch(os.path.join(d, 'fp.pth')).to('cuda:0')
+sl = sorted(lines, key=len)
+grp = [sl[k:k + 25] for k in range(0, 100, 25)]
+for it in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for g in grp:
+        model.ttmel_lines_alone(g)
+    torch.cuda.synchronize()
+    print('FastPitch, 4 ragged calls: %.1f ms' % ((time.perf_counter() - t0) * 1e3))

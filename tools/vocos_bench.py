@@ -18,3 +18,10 @@ for rnd in range(3):
         torch.cuda.synchronize(); print('vocos B=32 WINO4=%s: %.3f ms' % (mask, (time.perf_counter() - t0) * 100))
         outs[mask] = y[0] if isinstance(y, (tuple, list)) else y
 print('bit-identical:', torch.equal(outs['31'], outs['15']), 'max diff %.3e' % float((outs['31'] - outs['15']).abs().max()))
+# a T that is not a multiple of 4 (3 of 4 real batches): VocosEngine pads the frame rows to 16 bytes
+L.set_option('TTSAMD_WINO4', None)
+mel1 = torch.randn(32, 80, int(lens.max()) + 1, device=dev); lens1 = lens + 1
+for _ in range(3): voc.forward(mel1, lens1)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): voc.forward(mel1, lens1)
+torch.cuda.synchronize(); print('vocos B=32, T = %d (not a multiple of 4): %.3f ms' % (mel1.shape[2], (time.perf_counter() - t0) * 100))

@@ -720,14 +720,26 @@ int32_t launch_add_pos(float* x, const float* pos_table, int32_t pos_stride, con
     return 0;
 }
 
-// out[b] = min(lens[b] + 1, S): how far FastPitch's first conv-FF conv has to compute a row (fastpitch.hip: run_fft)
-__global__ void lens_plus1_kernel(const int64_t* __restrict__ lens, int S, int B, int64_t* __restrict__ out) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b < B) out[b] = min(lens[b] + 1, (int64_t)S);
+// out[b] = min(lens[b] + 1, W): how far FastPitch's first conv-FF conv has to compute a row (fastpitch.hip: run_fft).  W = the width of the
+// reference's padded batch: S (the encoder: the caller's ids tensor IS that batch) or, with clamp_at_max (the decoder: its rows may be wider
+// than the longest utterance -- padded to 16 bytes by the caller), the longest row: a frame past it does not exist in the reference's
+// arithmetic -- it is zero padding, not a hidden activation
+__global__ void lens_plus1_kernel(const int64_t* __restrict__ lens, int S, int B, int clamp_at_max, int64_t* __restrict__ out) {
+    __shared__ long long red[256];
+    long long mx = clamp_at_max ? 0 : (long long)S;
+    for (int b = threadIdx.x; b < B; b += 256) mx = max(mx, (long long)lens[b]);
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    const long long cap = min((long long)S, red[0]);
+    for (int b = threadIdx.x; b < B; b += 256) out[b] = min((long long)lens[b] + 1, cap);
 }
 
-int32_t launch_lens_plus1(const int64_t* lens, int32_t S, int32_t B, int64_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(lens_plus1_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, S, B, out);
+int32_t launch_lens_plus1(const int64_t* lens, int32_t S, int32_t B, int32_t clamp_at_max, int64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(lens_plus1_kernel, dim3(1), dim3(256), 0, s, lens, S, B, clamp_at_max, out);
     TTS_CHECK_HIP(hipGetLastError());
     return 0;
 }

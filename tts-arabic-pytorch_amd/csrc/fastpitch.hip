@@ -421,9 +421,11 @@ static int32_t run_fft(const FastPitch* h, const std::vector<FftLayer>& layers, 
 }
 
 // model.py:129-133; input masked on load (lens_in), hidden NOT masked
+// (lens1 = min(len + 1, longest row) or nullptr: the second conv's input past that is zero PADDING in the reference, not a hidden frame --
+// it matters when the caller's rows are wider than the longest utterance)
 static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const float* x, const int64_t* lens, int B,
                              int S, float* t0, float* t1, float* out, float* out2, float max_dur, float mul,
-                             float add, hipStream_t s, void* px3 = nullptr) {
+                             float add, hipStream_t s, void* px3 = nullptr, const int64_t* lens1 = nullptr) {
     const float* src = x;
     float* bufs[2] = {t0, t1};
     {
@@ -455,7 +457,7 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
             // LayerNorm of layer 0 in place (fp32, t0) + its octet copy into t1 (the packed input there is dead now)
             TTS_TRY(launch_layernorm_cf_octet(t0, t0, t1, h->dev + pr.ln_g[0], h->dev + pr.ln_b[0], nullptr, 0, B, pr.filter, S, s));
             // the second conv reads the octet copy; the fp32 LayerNorm output in t0 is dead, so its result goes there
-            TTS_TRY(conv(pr.convs[1], t1, t0, h->alone.load(std::memory_order_relaxed) ? lens : nullptr));
+            TTS_TRY(conv(pr.convs[1], t1, t0, h->alone.load(std::memory_order_relaxed) ? lens : lens1));
             TTS_TRY(launch_layernorm_cf(t0, t0, h->dev + pr.ln_g[1], h->dev + pr.ln_b[1], nullptr, 0, B, pr.filter, S, s));
             return launch_pred_fc(t0, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul, add, s);
         }
@@ -483,14 +485,14 @@ static int32_t run_predictor(const FastPitch* h, const Predictor& pr, const floa
             TTS_TRY(bfo3_launch_pack(x, B, pr.convs[0].cin, S, 1.f, px3, s));
             TTS_TRY(conv(pr.convs[0], px3, t0, lens));
             TTS_TRY(launch_layernorm_cf_x3(t0, t0, px3, h->dev + pr.ln_g[0], h->dev + pr.ln_b[0], nullptr, 0, B, pr.filter, S, s));
-            TTS_TRY(conv(pr.convs[1], px3, t1, h->alone.load(std::memory_order_relaxed) ? lens : nullptr));
+            TTS_TRY(conv(pr.convs[1], px3, t1, h->alone.load(std::memory_order_relaxed) ? lens : lens1));
             TTS_TRY(launch_layernorm_cf(t1, t1, h->dev + pr.ln_g[1], h->dev + pr.ln_b[1], nullptr, 0, B, pr.filter, S, s));
             return launch_pred_fc(t1, h->dev + pr.fc_w, h->dev + pr.fc_b, lens, B, pr.filter, S, out, out2, max_dur, mul, add, s);
         }
     }
     for (size_t i = 0; i < pr.convs.size(); ++i) {
         float* dst = bufs[i & 1];
-        TTS_TRY(run_conv(h, pr.convs[i], src, dst, nullptr, B, S, (i == 0 || h->alone.load(std::memory_order_relaxed)) ? lens : nullptr, 1, s));
+        TTS_TRY(run_conv(h, pr.convs[i], src, dst, nullptr, B, S, (i == 0 || h->alone.load(std::memory_order_relaxed)) ? lens : lens1, 1, s));
         TTS_TRY(launch_layernorm_cf(dst, dst, h->dev + pr.ln_g[i], h->dev + pr.ln_b[i], nullptr, 0, B, pr.filter, S, s));
         src = dst;
     }
@@ -555,21 +557,22 @@ int32_t fastpitch_encode(const FastPitch* h, const int64_t* ids, int32_t B, int3
     const float* spk = (c.n_speakers > 1 && h->spk_emb >= 0) ? h->dev + h->spk_emb + (int64_t)speaker * d : nullptr;
     TTS_TRY(launch_embed(ids, h->dev + h->word_emb, h->dev + h->pos_enc, h->pos_cap, spk, c.padding_idx, c.n_symbols, B, L, d, x,
                          w.lens, s));
-    if (B >= 2) {
-        TTS_TRY(launch_lens_plus1(w.lens, L, B, w.f.lens1, s));
+    // (one frame past a row's end is what a k = 3 conv reads: the ragged schedule is built for the reference's kernel sizes)
+    if (B >= 2 && c.in_fft_kernel == 3 && c.dur_kernel == 3 && c.pitch_kernel == 3 && (!c.energy_conditioning || c.energy_kernel == 3)) {
+        TTS_TRY(launch_lens_plus1(w.lens, L, B, /*clamp_at_max=*/0, w.f.lens1, s));
         w.f.ragged = true;
     }
     TTS_TRY(run_fft(h, h->enc, c.in_fft_d_head, x, w.lens, B, L, w.f, s));
     // durations (model.py:367-368)
-    TTS_TRY(run_predictor(h, h->dur, x, w.lens, B, L, w.p0, w.p1, w.log_dur, dur_pred, max_duration, 1.f, 0.f, s, w.f.o3));
+    TTS_TRY(run_predictor(h, h->dur, x, w.lens, B, L, w.p0, w.p1, w.log_dur, dur_pred, max_duration, 1.f, 0.f, s, w.f.o3, w.f.ragged ? w.f.lens1 : nullptr));
     // pitch (model.py:371-386); pitch_trf = mul*p + add (networks.py:38-42)
-    TTS_TRY(run_predictor(h, h->pitch, x, w.lens, B, L, w.p0, w.p1, pitch_pred, nullptr, 0.f, pitch_mul, pitch_add, s, w.f.o3));
+    TTS_TRY(run_predictor(h, h->pitch, x, w.lens, B, L, w.p0, w.p1, pitch_pred, nullptr, 0.f, pitch_mul, pitch_add, s, w.f.o3, w.f.ragged ? w.f.lens1 : nullptr));
     TTS_TRY(launch_scalar_emb_add(x, pitch_tgt ? pitch_tgt : pitch_pred, h->dev + h->pitch_emb_w,
                                   h->dev + h->pitch_emb_b, B, d, L, c.pitch_emb_kernel, s));
     // energy (model.py:389-399)
     if (c.energy_conditioning) {
         if (energy_pred)
-            TTS_TRY(run_predictor(h, h->energy, x, w.lens, B, L, w.p0, w.p1, energy_pred, nullptr, 0.f, 1.f, 0.f, s, w.f.o3));
+            TTS_TRY(run_predictor(h, h->energy, x, w.lens, B, L, w.p0, w.p1, energy_pred, nullptr, 0.f, 1.f, 0.f, s, w.f.o3, w.f.ragged ? w.f.lens1 : nullptr));
         TTS_TRY(launch_scalar_emb_add(x, energy_tgt ? energy_tgt : energy_pred, h->dev + h->energy_emb_w,
                                       h->dev + h->energy_emb_b, B, d, L, c.energy_emb_kernel, s));
     }
@@ -613,8 +616,8 @@ int32_t fastpitch_decode(const FastPitch* h, float* x, const int64_t* dec_lens, 
     SmallBatchScope small_f32(B);
     // decoder input = len_regulated + pos_emb*mask (transformer.py:215-219, embed_input=False)
     TTS_TRY(launch_add_pos(x, h->dev + h->pos_dec, h->pos_cap, dec_lens, B, c.d_model, T, s));
-    if (B >= 2) {
-        TTS_TRY(launch_lens_plus1(dec_lens, T, B, w.lens1, s));
+    if (B >= 2 && c.out_fft_kernel == 3) {
+        TTS_TRY(launch_lens_plus1(dec_lens, T, B, /*clamp_at_max=*/1, w.lens1, s));     // t_max may be the caller's 16-byte-padded row width
         w.ragged = true;
     }
     TTS_TRY(run_fft(h, h->dec, c.out_fft_d_head, x, dec_lens, B, T, w, s));

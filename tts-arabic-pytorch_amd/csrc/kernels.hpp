@@ -59,7 +59,7 @@ int32_t launch_regulate_gather(const float* enc, const int64_t* reps, const floa
                                int32_t L, int32_t C, int32_t T, float* out, int32_t* idx, hipStream_t s);
 
 // x[b][c][t] += pos[t][c] * (t < lens[b])
-int32_t launch_lens_plus1(const int64_t* lens, int32_t S, int32_t B, int64_t* out, hipStream_t s);   // out[b] = min(lens[b] + 1, S)
+int32_t launch_lens_plus1(const int64_t* lens, int32_t S, int32_t B, int32_t clamp_at_max, int64_t* out, hipStream_t s);   // out[b] = min(lens[b] + 1, clamp_at_max ? max_b lens[b] : S)
 int32_t launch_add_pos(float* x, const float* pos_table, int32_t pos_stride, const int64_t* lens, int32_t B, int32_t C,
                        int32_t S, hipStream_t s);
 

@@ -154,6 +154,10 @@ class FastPitchEngine:
         self.handle = handle
         self.ws = _Workspace()
         self._alone = False
+        # rows padded to 16 bytes (see infer): the library's ragged schedule handles the reference's kernel size 3 only
+        self._pad_ok = all(int(c[k]) == 3 for k in ('in_fft_conv1d_kernel_size', 'out_fft_conv1d_kernel_size', 'dur_predictor_kernel_size',
+                                                    'pitch_predictor_kernel_size')) and \
+            (not c['energy_conditioning'] or int(c['energy_predictor_kernel_size']) == 3)
 
     def __del__(self):
         if getattr(self, 'handle', None):
@@ -175,9 +179,17 @@ class FastPitchEngine:
             self._alone = bool(alone)
         dev = self.device
         ids = torch.as_tensor(ids).to(device=dev, dtype=torch.int64).contiguous()
-        B, Lt = ids.shape
+        B, Lt0 = ids.shape
         d = self.d_model
         dur_tgt, pitch_tgt, energy_tgt = _f32(dur_tgt, dev), _f32(pitch_tgt, dev), _f32(energy_tgt, dev)
+        # Batches: the DECODER's frame rows padded to a multiple of 4 (16 bytes).  The conv engine's fast paths -- the Winograd F(4,3) kernel,
+        # the float4 row epilogue -- need 16-byte-aligned rows, and a real batch's longest utterance is a multiple of 4 one time in four (config
+        # 1: three of the four FastPitch calls ran the decoder conv-FF on the direct kernel's per-lane epilogue, 2x the time).  The decoder
+        # takes the batch's length from dec_lens, not from the row width (lens_plus1_kernel), so the extra columns are plain padding; mel is
+        # returned as a view of the un-padded shape.  (Batch 1 keeps its exact shape: one launch more would cost what alignment gains; the
+        # bf16 octet path has no ragged schedule; the encoder's rows stay as given -- the caller's ids tensor IS the reference's padded batch.)
+        pad = B >= 2 and self._pad_ok and get_precision() != 'bf16'
+        Lt = Lt0
         enc = torch.empty(B, d, Lt, dtype=torch.float32, device=dev)
         dur_pred = torch.empty(B, Lt, dtype=torch.float32, device=dev)
         pitch_pred = torch.empty(B, 1, Lt, dtype=torch.float32, device=dev)
@@ -194,9 +206,10 @@ class FastPitchEngine:
                                                 _ptr(energy_pred), _ptr(reps), _ptr(dec_lens), _ptr(ws), nb, _stream()),
                     'fastpitch_encode')
             if lens_hook is None:
-                t_max = int(dec_lens.max().item())      # the reference syncs here too (model.py:76)
+                t_max0 = int(dec_lens.max().item())     # the reference syncs here too (model.py:76)
             else:
-                t_max = int(max(lens_hook(dec_lens), default=0))
+                t_max0 = int(max(lens_hook(dec_lens), default=0))
+            t_max = (t_max0 + 3) & ~3 if pad else t_max0
             x = torch.empty(B, d, t_max, dtype=torch.float32, device=dev)
             idx = torch.empty(B, t_max, dtype=torch.int32, device=dev) if return_idx else None
             mel = torch.empty(B, self.n_mel, t_max, dtype=torch.float32, device=dev)
@@ -207,6 +220,9 @@ class FastPitchEngine:
                 ws = self.ws.get(nb, dev)
                 L.check(lib.ttsamd_fastpitch_decode(self.handle, _ptr(x), _ptr(dec_lens), B, t_max, _ptr(mel), _ptr(ws), nb,
                                                     _stream()), 'fastpitch_decode')
+        if t_max != t_max0:
+            mel = mel[:, :, :t_max0]
+            idx = None if idx is None else idx[:, :t_max0]
         out = (mel, dec_lens, dur_pred, pitch_pred, energy_pred)
         return out + (idx,) if return_idx else out
 
@@ -291,21 +307,26 @@ class VocosEngine:
     def forward(self, mel, lens=None, denoise=0.0):
         """mel [B,80,T] on the GPU, lens int64 [B] or None -> wave [B, 256*T] (zeros past 256*lens[b])."""
         mel = _f32(mel, self.device)
-        B, M, T = mel.shape
+        B, M, T0 = mel.shape
         assert M == self.n_mels
         if lens is None:
-            lens = torch.full((B,), T, dtype=torch.int64, device=self.device)
+            lens = torch.full((B,), T0, dtype=torch.int64, device=self.device)
         lens = lens.to(device=self.device, dtype=torch.int64).contiguous()
+        if T0 == 0:
+            return torch.zeros(B, 0, dtype=torch.float32, device=self.device)
+        # frame rows padded to a multiple of 4 (16 bytes): the conv engine's fast paths (the k = 1 GEMM route, float4 row epilogues) need aligned
+        # rows and a real T is a multiple of 4 one time in four; every layer reads frames >= lens[b] as zero, so the extra columns change nothing
+        T = (T0 + 3) & ~3
+        if T != T0:
+            mel = torch.nn.functional.pad(mel, (0, T - T0))
         wave = torch.zeros(B, self.hop * T, dtype=torch.float32, device=self.device)
-        if T == 0:
-            return wave
         bias = self.bias_vec().reshape(-1) if denoise != 0 else None
         with torch.cuda.device(self.device):
             nb = self.lib.ttsamd_vocos_workspace_bytes(self.handle, B, T)
             ws = self.ws.get(nb, self.device)
             L.check(self.lib.ttsamd_vocos_forward(self.handle, _ptr(mel), _ptr(lens), B, T, float(denoise), _ptr(bias),
                                                   _ptr(wave), _ptr(ws), nb, _stream()), 'vocos_forward')
-        return wave
+        return wave if T == T0 else wave[:, :self.hop * T0]
 
 
 class Tacotron2Engine:
