@@ -179,7 +179,10 @@ int32_t ttsamd_length_regulate(const float* enc, const int64_t* reps, int32_t ba
                                float* out, int32_t* idx, void* stream);
 
 /* Phase B (model.py:405-408): decoder FFT + proj.  x [B][d_model][t_max] channel-first
- * (output of ttsamd_length_regulate; clobbered), dec_lens int64 [B], mel [B][80][t_max]. */
+ * (output of ttsamd_length_regulate; clobbered), dec_lens int64 [B], mel [B][80][t_max].
+ * t_max is the ROW WIDTH of x and mel and may exceed max(dec_lens): the length of the reference's padded batch is taken from
+ * dec_lens (batches of 2 and more), the extra columns are padding.  Pass a multiple of 4 for batches: the Winograd and float4-epilogue
+ * paths of the conv engine need 16-byte-aligned rows (ttsamd/engine.py: FastPitchEngine.infer rounds t_max up and returns a view). */
 int32_t ttsamd_fastpitch_decode(void* handle, float* x, const int64_t* dec_lens, int32_t batch,
                                 int32_t t_max, float* mel, void* workspace,
                                 int64_t workspace_bytes, void* stream);
